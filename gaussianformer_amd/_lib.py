@@ -1,0 +1,78 @@
+"""ctypes binding of ``libgf_hip.so`` (C ABI declared in ``include/gf_hip.h``).
+
+There is NO fallback: if the library is missing or a call fails, a ``RuntimeError`` is
+raised.  Tensors cross the boundary as raw device pointers + sizes; the stream is torch's
+current HIP stream.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgf_hip.so")
+
+GF_ABI_VERSION = 1
+GF_SPLAT_BASE, GF_SPLAT_PROB = 0, 1
+GF_NUM_CHANNELS = 18
+GF_PTS_AUTO, GF_PTS_ASSUME_DENSE, GF_PTS_GENERAL, GF_FAST_EXP = 0, 1, 2, 4
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/gf_hip.h declares
+SIGNATURES = {
+    "gf_abi_version": (_i, []),
+    "gf_last_error": (ctypes.c_char_p, []),
+    "gf_splat_workspace_bytes": (_sz, [_i] * 5),
+    "gf_splat_state_bytes": (_sz, []),
+    "gf_splat_forward": (_i, [_i] * 9 + [_vp] * 13 + [_vp, _sz, _vp]),
+    "gf_splat_backward": (_i, [_i] * 9 + [_vp] * 20 + [_vp, _sz, _vp]),
+    "gf_splat_box_volumes": (_i, [_i] * 5 + [_vp] * 5),
+    "gf_daf_forward": (_i, [_i] * 7 + [_vp] * 7),
+    "gf_daf_backward": (_i, [_i] * 7 + [_vp] * 10),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. "
+            "Run `python -m gaussianformer_amd.build` (needs hipcc; cross-compiles gfx950 without a GPU). "
+            "There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gf_abi_version() != GF_ABI_VERSION:
+        raise RuntimeError(f"libgf_hip.so ABI {lib.gf_abi_version()} != expected {GF_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (``None`` -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "gaussianformer_amd ops run on MI355X only (HIP kernels); got a CPU tensor. "
+                "There is no CPU fallback -- move the inputs to the GPU.")
+
+
+def current_stream(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,64 @@
+"""Builds ``libgf_hip.so`` (the C-ABI library, ``include/gf_hip.h``) with hipcc for gfx950.
+
+In-tree build: the ``.so`` lands next to the sources in ``gaussianformer_amd/csrc`` so it
+travels with a repo snapshot to the GPU box.  hipcc cross-compiles without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_NAME = "libgf_hip.so"
+SOURCES = ["gf_api.hip", "splat_fwd.hip", "splat_bwd.hip", "daf.hip"]
+HEADERS = ["gf_common.hpp", os.path.join("..", "..", "include", "gf_hip.h")]
+ARCH = "gfx950"
+
+
+def lib_path():
+    return os.path.join(CSRC, LIB_NAME)
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _stale():
+    lib = lib_path()
+    if not os.path.exists(lib):
+        return True
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared library.  Returns its path."""
+    if not force and not _stale():
+        return lib_path()
+    objs = []
+    common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+              "-Wall", "-Wno-unused-function"]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path()] + objs
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc link failed:\n{r.stdout}")
+    return lib_path()
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,119 @@
+// gf_common.hpp -- shared device/host helpers for libgf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gf_hip.h"
+
+namespace gf {
+
+// ---- geometry constants -------------------------------------------------------------
+constexpr int kC = GF_NUM_CHANNELS;  // 18 semantic channels
+constexpr int kTile = 4;             // a tile is 4x4 voxel columns x all z; a brick is 4x4x4
+constexpr int kSuper = 20;           // a supertile is 20x20 voxel columns = 5x5 tiles
+constexpr int kTilesPerSuperAxis = kSuper / kTile;
+constexpr int kTilesPerSuper = kTilesPerSuperAxis * kTilesPerSuperAxis;
+constexpr int kRecDwords = 32;       // packed per-Gaussian record, 128 B
+
+// record layout (dwords)
+//  0..2 mean xyz | 3 opacity | 4..9 cov (xx,yy,zz,xy,yz,xz) | 10 box lo | 11 box hi (excl.)
+//  12..29 semantics[18] | 30 prob: (2pi)^-1.5 * sqrt(det) | 31 unused
+constexpr int kRecMean = 0, kRecOpa = 3, kRecCov = 4, kRecLo = 10, kRecHi = 11, kRecSem = 12,
+              kRecKdet = 30;
+
+// packed voxel coordinate: x | y<<11 | z<<22   (H,W <= 2047, D <= 1023)
+__host__ __device__ __forceinline__ uint32_t pack3(int x, int y, int z)
+{
+    return (uint32_t)x | ((uint32_t)y << 11) | ((uint32_t)z << 22);
+}
+__host__ __device__ __forceinline__ int ux(uint32_t p) { return (int)(p & 2047u); }
+__host__ __device__ __forceinline__ int uy(uint32_t p) { return (int)((p >> 11) & 2047u); }
+__host__ __device__ __forceinline__ int uz(uint32_t p) { return (int)(p >> 22); }
+
+// workspace carve-up (all sections 256-B aligned)
+struct SplatWorkspace {
+    uint32_t *flags;        // [64]  flags[0] = "pts is not the dense grid"
+    float *records;         // [P][32]
+    uint2 *boxes;           // [P]  (lo, hi) packed
+    unsigned long long *bitmask;  // [nsuper][nwords]
+    int *voxel2pts;         // [V]   (backward, general pts only)
+    uint2 *items;           // [item_cap] backward work items (gaussian, chunk)
+    uint32_t *item_count;   // [1] (inside flags block: flags[16])
+    int nwords, nsx, nsy, nsuper;
+    size_t item_cap;
+    size_t total_bytes;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+constexpr int kBwdMaxChunks = 32;  // a Gaussian's box is split into at most this many work items
+
+inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, int D)
+{
+    (void)N;
+    SplatWorkspace ws;
+    ws.nwords = (P + 63) / 64;
+    ws.nsx = (H + kSuper - 1) / kSuper;
+    ws.nsy = (W + kSuper - 1) / kSuper;
+    ws.nsuper = ws.nsx * ws.nsy;
+    ws.item_cap = (size_t)(P > 0 ? P : 1) * kBwdMaxChunks;
+    char *p = (char *)base;
+    size_t off = 0;
+    ws.flags = (uint32_t *)(p + off); off += 256;
+    ws.item_count = ws.flags + 16;
+    ws.records = (float *)(p + off); off += align256((size_t)P * kRecDwords * 4);
+    ws.boxes = (uint2 *)(p + off); off += align256((size_t)P * 8);
+    ws.bitmask = (unsigned long long *)(p + off); off += align256((size_t)ws.nsuper * ws.nwords * 8);
+    ws.voxel2pts = (int *)(p + off); off += align256((size_t)H * W * D * 4);
+    ws.items = (uint2 *)(p + off); off += align256(ws.item_cap * 8);
+    ws.total_bytes = off;
+    return ws;
+}
+
+// ---- error reporting ----------------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define GF_CHECK_ARG(cond, msg)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            gf::set_error("%s: %s", __func__, msg); \
+            return GF_EINVAL;                  \
+        }                                      \
+    } while (0)
+
+#define GF_CHECK_LAUNCH()                                                      \
+    do {                                                                       \
+        hipError_t e_ = hipGetLastError();                                     \
+        if (e_ != hipSuccess) {                                                \
+            gf::set_error("%s: HIP launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return GF_ELAUNCH;                                                 \
+        }                                                                      \
+    } while (0)
+
+// ---- wave-level helpers (wave64) ------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int mbcnt(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// DPP add-reduce over the 64 lanes; the total ends up in lane 63 and is broadcast through
+// v_readlane.  row_shr 1,2,4(3 steps via 1+2, then 3), row_bcast15, row_bcast31.
+__device__ __forceinline__ float wave_sum(float v)
+{
+    // within each row of 16: inclusive prefix by row_shr, last lane of the row has the row sum
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)); // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true)); // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)); // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true)); // row_shr:8
+    // lane 15 of each row now holds the row sum; combine rows
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true)); // row_bcast:15 -> rows 1,3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true)); // row_bcast:31 -> rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+}  // namespace gf

@@ -1,0 +1,330 @@
+// splat_bwd.hip -- Gaussian -> voxel splat, backward, for gfx950 (MI355X).
+//
+// The reference (model/head/localagg/src/backward.cu:23-103) runs ONE THREAD per Gaussian
+// over that Gaussian's box voxels: the appended whole-grid "empty" Gaussian is 640 000 x 18
+// serial iterations on a single lane.  Here the work is cut into items of ~4096 voxels
+// (a Gaussian's box is split into at most 32 items), one wave per item, lanes striding
+// over the item's voxels with z fastest (consecutive lanes read consecutive 72-B out_grad
+// rows).  The Gaussian's parameters are wave-uniform (SGPRs); each lane keeps the 28
+// partial gradients in VGPRs and the wave reduces them once per item with DPP adds.
+// Single-item Gaussians store their gradients; split ones combine with fp32 atomics.
+//
+// Launches: [voxel->point map (arbitrary pts only)] -> item table -> gradient kernel.
+#include "gf_common.hpp"
+
+namespace gf {
+
+constexpr int kBwdChunk = 4096;
+
+struct BwdArgs {
+    const float *pts;
+    const int *points_int;
+    const float *means3D;
+    const int *means_int;
+    const float *opacity;
+    const float *semantics;
+    const int *radii;
+    const float *cov3D;
+    const float *logits;       // prob only
+    const float *bin_logits;   // prob only
+    const float *probability;  // prob only
+    const float *out_grad;     // [N,18]
+    const float *bin_grad;     // prob only, may be null
+    const float *dens_grad;    // prob only, may be null
+    float *means_grad;
+    float *opa_grad;
+    float *sem_grad;
+    float *cov_grad;
+    const uint32_t *state;
+    int *voxel2pts;
+    uint2 *items;
+    uint32_t *item_count;
+    int P, N, H, W, D, per_axis, force_general, assume_dense;
+};
+
+__device__ __forceinline__ void box_of(const BwdArgs &a, int g, int lo[3], int hi[3])
+{
+    const int m0 = a.means_int[3 * g], m1 = a.means_int[3 * g + 1], m2 = a.means_int[3 * g + 2];
+    int r0, r1, r2;
+    if (a.per_axis) {
+        r0 = a.radii[3 * g]; r1 = a.radii[3 * g + 1]; r2 = a.radii[3 * g + 2];
+    } else {
+        r0 = r1 = r2 = a.radii[g];
+    }
+    lo[0] = min(a.H, max(0, m0 - r0)); hi[0] = min(a.H, max(0, m0 + r0 + 1));
+    lo[1] = min(a.W, max(0, m1 - r1)); hi[1] = min(a.W, max(0, m1 + r1 + 1));
+    lo[2] = min(a.D, max(0, m2 - r2)); hi[2] = min(a.D, max(0, m2 + r2 + 1));
+}
+
+__device__ __forceinline__ bool pts_are_dense(const BwdArgs &a)
+{
+    if (a.force_general) return false;
+    if (a.assume_dense) return true;
+    return a.state != nullptr && a.state[0] == 0u;
+}
+
+// voxel2pts = -1, then voxel2pts[voxel(n)] = n with the highest point index winning
+// (BACKWARD::preprocessCUDA, model/head/localagg/src/backward.cu:8-20, is a racy
+// last-writer-wins scatter; any winner is a legal outcome, we pick a deterministic one).
+__global__ __launch_bounds__(256) void gf_v2p_fill_kernel(BwdArgs a)
+{
+    if (pts_are_dense(a)) return;
+    const size_t V = (size_t)a.H * a.W * a.D;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) a.voxel2pts[i] = -1;
+}
+
+__global__ __launch_bounds__(256) void gf_v2p_scatter_kernel(BwdArgs a)
+{
+    if (pts_are_dense(a)) return;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.N) return;
+    const int x = a.points_int[3 * (size_t)n], y = a.points_int[3 * (size_t)n + 1], z = a.points_int[3 * (size_t)n + 2];
+    if (x < 0 || x >= a.H || y < 0 || y >= a.W || z < 0 || z >= a.D) return;
+    atomicMax(a.voxel2pts + ((size_t)x * a.W + y) * a.D + z, n);
+}
+
+// One thread per Gaussian: how many work items its box needs; zero the gradients of
+// Gaussians whose items combine atomically (and of empty ones); append the items.
+__global__ __launch_bounds__(256) void gf_bwd_items_kernel(BwdArgs a)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.P) return;
+    int lo[3], hi[3];
+    box_of(a, g, lo, hi);
+    const int nx = hi[0] - lo[0], ny = hi[1] - lo[1], nz = hi[2] - lo[2];
+    const uint32_t vol = (nx > 0 && ny > 0 && nz > 0) ? (uint32_t)nx * (uint32_t)ny * (uint32_t)nz : 0u;
+    const uint32_t n = vol == 0u ? 0u : min((uint32_t)kBwdMaxChunks, (vol + kBwdChunk - 1) / kBwdChunk);
+    if (n != 1u) {
+        a.means_grad[3 * g] = 0.f; a.means_grad[3 * g + 1] = 0.f; a.means_grad[3 * g + 2] = 0.f;
+        a.opa_grad[g] = 0.f;
+        for (int ch = 0; ch < kC; ++ch) a.sem_grad[(size_t)kC * g + ch] = 0.f;
+        for (int k = 0; k < 6; ++k) a.cov_grad[6 * g + k] = 0.f;
+    }
+    if (n > 0u) {
+        const uint32_t base = atomicAdd(a.item_count, n);
+        for (uint32_t c = 0; c < n; ++c) a.items[base + c] = make_uint2((uint32_t)g, c | (n << 16));
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
+{
+    const int lane = lane_id();
+    const int wave_global = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int nwaves = (int)gridDim.x * 4;
+    const int count = (int)*a.item_count;
+    const bool dense = pts_are_dense(a);
+
+    for (int it = wave_global; it < count; it += nwaves) {
+        const uint2 item = a.items[it];
+        const int g = (int)item.x;
+        const int c = (int)(item.y & 0xFFFFu), n = (int)(item.y >> 16);
+        int lo[3], hi[3];
+        box_of(a, g, lo, hi);
+        const int ny = hi[1] - lo[1], nz = hi[2] - lo[2];
+        const int vol = (hi[0] - lo[0]) * ny * nz;
+        const int cs = (((vol + n - 1) / n) + 63) & ~63;
+        const int start = c * cs;
+        const int end = min(vol, start + cs);
+
+        // wave-uniform Gaussian parameters
+        const float mx = a.means3D[3 * g], my = a.means3D[3 * g + 1], mz = a.means3D[3 * g + 2];
+        const float *cv = a.cov3D + 6 * (size_t)g;
+        const float c1x = cv[0], c1y = cv[1], c1z = cv[2], c2x = cv[3], c2y = cv[4], c2z = cv[5];
+        const float opa = a.opacity[g];
+        float sem[kC];
+#pragma unroll
+        for (int ch = 0; ch < kC; ++ch) sem[ch] = a.semantics[(size_t)kC * g + ch];
+        float deter = 1.f, kdet = 0.f;
+        if (VARIANT == GF_SPLAT_PROB) {
+            // model/head/localagg_prob/src/backward.cu:78-79
+            deter = c1x * c1y * c1z + 2 * c2x * c2y * c2z - c1x * c2y * c2y - c1y * c2z * c2z - c1z * c2x * c2x;
+            kdet = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f);
+        }
+
+        float mg0 = 0.f, mg1 = 0.f, mg2 = 0.f, og = 0.f, dg = 0.f;
+        float cg0 = 0.f, cg1 = 0.f, cg2 = 0.f, cg3 = 0.f, cg4 = 0.f, cg5 = 0.f;
+        float sg[kC];
+#pragma unroll
+        for (int ch = 0; ch < kC; ++ch) sg[ch] = 0.f;
+
+        // lane's first voxel of the item, decoded once; then advanced by 64 per iteration
+        int i = start + lane;
+        int z = i % nz;
+        int t = i / nz;
+        int y = t % ny;
+        int x = t / ny;
+        const int rz = 64 % nz, qz = 64 / nz;
+        const int ry = qz % ny, qx = qz / ny;
+
+        for (; i < end; i += 64) {
+            const size_t v = ((size_t)(lo[0] + x) * a.W + (lo[1] + y)) * a.D + (lo[2] + z);
+            const int p = dense ? (int)v : a.voxel2pts[v];
+            if (p >= 0) {
+                const float dx = mx - a.pts[3 * (size_t)p], dy = my - a.pts[3 * (size_t)p + 1], dz = mz - a.pts[3 * (size_t)p + 2];
+                float power = c1x * dx * dx + c1y * dy * dy + c1z * dz * dz;
+                power = -0.5f * power - (c2x * dx * dy + c2y * dy * dz + c2z * dx * dz);
+                const float e = expf(power);
+                float dL[kC];
+                const float2 *row = reinterpret_cast<const float2 *>(a.out_grad + (size_t)p * kC);
+#pragma unroll
+                for (int q = 0; q < kC / 2; ++q) {
+                    const float2 tq = row[q];
+                    dL[2 * q] = tq.x; dL[2 * q + 1] = tq.y;
+                }
+                const float sx = c1x * dx + c2x * dy + c2z * dz;  // (Sigma^-1 d)
+                const float sy = c2x * dx + c1y * dy + c2y * dz;
+                const float sz = c2z * dx + c2y * dy + c1z * dz;
+                if (VARIANT == GF_SPLAT_BASE) {
+                    // model/head/localagg/src/backward.cu:72-87, with the channel sum factored
+                    // out of the six covariance and three mean accumulators.
+                    float S = 0.f;
+                    const float oe = opa * e;
+#pragma unroll
+                    for (int ch = 0; ch < kC; ++ch) {
+                        S += sem[ch] * dL[ch];
+                        sg[ch] += oe * dL[ch];
+                    }
+                    const float T = e * S;
+                    og += T;
+                    const float K = opa * T;
+                    cg0 += -0.5f * K * dx * dx; cg1 += -0.5f * K * dy * dy; cg2 += -0.5f * K * dz * dz;
+                    cg3 += -K * dx * dy; cg4 += -K * dy * dz; cg5 += -K * dx * dz;
+                    mg0 -= K * sx; mg1 -= K * sy; mg2 -= K * sz;
+                } else {
+                    // model/head/localagg_prob/src/backward.cu:76-107
+                    const float prob = kdet * e;
+                    const float psum = a.probability[p];
+                    float prob_grad = 0.f;
+                    if ((double)psum > 1e-9) {
+                        const float2 *lrow = reinterpret_cast<const float2 *>(a.logits + (size_t)p * kC);
+                        const float coef = prob * opa / psum;
+                        float Asum = 0.f;
+#pragma unroll
+                        for (int q = 0; q < kC / 2; ++q) {
+                            const float2 lq = lrow[q];
+                            sg[2 * q] += dL[2 * q] * coef;
+                            sg[2 * q + 1] += dL[2 * q + 1] * coef;
+                            Asum += dL[2 * q] * (sem[2 * q] - lq.x);
+                            Asum += dL[2 * q + 1] * (sem[2 * q + 1] - lq.y);
+                        }
+                        prob_grad = Asum * opa / psum;
+                        og += Asum * prob / psum;
+                    }
+                    float power_grad = prob_grad * kdet;
+                    if (a.bin_grad) power_grad += (1 - a.bin_logits[p]) / (1 - e + 1e-9f) * a.bin_grad[p];
+                    if (a.dens_grad) power_grad += a.dens_grad[p];
+                    dg += prob_grad * prob / 2 / deter;
+                    const float pg = power_grad * e;
+                    mg0 -= pg * sx; mg1 -= pg * sy; mg2 -= pg * sz;
+                    cg0 += pg * (-0.5f * dx * dx); cg1 += pg * (-0.5f * dy * dy); cg2 += pg * (-0.5f * dz * dz);
+                    cg3 += pg * (-dx * dy); cg4 += pg * (-dy * dz); cg5 += pg * (-dx * dz);
+                }
+            }
+            // advance (x, y, z) by 64 voxels in z-fastest order
+            z += rz;
+            int carry = 0;
+            if (z >= nz) { z -= nz; carry = 1; }
+            y += ry + carry;
+            carry = 0;
+            if (y >= ny) { y -= ny; carry = 1; }
+            x += qx + carry;
+        }
+
+        // reduce across the wave
+        mg0 = wave_sum(mg0); mg1 = wave_sum(mg1); mg2 = wave_sum(mg2);
+        og = wave_sum(og);
+        cg0 = wave_sum(cg0); cg1 = wave_sum(cg1); cg2 = wave_sum(cg2);
+        cg3 = wave_sum(cg3); cg4 = wave_sum(cg4); cg5 = wave_sum(cg5);
+#pragma unroll
+        for (int ch = 0; ch < kC; ++ch) sg[ch] = wave_sum(sg[ch]);
+        if (VARIANT == GF_SPLAT_PROB) {
+            dg = wave_sum(dg);
+            // deter_grad terms, model/head/localagg_prob/src/backward.cu:102-107
+            cg0 += dg * (c1y * c1z - c2y * c2y);
+            cg1 += dg * (c1x * c1z - c2z * c2z);
+            cg2 += dg * (c1x * c1y - c2x * c2x);
+            cg3 += 2 * dg * (c2y * c2z - c1z * c2x);
+            cg4 += 2 * dg * (c2x * c2z - c1x * c2y);
+            cg5 += 2 * dg * (c2x * c2y - c1y * c2z);
+        }
+        if (lane == 0) {
+            float *pm = a.means_grad + 3 * (size_t)g;
+            float *pc = a.cov_grad + 6 * (size_t)g;
+            float *ps = a.sem_grad + (size_t)kC * g;
+            if (n == 1) {
+                pm[0] = mg0; pm[1] = mg1; pm[2] = mg2;
+                a.opa_grad[g] = og;
+                pc[0] = cg0; pc[1] = cg1; pc[2] = cg2; pc[3] = cg3; pc[4] = cg4; pc[5] = cg5;
+#pragma unroll
+                for (int ch = 0; ch < kC; ++ch) ps[ch] = sg[ch];
+            } else {
+                unsafeAtomicAdd(pm, mg0); unsafeAtomicAdd(pm + 1, mg1); unsafeAtomicAdd(pm + 2, mg2);
+                unsafeAtomicAdd(a.opa_grad + g, og);
+                unsafeAtomicAdd(pc, cg0); unsafeAtomicAdd(pc + 1, cg1); unsafeAtomicAdd(pc + 2, cg2);
+                unsafeAtomicAdd(pc + 3, cg3); unsafeAtomicAdd(pc + 4, cg4); unsafeAtomicAdd(pc + 5, cg5);
+#pragma unroll
+                for (int ch = 0; ch < kC; ++ch) unsafeAtomicAdd(ps + ch, sg[ch]);
+            }
+        }
+    }
+}
+
+}  // namespace gf
+
+extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
+                                 int W, int D, const float *pts, const int *points_int,
+                                 const float *means3D, const int *means3D_int, const float *opacity,
+                                 const float *semantics, const int *radii, const float *cov3D,
+                                 const float *logits, const float *bin_logits, const float *density,
+                                 const float *probability, const float *logits_grad,
+                                 const float *bin_logits_grad, const float *density_grad,
+                                 float *means3D_grad, float *opacity_grad, float *semantics_grad,
+                                 float *cov3D_grad, const void *state, void *workspace,
+                                 size_t workspace_bytes, void *stream_)
+{
+    using namespace gf;
+    (void)density;
+    hipStream_t stream = (hipStream_t)stream_;
+    GF_CHECK_ARG(variant == GF_SPLAT_BASE || variant == GF_SPLAT_PROB, "unknown variant");
+    GF_CHECK_ARG(C == kC, "only 18 semantic channels are supported (NUM_CHANNELS)");
+    GF_CHECK_ARG(P >= 0 && N >= 0, "negative size");
+    GF_CHECK_ARG(H > 0 && W > 0 && D > 0 && H <= 2047 && W <= 2047 && D <= 1023, "grid size out of range");
+    GF_CHECK_ARG((long long)H * W * D < (1ll << 31), "grid too large");
+    if (P == 0) return GF_OK;
+    GF_CHECK_ARG(means3D && means3D_int && opacity && semantics && radii && cov3D, "null Gaussian pointer");
+    GF_CHECK_ARG(means3D_grad && opacity_grad && semantics_grad && cov3D_grad, "null gradient output");
+    GF_CHECK_ARG(N == 0 || (pts && points_int && logits_grad), "null point/grad pointer");
+    GF_CHECK_ARG(variant == GF_SPLAT_BASE || N == 0 || (logits && bin_logits && probability),
+                 "prob variant needs the forward outputs");
+    GF_CHECK_ARG(workspace != nullptr, "null workspace");
+    SplatWorkspace ws = carve_workspace(workspace, P, N, H, W, D);
+    if (workspace_bytes < ws.total_bytes) {
+        set_error("gf_splat_backward: workspace too small (%zu < %zu)", workspace_bytes, ws.total_bytes);
+        return GF_EWORKSPACE;
+    }
+    BwdArgs a;
+    a.pts = pts; a.points_int = points_int; a.means3D = means3D; a.means_int = means3D_int; a.opacity = opacity;
+    a.semantics = semantics; a.radii = radii; a.cov3D = cov3D; a.logits = logits; a.bin_logits = bin_logits;
+    a.probability = probability; a.out_grad = logits_grad; a.bin_grad = bin_logits_grad; a.dens_grad = density_grad;
+    a.means_grad = means3D_grad; a.opa_grad = opacity_grad; a.sem_grad = semantics_grad; a.cov_grad = cov3D_grad;
+    a.state = (const uint32_t *)state; a.voxel2pts = ws.voxel2pts; a.items = ws.items; a.item_count = ws.item_count;
+    a.P = P; a.N = N; a.H = H; a.W = W; a.D = D; a.per_axis = radii_per_axis ? 1 : 0;
+    const long long V = (long long)H * W * D;
+    a.force_general = ((long long)N != V || (flags & GF_PTS_GENERAL)) ? 1 : 0;
+    a.assume_dense = (!a.force_general && (flags & GF_PTS_ASSUME_DENSE)) ? 1 : 0;
+
+    (void)hipMemsetAsync(ws.item_count, 0, sizeof(uint32_t), stream);
+    if (!a.assume_dense) {
+        hipLaunchKernelGGL(gf_v2p_fill_kernel, dim3(1024), dim3(256), 0, stream, a);
+        if (N > 0) hipLaunchKernelGGL(gf_v2p_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
+    }
+    hipLaunchKernelGGL(gf_bwd_items_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
+    const int blocks = 2048;
+    if (variant == GF_SPLAT_BASE)
+        hipLaunchKernelGGL(gf_splat_bwd_kernel<GF_SPLAT_BASE>, dim3(blocks), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(gf_splat_bwd_kernel<GF_SPLAT_PROB>, dim3(blocks), dim3(256), 0, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

@@ -1,0 +1,98 @@
+"""Host-side mirror of ``model/encoder/gaussian_encoder/ops/deformable_aggregation.py``.
+
+``DeformableAggregationFunction`` keeps the reference's interface (apply signature,
+dtype coercions, ``once_differentiable`` backward that accumulates into three zeroed
+buffers, ``feature_maps_format``) and calls the HIP kernels through the C ABI.
+"""
+import torch
+from torch.autograd.function import Function, once_differentiable
+
+from . import _lib
+
+
+def deformable_aggregation_forward(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights):
+    """Counterpart of ``deformable_aggregation_ext.deformable_aggregation_forward``
+    (ops/src/deformable_aggregation.cpp:41-71): dims are read from the tensor sizes."""
+    lib = _lib.load()
+    _lib.require_gpu(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights)
+    B, cams, num_feat, C = mc_ms_feat.shape
+    L, pts, G = spatial_shape.shape[0], sampling_location.shape[1], weights.shape[4]
+    out = torch.empty((B, pts, C), dtype=torch.float32, device=mc_ms_feat.device)
+    with torch.cuda.device(mc_ms_feat.device):
+        rc = lib.gf_daf_forward(B, cams, num_feat, C, L, pts, G, _lib.ptr(mc_ms_feat), _lib.ptr(spatial_shape),
+                                _lib.ptr(scale_start_index), _lib.ptr(sampling_location), _lib.ptr(weights),
+                                _lib.ptr(out), _lib.current_stream(mc_ms_feat.device))
+    _lib.check(rc, "gf_daf_forward")
+    return out
+
+
+def deformable_aggregation_backward(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights,
+                                    grad_output, grad_mc_ms_feat, grad_sampling_location, grad_weights):
+    """Counterpart of ``deformable_aggregation_ext.deformable_aggregation_backward``
+    (ops/src/deformable_aggregation.cpp:73-110): accumulates in place into the three
+    caller-zeroed gradient tensors."""
+    lib = _lib.load()
+    _lib.require_gpu(mc_ms_feat, grad_output, grad_mc_ms_feat, grad_sampling_location, grad_weights)
+    B, cams, num_feat, C = mc_ms_feat.shape
+    L, pts, G = spatial_shape.shape[0], sampling_location.shape[1], weights.shape[4]
+    with torch.cuda.device(mc_ms_feat.device):
+        rc = lib.gf_daf_backward(B, cams, num_feat, C, L, pts, G, _lib.ptr(mc_ms_feat), _lib.ptr(spatial_shape),
+                                 _lib.ptr(scale_start_index), _lib.ptr(sampling_location), _lib.ptr(weights),
+                                 _lib.ptr(grad_output), _lib.ptr(grad_mc_ms_feat),
+                                 _lib.ptr(grad_sampling_location), _lib.ptr(grad_weights),
+                                 _lib.current_stream(mc_ms_feat.device))
+    _lib.check(rc, "gf_daf_backward")
+
+
+class DeformableAggregationFunction(Function):
+    """ops/deformable_aggregation.py:7-117."""
+
+    @staticmethod
+    def forward(ctx, mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights):
+        # output: [bs, num_pts, num_embeds]
+        mc_ms_feat = mc_ms_feat.contiguous().float()
+        spatial_shape = spatial_shape.contiguous().int()
+        scale_start_index = scale_start_index.contiguous().int()
+        sampling_location = sampling_location.contiguous().float()
+        weights = weights.contiguous().float()
+        output = deformable_aggregation_forward(mc_ms_feat, spatial_shape, scale_start_index,
+                                                sampling_location, weights)
+        ctx.save_for_backward(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights = ctx.saved_tensors
+        grad_mc_ms_feat = torch.zeros_like(mc_ms_feat)
+        grad_sampling_location = torch.zeros_like(sampling_location)
+        grad_weights = torch.zeros_like(weights)
+        deformable_aggregation_backward(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights,
+                                        grad_output.contiguous().float(), grad_mc_ms_feat, grad_sampling_location,
+                                        grad_weights)
+        return grad_mc_ms_feat, None, None, grad_sampling_location, grad_weights
+
+    @staticmethod
+    def feature_maps_format(feature_maps, inverse=False):
+        """List of ``[bs, cams, C, h, w]`` maps <-> ``(col_feats [bs,cams,sum(hw),C],
+        spatial_shape [L,2] int64, scale_start_index [L] int64)`` -- ops/deformable_aggregation.py:77-117."""
+        if not inverse:
+            bs, num_cams = feature_maps[0].shape[:2]
+            shapes = [tuple(f.shape[-2:]) for f in feature_maps]
+            starts, run = [], 0
+            for h, w in shapes:
+                starts.append(run)
+                run += h * w
+            flat = [f.reshape(bs, num_cams, f.shape[2], -1) for f in feature_maps]
+            col_feats = torch.cat(flat, dim=-1).permute(0, 1, 3, 2)
+            dev = col_feats.device
+            return [col_feats,
+                    torch.tensor(shapes, dtype=torch.int64, device=dev),
+                    torch.tensor(starts, dtype=torch.int64, device=dev)]
+        spatial_shape = feature_maps[1].int()
+        sizes = (spatial_shape[:, 0] * spatial_shape[:, 1]).tolist()
+        maps = feature_maps[0].permute(0, 1, 3, 2)
+        out = []
+        for i, f in enumerate(torch.split(maps, sizes, dim=-1)):
+            out.append(f.reshape(f.shape[:3] + (int(spatial_shape[i, 0]), int(spatial_shape[i, 1]))))
+        return out

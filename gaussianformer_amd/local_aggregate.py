@@ -1,0 +1,270 @@
+"""Host-side mirror of the reference's three splat packages
+(``local_aggregate``, ``local_aggregate_prob``, ``local_aggregate_prob_fast``).
+
+Same class names, constructor arguments, forward signature, outputs, gradient routing
+and error behaviour as
+  model/head/localagg/local_aggregate/__init__.py:18-161            (base)
+  model/head/localagg_prob/local_aggregate_prob/__init__.py:18-169  (prob)
+  model/head/localagg_prob_fast/local_aggregate_prob_fast/__init__.py:151 (per-axis radii)
+so ``GaussianHead`` (model/head/gaussian_head.py:30-39) can import these unchanged.
+The compute goes through the C ABI of ``libgf_hip.so``; there is no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_C18 = _lib.GF_NUM_CHANNELS
+
+
+class _Workspace:
+    """Per-device scratch reused across calls (stream-ordered, like any torch temp)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, device, nbytes):
+        key = (device.type, device.index)
+        buf = cls._cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            cls._cache[key] = buf
+        return buf
+
+
+def _contig(t, dtype):
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def splat_forward(variant, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
+                  H, W, D, flags=_lib.GF_PTS_AUTO):
+    """Raw op: the counterpart of ``_C.local_aggregate``
+    (model/head/localagg/local_aggregate.h:18-28; prob: localagg_prob/local_aggregate.cu:35-45).
+    Returns ``(logits, bin_logits, density, probability, state)``; the last four are ``None``
+    for the base variant except ``state`` (a small device block consumed by the backward)."""
+    lib = _lib.load()
+    _lib.require_gpu(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D)
+    dev = pts.device
+    f32, i32 = torch.float32, torch.int32
+    pts, means3D, opacities, semantics, cov3D = (_contig(t, f32) for t in (pts, means3D, opacities, semantics, cov3D))
+    points_int, means3D_int, radii = (_contig(t, i32) for t in (points_int, means3D_int, radii))
+    N, P, C = pts.shape[0], means3D.shape[0], semantics.shape[1]
+    if C != _C18:
+        raise RuntimeError(f"semantics must have {_C18} channels (NUM_CHANNELS), got {C}")
+    per_axis = int(radii.dim() == 2)
+    prob = variant == _lib.GF_SPLAT_PROB
+    logits = torch.empty((N, C), dtype=f32, device=dev)
+    bin_logits = density = probability = None
+    if prob:
+        bin_logits = torch.empty(N, dtype=f32, device=dev)
+        density = torch.empty(N, dtype=f32, device=dev)
+        probability = torch.empty(N, dtype=f32, device=dev)
+    state = torch.empty(lib.gf_splat_state_bytes(), dtype=torch.uint8, device=dev)
+    nbytes = lib.gf_splat_workspace_bytes(P, N, H, W, D)
+    ws = _Workspace.get(dev, nbytes)
+    with torch.cuda.device(dev):
+        rc = lib.gf_splat_forward(
+            variant, per_axis, flags, P, N, C, H, W, D,
+            _lib.ptr(pts), _lib.ptr(points_int), _lib.ptr(means3D), _lib.ptr(means3D_int), _lib.ptr(opacities),
+            _lib.ptr(semantics), _lib.ptr(radii), _lib.ptr(cov3D),
+            _lib.ptr(logits), _lib.ptr(bin_logits), _lib.ptr(density), _lib.ptr(probability), _lib.ptr(state),
+            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev))
+    _lib.check(rc, "gf_splat_forward")
+    return logits, bin_logits, density, probability, state
+
+
+def splat_backward(variant, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
+                   H, W, D, logits_grad, fwd_outputs=None, bin_logits_grad=None, density_grad=None,
+                   state=None, flags=_lib.GF_PTS_AUTO):
+    """Raw op: the counterpart of ``_C.local_aggregate_backward``
+    (model/head/localagg/local_aggregate.h:30-43).  ``fwd_outputs`` =
+    ``(logits, bin_logits, density, probability)`` for the prob variant.
+    Returns ``(means3D_grad, opacity_grad, semantics_grad, cov3D_grad)``."""
+    lib = _lib.load()
+    dev = pts.device
+    f32 = torch.float32
+    N, P, C = pts.shape[0], means3D.shape[0], semantics.shape[1]
+    per_axis = int(radii.dim() == 2)
+    logits_grad = _contig(logits_grad, f32)
+    lg = bl = de = pr = None
+    if variant == _lib.GF_SPLAT_PROB:
+        lg, bl, de, pr = (_contig(t, f32) for t in fwd_outputs)
+        bin_logits_grad = None if bin_logits_grad is None else _contig(bin_logits_grad, f32)
+        density_grad = None if density_grad is None else _contig(density_grad, f32)
+    mg = torch.empty((P, 3), dtype=f32, device=dev)
+    og = torch.empty(P, dtype=f32, device=dev)
+    sg = torch.empty((P, C), dtype=f32, device=dev)
+    cg = torch.empty((P, 6), dtype=f32, device=dev)
+    nbytes = lib.gf_splat_workspace_bytes(P, N, H, W, D)
+    ws = _Workspace.get(dev, nbytes)
+    with torch.cuda.device(dev):
+        rc = lib.gf_splat_backward(
+            variant, per_axis, flags, P, N, C, H, W, D,
+            _lib.ptr(pts), _lib.ptr(points_int), _lib.ptr(means3D), _lib.ptr(means3D_int), _lib.ptr(opacities),
+            _lib.ptr(semantics), _lib.ptr(radii), _lib.ptr(cov3D),
+            _lib.ptr(lg), _lib.ptr(bl), _lib.ptr(de), _lib.ptr(pr),
+            _lib.ptr(logits_grad), _lib.ptr(bin_logits_grad), _lib.ptr(density_grad),
+            _lib.ptr(mg), _lib.ptr(og), _lib.ptr(sg), _lib.ptr(cg), _lib.ptr(state),
+            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev))
+    _lib.check(rc, "gf_splat_backward")
+    return mg, og, sg, cg
+
+
+def splat_box_volumes(means3D_int, radii, H, W, D):
+    """(tiles_touched u32-as-int64 [P], num_rendered int) -- integer-exact counterpart of
+    FORWARD::preprocessCUDA + the inclusive scan's last element
+    (model/head/localagg/src/forward.cu:9-28, src/aggregator_impl.cu:193-197).
+    Reading ``num_rendered`` synchronises the stream (the reference does too, :197)."""
+    lib = _lib.load()
+    _lib.require_gpu(means3D_int, radii)
+    dev = means3D_int.device
+    means3D_int = _contig(means3D_int, torch.int32)
+    radii = _contig(radii, torch.int32)
+    P = means3D_int.shape[0]
+    touched = torch.zeros(P, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gf_splat_box_volumes(int(radii.dim() == 2), P, H, W, D, _lib.ptr(means3D_int), _lib.ptr(radii),
+                                      _lib.ptr(touched), _lib.ptr(total), _lib.current_stream(dev))
+    _lib.check(rc, "gf_splat_box_volumes")
+    return touched.to(torch.int64) & 0xFFFFFFFF, int(total.item())
+
+
+class _LocalAggregate(torch.autograd.Function):
+    """model/head/localagg/local_aggregate/__init__.py:18-106."""
+
+    @staticmethod
+    def forward(ctx, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D, H, W, D):
+        logits, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, pts, points_int, means3D, means3D_int,
+                                               opacities, semantics, radii, cov3D, H, W, D)
+        ctx.dims = (H, W, D)
+        ctx.save_for_backward(state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii)
+        return logits
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        H, W, D = ctx.dims
+        state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii = ctx.saved_tensors
+        mg, og, sg, cg = splat_backward(_lib.GF_SPLAT_BASE, pts, points_int, means3D, means3D_int, opacities,
+                                        semantics, radii, cov3D, H, W, D, out_grad, state=state)
+        # grads for (means3D, opacities, semantics, cov3D) only -- :91-104
+        return None, None, mg, None, og, sg, None, cg, None, None, None
+
+
+class _LocalAggregateProb(torch.autograd.Function):
+    """model/head/localagg_prob/local_aggregate_prob/__init__.py:18-116."""
+
+    @staticmethod
+    def forward(ctx, pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D, H, W, D):
+        logits, bin_logits, density, probability, state = splat_forward(
+            _lib.GF_SPLAT_PROB, pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D, H, W, D)
+        ctx.dims = (H, W, D)
+        ctx.save_for_backward(state, means3D, means3D_int, pts, points_int, cov3D, opas, semantics, radii,
+                              logits, bin_logits, density, probability)
+        return logits, bin_logits, density
+
+    @staticmethod
+    def backward(ctx, logits_grad, bin_logits_grad, density_grad):
+        H, W, D = ctx.dims
+        (state, means3D, means3D_int, pts, points_int, cov3D, opas, semantics, radii,
+         logits, bin_logits, density, probability) = ctx.saved_tensors
+        mg, og, sg, cg = splat_backward(_lib.GF_SPLAT_PROB, pts, points_int, means3D, means3D_int, opas, semantics,
+                                        radii, cov3D, H, W, D, logits_grad,
+                                        fwd_outputs=(logits, bin_logits, density, probability),
+                                        bin_logits_grad=bin_logits_grad, density_grad=density_grad, state=state)
+        return None, None, mg, None, og, sg, None, cg, None, None, None
+
+
+class _AggregatorBase(nn.Module):
+    """Shared pre-processing of the three ``LocalAggregator`` classes."""
+
+    def _prepare(self, pts, means3D, opacities, semantics, scales, cov3D):
+        assert pts.shape[0] == 1
+        pts = pts.squeeze(0)
+        assert not pts.requires_grad
+        means3D = means3D.squeeze(0)
+        opacities = opacities.squeeze(0)
+        semantics = semantics.squeeze(0)
+        scales = scales.detach().squeeze(0)
+        cov3D = cov3D.squeeze(0)
+        # integer path: fp32 subtract, fp32 true division, truncation (.to(torch.int)) --
+        # model/head/localagg/local_aggregate/__init__.py:137-141
+        points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
+        means3D_int = ((means3D.detach() - self.pc_min) / self.grid_size).to(torch.int)
+        if self.check_inputs:
+            # the reference asserts these on every call (8 host syncs, :138-142); here they
+            # are opt-in so the default path never synchronises.
+            assert points_int.min() >= 0 and points_int[:, 0].max() < self.H and points_int[:, 1].max() < self.W \
+                and points_int[:, 2].max() < self.D
+            assert means3D_int.min() >= 0 and means3D_int[:, 0].max() < self.H \
+                and means3D_int[:, 1].max() < self.W and means3D_int[:, 2].max() < self.D
+        return pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D
+
+
+class LocalAggregator(_AggregatorBase):
+    """Drop-in for ``local_aggregate.LocalAggregator``
+    (model/head/localagg/local_aggregate/__init__.py:108-161)."""
+
+    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, inv_softmax=False, check_inputs=False):
+        super().__init__()
+        self.scale_multiplier = scale_multiplier
+        self.H = H
+        self.W = W
+        self.D = D
+        self.register_buffer('pc_min', torch.tensor(pc_min, dtype=torch.float).unsqueeze(0))
+        self.grid_size = grid_size
+        self.inv_softmax = inv_softmax
+        self.check_inputs = check_inputs
+
+    def forward(self, pts, means3D, opacities, semantics, scales, cov3D):
+        pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D = self._prepare(
+            pts, means3D, opacities, semantics, scales, cov3D)
+        radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
+        if self.check_inputs:
+            assert radii.min() >= 1
+        cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
+        logits = _LocalAggregate.apply(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
+                                       self.H, self.W, self.D)
+        if not self.inv_softmax:
+            return logits  # n, c
+        else:
+            assert False  # unreachable in the reference as well (:158-161)
+
+
+class LocalAggregatorProb(_AggregatorBase):
+    """Drop-in for ``local_aggregate_prob.LocalAggregator``
+    (model/head/localagg_prob/local_aggregate_prob/__init__.py:118-169); ``per_axis_radii``
+    selects ``local_aggregate_prob_fast`` behaviour (…_prob_fast/__init__.py:151)."""
+    per_axis_radii = False
+
+    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, radii_min=1, check_inputs=False):
+        super().__init__()
+        self.scale_multiplier = scale_multiplier
+        self.H = H
+        self.W = W
+        self.D = D
+        self.register_buffer('pc_min', torch.tensor(pc_min, dtype=torch.float).unsqueeze(0))
+        self.grid_size = grid_size
+        self.radii_min = radii_min
+        self.check_inputs = check_inputs
+
+    def forward(self, pts, means3D, opas, semantics, scales, cov3D):
+        pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D = self._prepare(
+            pts, means3D, opas, semantics, scales, cov3D)
+        if self.per_axis_radii:
+            radii = torch.ceil(scales * self.scale_multiplier / self.grid_size).to(torch.int)
+        else:
+            radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
+        radii = radii.clamp(min=self.radii_min)
+        if self.check_inputs:
+            assert radii.min() >= 1
+        cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
+        logits, bin_logits, density = _LocalAggregateProb.apply(
+            pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D, self.H, self.W, self.D)
+        return logits, bin_logits, density  # n, c; n; n
+
+
+class LocalAggregatorProbFast(LocalAggregatorProb):
+    """Drop-in for ``local_aggregate_prob_fast.LocalAggregator``."""
+    per_axis_radii = True

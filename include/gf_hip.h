@@ -1,0 +1,141 @@
+/*
+ * gf_hip.h -- C ABI of libgf_hip.so: the MI355X (gfx950) implementation of
+ * GaussianFormer's hot path.  Plain pointers and sizes only; every pointer is a DEVICE
+ * pointer unless stated otherwise; `stream` is a hipStream_t passed as void* (NULL = the
+ * null stream).  All entry points return 0 on success or a negative GF_E* code;
+ * gf_last_error() gives a thread-local message.  No entry point synchronises the host
+ * with the device or allocates device memory: scratch comes from the caller-provided
+ * workspace (size it with gf_splat_workspace_bytes()).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * huang-yh/GaussianFormer tree); INTEGRATION.md shows the binding a maintainer adds on the
+ * reference side.
+ */
+#ifndef GF_HIP_H_INCLUDED
+#define GF_HIP_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_ABI_VERSION 1
+
+/* error codes */
+#define GF_OK 0
+#define GF_EINVAL (-1)    /* bad argument (null pointer, unsupported size) */
+#define GF_EWORKSPACE (-2) /* workspace too small */
+#define GF_ELAUNCH (-3)   /* HIP launch failure */
+
+/* splat variants: model/head/localagg (base) vs model/head/localagg_prob{,_fast} (prob) */
+#define GF_SPLAT_BASE 0
+#define GF_SPLAT_PROB 1
+
+/* number of semantic channels; compile-time constant in the reference too
+ * (model/head/localagg/src/config.h:15  NUM_CHANNELS 18) */
+#define GF_NUM_CHANNELS 18
+
+/* flags for gf_splat_forward / gf_splat_backward */
+#define GF_PTS_AUTO 0          /* verify on device whether pts is the dense voxel-centre grid */
+#define GF_PTS_ASSUME_DENSE 1  /* caller guarantees point n lies in voxel n (N == H*W*D) */
+#define GF_PTS_GENERAL 2       /* always take the arbitrary-points path */
+#define GF_FAST_EXP 4          /* v_exp_f32-based exp (rel. err ~1e-6) instead of full-precision expf */
+
+int gf_abi_version(void);
+const char *gf_last_error(void);
+
+/* Bytes of device scratch gf_splat_forward / gf_splat_backward need for these sizes. */
+size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D);
+
+/* Bytes of the small per-call state block written by gf_splat_forward and read by
+ * gf_splat_backward (replaces the geomBuffer/binningBuffer/imgBuffer triple the reference
+ * saves in ctx: model/head/localagg/local_aggregate/__init__.py:52-62). */
+size_t gf_splat_state_bytes(void);
+
+/*
+ * Gaussian -> voxel splat, forward.
+ * Replaces  _C.local_aggregate            model/head/localagg/local_aggregate.h:18-28,
+ *           LocalAggregateCUDA            model/head/localagg/local_aggregate.cu:35-83,
+ *           Aggregator::forward           model/head/localagg/src/aggregator_impl.cu:152-252
+ * and the prob / prob_fast counterparts   model/head/localagg_prob/local_aggregate.cu:35-89.
+ *
+ *   pts          f32 [N,3]   query points            points_int  i32 [N,3]  their voxel coords
+ *   means3D      f32 [P,3]                           means3D_int i32 [P,3]
+ *   opacity      f32 [P]     semantics f32 [P,18]    cov3D f32 [P,6] = (xx,yy,zz,xy,yz,xz) of Sigma^-1
+ *   radii        i32 [P] (radii_per_axis=0) or i32 [P,3] (radii_per_axis=1, localagg_prob_fast)
+ *   out_logits   f32 [N,18]  written in full (no pre-zeroing needed)
+ *   out_bin_logits / out_density / out_probability  f32 [N]  (GF_SPLAT_PROB only, else NULL)
+ *   state        gf_splat_state_bytes() bytes, kept by the caller until backward
+ * Limits: C == 18, H,W <= 2047, D <= 1023, H*W*D < 2^31.
+ */
+int gf_splat_forward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
+                     int W, int D, const float *pts, const int *points_int,
+                     const float *means3D, const int *means3D_int, const float *opacity,
+                     const float *semantics, const int *radii, const float *cov3D,
+                     float *out_logits, float *out_bin_logits, float *out_density,
+                     float *out_probability, void *state, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
+/*
+ * Splat backward.
+ * Replaces  _C.local_aggregate_backward   model/head/localagg/local_aggregate.h:30-43,
+ *           LocalAggregateBackwardCUDA    model/head/localagg/local_aggregate.cu:85-130,
+ *           Aggregator::backward          model/head/localagg/src/aggregator_impl.cu:256-307
+ * and the prob counterpart                model/head/localagg_prob/local_aggregate.cu:91-148.
+ * logits/bin_logits/density/probability are the forward outputs (GF_SPLAT_PROB only);
+ * bin_logits_grad/density_grad may be NULL (treated as zero).  Gradient outputs
+ * (means3D_grad [P,3], opacity_grad [P], semantics_grad [P,18], cov3D_grad [P,6]) are
+ * written in full.
+ */
+int gf_splat_backward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
+                      int W, int D, const float *pts, const int *points_int,
+                      const float *means3D, const int *means3D_int, const float *opacity,
+                      const float *semantics, const int *radii, const float *cov3D,
+                      const float *logits, const float *bin_logits, const float *density,
+                      const float *probability, const float *logits_grad,
+                      const float *bin_logits_grad, const float *density_grad,
+                      float *means3D_grad, float *opacity_grad, float *semantics_grad,
+                      float *cov3D_grad, const void *state, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/*
+ * Per-Gaussian clipped box volume (tiles_touched, u32 [P]) and their total
+ * (num_rendered, u64 [1], device).  Integer-exact restatement of
+ * FORWARD::preprocessCUDA (model/head/localagg/src/forward.cu:9-28) + InclusiveSum's last
+ * element (src/aggregator_impl.cu:193-197); used by parity tests and to report R.
+ */
+int gf_splat_box_volumes(int radii_per_axis, int P, int H, int W, int D,
+                         const int *means3D_int, const int *radii, uint32_t *tiles_touched,
+                         unsigned long long *num_rendered, void *stream);
+
+/*
+ * Multi-camera multi-level deformable aggregation, forward.
+ * Replaces  deformable_aggregation_forward  model/encoder/gaussian_encoder/ops/src/deformable_aggregation.cpp:41-71
+ *           deformable_aggregation_kernel   .../ops/src/deformable_aggregation_cuda.cu:125-187
+ *   mc_ms_feat f32 [B,cams,num_feat,C]   spatial_shape i32 [L,2]   scale_start_index i32 [L]
+ *   sampling_location f32 [B,pts,cams,2] weights f32 [B,pts,cams,L,G]   output f32 [B,pts,C]
+ * Requires C % G == 0.
+ */
+int gf_daf_forward(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,
+                   const float *mc_ms_feat, const int *spatial_shape,
+                   const int *scale_start_index, const float *sampling_location,
+                   const float *weights, float *output, void *stream);
+
+/*
+ * Deformable aggregation, backward.  Accumulates into the three caller-zeroed gradient
+ * buffers exactly like the reference (ops/deformable_aggregation.py:55-67).
+ * Replaces  deformable_aggregation_backward  .../ops/src/deformable_aggregation.cpp:73-110
+ *           deformable_aggregation_grad_kernel .../ops/src/deformable_aggregation_cuda.cu:190-259
+ */
+int gf_daf_backward(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,
+                    const float *mc_ms_feat, const int *spatial_shape,
+                    const int *scale_start_index, const float *sampling_location,
+                    const float *weights, const float *grad_output, float *grad_mc_ms_feat,
+                    float *grad_sampling_location, float *grad_weights, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GF_HIP_H_INCLUDED */

@@ -1,0 +1,219 @@
+"""GPU parity of the splat (forward + backward, base / prob / prob_fast) against the CPU
+oracle, through the C ABI.  Tolerances: see tests/util.py."""
+import numpy as np
+import pytest
+
+import oracle
+from gaussianformer_amd.synthetic import make_splat_inputs
+
+from util import (assert_grad_close, assert_logits_close, hip_splat_backward, hip_splat_forward, prep)
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [
+    # config, P, H, W, D, per_axis
+    ("nuscenes_gs25600_solid", 300, 24, 20, 16, False),
+    ("nuscenes_gs25600_solid", 257, 23, 21, 16, False),   # H, W not multiples of the 4x4 tile
+    ("nuscenes_gs25600_solid", 200, 20, 20, 10, False),   # D not a multiple of 4 (scalar row stores)
+    ("nuscenes_gs25600_solid", 200, 20, 20, 40, False),   # D > 16: several z-brick groups per tile
+    ("nuscenes_gs144000", 1000, 40, 44, 16, False),
+    ("prob_gs6400", 120, 24, 20, 16, False),
+    ("prob_gs6400", 120, 24, 20, 16, True),               # localagg_prob_fast: per-axis radii
+]
+
+
+def _oracle_fwd(si, pi, mi, radii, cov6):
+    return oracle.splat_forward(si.variant, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6,
+                                si.H, si.W, si.D)
+
+
+def _check_fwd(got, ref, variant):
+    assert_logits_close(got["logits"], ref["logits"])
+    if variant == "prob":
+        for k in ("bin_logits", "density", "probability"):
+            assert_logits_close(got[k], ref[k], what=k)
+
+
+@pytest.mark.parametrize("config,P,H,W,D,per_axis", SMALL)
+def test_forward_dense_small(gpu, config, P, H, W, D, per_axis):
+    si = make_splat_inputs(config, seed=3, P=P, H=H, W=W, D=D)
+    pi, mi, radii, cov6 = prep(si, per_axis)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _check_fwd(got, ref, si.variant)
+    # the trusted-dense and forced-general paths must agree with the automatic one
+    from gaussianformer_amd import _lib
+    for flags in (_lib.GF_PTS_ASSUME_DENSE, _lib.GF_PTS_GENERAL):
+        got2, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
+        _check_fwd(got2, ref, si.variant)
+
+
+@pytest.mark.parametrize("config,per_axis", [("nuscenes_gs25600_solid", False), ("prob_gs6400", True)])
+def test_forward_arbitrary_points(gpu, config, per_axis):
+    """Random query points: several per voxel, most voxels empty (model/head/localagg/debug.py
+    shape: N random pts)."""
+    si = make_splat_inputs(config, seed=4, P=150, H=20, W=24, D=16, dense_pts=False, N=5000)
+    pi, mi, radii, cov6 = prep(si, per_axis)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _check_fwd(got, ref, si.variant)
+
+
+def test_forward_permuted_grid_falls_back(gpu):
+    """N == H*W*D but points are NOT in canonical voxel order: the dense kernel must
+    detect it on the device and the general kernel must produce the result."""
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=5, P=200, H=20, W=20, D=16)
+    perm = np.random.default_rng(0).permutation(si.pts.shape[0])
+    si.pts = np.ascontiguousarray(si.pts[perm])
+    pi, mi, radii, cov6 = prep(si)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _check_fwd(got, ref, si.variant)
+
+
+def test_voxel_membership_bit_exact(gpu):
+    """Integer path: with Sigma^-1 = 0, opacity = 1, semantics = 1 every covered voxel
+    receives exactly 1.0 per covering Gaussian, so logits == per-voxel Gaussian count --
+    compared bit-exactly with the oracle; plus tiles_touched / num_rendered
+    (src/forward.cu:9-28, src/aggregator_impl.cu:193-197)."""
+    import torch
+    from gaussianformer_amd.local_aggregate import splat_box_volumes
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=6, P=2000, H=40, W=36, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    si.opacities[:] = 1.0
+    si.semantics[:] = 1.0
+    cov6 = np.zeros_like(cov6)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    assert np.array_equal(got["logits"], ref["logits"])
+    touched_ref, _, R_ref = oracle.box_offsets(mi, radii, si.H, si.W, si.D)
+    touched, R = splat_box_volumes(torch.from_numpy(mi).to(gpu), torch.from_numpy(radii).to(gpu), si.H, si.W, si.D)
+    assert np.array_equal(touched.cpu().numpy().astype(np.uint32), touched_ref)
+    assert R == R_ref == ref["num_rendered"]
+
+
+def test_forward_edge_cases(gpu):
+    """Empty Gaussian set; a single whole-grid Gaussian; Gaussians whose centre lies
+    outside the grid (the reference asserts; we clip the box like getRect does)."""
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=7, P=0, H=12, W=12, D=8)  # only the empty Gaussian
+    pi, mi, radii, cov6 = prep(si)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _check_fwd(got, ref, si.variant)
+    # P = 0
+    import torch
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import splat_forward
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=gpu)
+    pts = torch.from_numpy(si.pts).to(gpu)
+    pint = torch.from_numpy(pi).to(gpu)
+    logits, *_ = splat_forward(_lib.GF_SPLAT_BASE, pts, pint, z(0, 3), z(0, 3, dt=torch.int32), z(0), z(0, 18),
+                               z(0, dt=torch.int32), z(0, 6), si.H, si.W, si.D)
+    assert float(logits.abs().max()) == 0.0
+    lp, bl, de, pr, _ = splat_forward(_lib.GF_SPLAT_PROB, pts, pint, z(0, 3), z(0, 3, dt=torch.int32), z(0), z(0, 18),
+                                      z(0, dt=torch.int32), z(0, 6), si.H, si.W, si.D)
+    assert torch.allclose(lp[:, :17], torch.full_like(lp[:, :17], 1.0 / 17)) and float(lp[:, 17].abs().max()) == 0.0
+    assert float(bl.abs().max()) == 0.0 and float(de.abs().max()) == 0.0 and float(pr.abs().max()) == 0.0
+    # centres outside the grid
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=8, P=100, H=16, W=16, D=8)
+    si.means3D[:50] += np.float32(3.0)
+    pi, mi, radii, cov6 = prep(si)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _check_fwd(got, ref, si.variant)
+
+
+def test_forward_crowded_tile(gpu):
+    """Thousands of Gaussians in one supertile: exercises the candidate sub-pass path and
+    the LDS list flush (lists far longer than the LDS capacity)."""
+    si = make_splat_inputs("nuscenes_gs144000", seed=9, P=6000, H=20, W=20, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _check_fwd(got, ref, si.variant)
+
+
+@pytest.mark.parametrize("config,P,H,W,D,per_axis", SMALL)
+def test_backward_small(gpu, config, P, H, W, D, per_axis):
+    si = make_splat_inputs(config, seed=11, P=P, H=H, W=W, D=D)
+    pi, mi, radii, cov6 = prep(si, per_axis)
+    rng = np.random.default_rng(12)
+    N = si.pts.shape[0]
+    g = rng.standard_normal((N, 18)).astype(np.float32)
+    gb = rng.standard_normal(N).astype(np.float32) if si.variant == "prob" else None
+    gd = rng.standard_normal(N).astype(np.float32) if si.variant == "prob" else None
+    fwd = _oracle_fwd(si, pi, mi, radii, cov6)
+    ref = oracle.splat_backward(si.variant, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6,
+                                si.H, si.W, si.D, g, fwd=fwd, bin_grad=gb, density_grad=gd)
+    _, t, state, fwd_t = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    got = hip_splat_backward(gpu, si, t, state, fwd_t, g, gb, gd)
+    for name, a, b in zip(("means3D_grad", "opacity_grad", "semantics_grad", "cov3D_grad"), got, ref):
+        assert_grad_close(a, b, what=name)
+
+
+def test_backward_arbitrary_points(gpu):
+    """Duplicate-voxel points: only the highest-index point of a voxel feeds the gradient
+    (voxel2pts semantics, backward.cu:18-19, made deterministic)."""
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=13, P=150, H=20, W=24, D=16, dense_pts=False, N=20000)
+    pi, mi, radii, cov6 = prep(si)
+    g = np.random.default_rng(14).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
+    ref = oracle.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6,
+                                si.H, si.W, si.D, g)
+    _, t, state, fwd_t = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    got = hip_splat_backward(gpu, si, t, state, fwd_t, g)
+    for name, a, b in zip(("means3D_grad", "opacity_grad", "semantics_grad", "cov3D_grad"), got, ref):
+        assert_grad_close(a, b, what=name)
+
+
+def test_module_autograd_matches_oracle(gpu):
+    """Through the drop-in ``local_aggregate.LocalAggregator`` module + autograd, including
+    the [0,4,8,1,5,2] gather of the 3x3 inverse covariance
+    (model/head/localagg/local_aggregate/__init__.py:143)."""
+    import torch
+    import local_aggregate
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=15, P=300, H=24, W=20, D=16)
+    agg = local_aggregate.LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)
+    assert "pc_min" in agg.state_dict()
+    tt = lambda a, g=False: torch.from_numpy(a).to(gpu)[None].requires_grad_(g)
+    means, opa, sem, cov = tt(si.means3D, True), tt(si.opacities, True), tt(si.semantics, True), tt(si.cov3D, True)
+    logits = agg(tt(si.pts), means, opa, sem, tt(si.scales), cov)
+    gout = np.random.default_rng(16).standard_normal(tuple(logits.shape)).astype(np.float32)
+    logits.backward(torch.from_numpy(gout).to(gpu))
+    pi, mi, radii, cov6 = prep(si)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    assert_logits_close(logits.detach().cpu().numpy(), ref["logits"])
+    rg = oracle.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6,
+                               si.H, si.W, si.D, gout)
+    assert_grad_close(means.grad[0].cpu().numpy(), rg[0], "means3D.grad")
+    assert_grad_close(opa.grad[0].cpu().numpy(), rg[1], "opacities.grad")
+    assert_grad_close(sem.grad[0].cpu().numpy(), rg[2], "semantics.grad")
+    cg = cov.grad[0].cpu().numpy().reshape(-1, 9)
+    assert_grad_close(cg[:, [0, 4, 8, 1, 5, 2]], rg[3], "cov3D.grad (packed entries)")
+    assert np.abs(cg[:, [3, 6, 7]]).max() == 0.0  # lower triangle receives nothing
+
+
+@pytest.mark.parametrize("config", ["nuscenes_gs25600_solid", "nuscenes_gs144000"])
+def test_forward_full_size(gpu, config):
+    """BASELINE.json configs at full size (200x200x16, P = 25 601 / 144 000) vs the oracle."""
+    si = make_splat_inputs(config, seed=0)
+    pi, mi, radii, cov6 = prep(si)
+    ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _check_fwd(got, ref, si.variant)
+    # size-independent properties: linearity in semantics and in opacity
+    si2 = make_splat_inputs(config, seed=0)
+    si2.semantics *= np.float32(2.0)
+    got2, *_ = hip_splat_forward(gpu, si2, pi, mi, radii, cov6)
+    assert np.array_equal(got2["logits"], np.float32(2.0) * got["logits"])  # exact: power-of-two scaling
+
+
+def test_backward_full_size(gpu):
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=0)
+    pi, mi, radii, cov6 = prep(si)
+    g = np.random.default_rng(1).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
+    ref = oracle.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6,
+                                si.H, si.W, si.D, g)
+    _, t, state, fwd_t = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    got = hip_splat_backward(gpu, si, t, state, fwd_t, g)
+    for name, a, b in zip(("means3D_grad", "opacity_grad", "semantics_grad", "cov3D_grad"), got, ref):
+        assert_grad_close(a, b, what=name)
