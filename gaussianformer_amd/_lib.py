@@ -28,6 +28,8 @@ SIGNATURES = {
     "gf_splat_box_volumes": (_i, [_i] * 5 + [_vp] * 5),
     "gf_daf_forward": (_i, [_i] * 7 + [_vp] * 7),
     "gf_daf_backward": (_i, [_i] * 7 + [_vp] * 10),
+    "gf_profile_enable": (_i, [_i]),
+    "gf_profile_read": (_i, [_vp, _i]),
 }
 
 _lib = None

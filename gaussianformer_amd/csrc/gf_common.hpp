@@ -73,6 +73,7 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
 
 // ---- error reporting ----------------------------------------------------------------
 void set_error(const char *fmt, ...);
+bool profile_slot(hipEvent_t *before, hipEvent_t *after);  // gf_api.hip
 
 #define GF_CHECK_ARG(cond, msg)                \
     do {                                       \

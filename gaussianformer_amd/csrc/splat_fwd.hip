@@ -501,10 +501,14 @@ static int launch_forward(bool fast_exp, int flags, const RenderArgs &ra, hipStr
     if (try_dense) {
         r.verify_dense = (flags & GF_PTS_ASSUME_DENSE) ? 0 : 1;
         const int per_xcd = (r.ntiles_total + 7) / 8;
+        hipEvent_t ev0, ev1;
+        const bool prof = profile_slot(&ev0, &ev1);
+        if (prof) (void)hipEventRecord(ev0, stream);
         if (fast_exp)
             hipLaunchKernelGGL((gf_splat_render_dense_kernel<VARIANT, true>), dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
         else
             hipLaunchKernelGGL((gf_splat_render_dense_kernel<VARIANT, false>), dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
+        if (prof) (void)hipEventRecord(ev1, stream);
         if (flags & GF_PTS_ASSUME_DENSE) return 0;
         r.only_if_nondense = 1;
     } else {

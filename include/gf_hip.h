@@ -135,6 +135,17 @@ int gf_daf_backward(int B, int num_cams, int num_feat, int C, int L, int num_pts
                     const float *weights, const float *grad_output, float *grad_mc_ms_feat,
                     float *grad_sampling_location, float *grad_weights, void *stream);
 
+/*
+ * Kernel-level timing for bench.py's roofline leg.  gf_profile_enable(n) pre-creates n
+ * hipEvent pairs; while enabled, every gf_splat_forward call brackets its dominant kernel
+ * (the dense render kernel) with hipEventRecord on the caller's stream (asynchronous, no
+ * host sync).  gf_profile_read() waits for the recorded events, writes the per-launch
+ * durations in milliseconds, resets the ring and returns how many were written.
+ * gf_profile_enable(0) disables and frees.  Not part of the reference interface.
+ */
+int gf_profile_enable(int max_records);
+int gf_profile_read(float *ms_out, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

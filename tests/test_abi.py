@@ -1,0 +1,61 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/gf_hip.h declares, and validates arguments before touching a device."""
+import ctypes
+import os
+import re
+
+from gaussianformer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "gf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gf_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), f"libgf_hip.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {n}"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version_and_sizes():
+    lib = _lib.load()
+    assert lib.gf_abi_version() == _lib.GF_ABI_VERSION
+    assert lib.gf_splat_state_bytes() >= 64
+    small = lib.gf_splat_workspace_bytes(100, 1000, 20, 20, 16)
+    big = lib.gf_splat_workspace_bytes(25601, 640000, 200, 200, 16)
+    assert 0 < small < big < (1 << 30)
+    assert lib.gf_splat_workspace_bytes(-1, 0, 20, 20, 16) == 0
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    # 17 channels -> GF_EINVAL before any HIP call
+    rc = lib.gf_splat_forward(0, 0, 0, 1, 1, 17, 8, 8, 8, *([None] * 13), None, 0, None)
+    assert rc == -1 and b"18" in lib.gf_last_error()
+    rc = lib.gf_splat_forward(7, 0, 0, 1, 1, 18, 8, 8, 8, *([None] * 13), None, 0, None)
+    assert rc == -1 and b"variant" in lib.gf_last_error()
+    rc = lib.gf_splat_forward(0, 0, 0, 1, 1, 18, 4096, 8, 8, *([None] * 13), None, 0, None)
+    assert rc == -1
+    rc = lib.gf_daf_forward(1, 6, 100, 128, 4, 10, 5, *([None] * 7))
+    assert rc == -1 and b"divisible" in lib.gf_last_error()
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    import pytest
+    import torch
+    import local_aggregate
+    agg = local_aggregate.LocalAggregator(3, 8, 8, 8, [-2.0, -2.0, -2.0], 0.5)
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        agg(z(1, 4, 3), z(1, 2, 3), z(1, 2), z(1, 2, 18), z(1, 2, 3) + 0.2, torch.eye(3).repeat(1, 2, 1, 1))
+    from model.encoder.gaussian_encoder.ops import DeformableAggregationFunction as DAF
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DAF.apply(z(1, 1, 4, 8), torch.tensor([[2, 2]]), torch.tensor([0]), z(1, 3, 1, 2), z(1, 3, 1, 1, 4))

@@ -27,11 +27,34 @@ def _oracle_fwd(si, pi, mi, radii, cov6):
                                 si.H, si.W, si.D)
 
 
-def _check_fwd(got, ref, variant):
+def _truth(si, pi, mi, radii, cov6):
+    """fp64 dense evaluation (small cases only)."""
+    import torch
+    from oracle import dense_ref
+    t = lambda a: torch.tensor(a, dtype=torch.float64)
+    out = dense_ref.splat_dense(si.variant, t(si.pts), torch.tensor(pi), t(si.means3D), torch.tensor(mi),
+                                t(si.opacities), t(si.semantics), torch.tensor(radii), t(cov6), si.H, si.W, si.D)
+    return [o.numpy() for o in out]
+
+
+def _check_fwd(got, ref, variant, truth=None):
     assert_logits_close(got["logits"], ref["logits"])
     if variant == "prob":
-        for k in ("bin_logits", "density", "probability"):
-            assert_logits_close(got[k], ref[k], what=k)
+        # The Prob config's scale range (0.01 .. 3.2 m) makes -1/2 d^T Sigma^-1 d a sum of
+        # terms ~1e3 that cancel to ~1e0, so ANY fp32 evaluation of density / probability is
+        # only good to ~1e-4 relative (the CUDA reference included: nvcc's FMA contraction
+        # differs from both gcc and hipcc).  These three outputs are therefore judged
+        # against the fp64 truth: the HIP result may not be further from it than twice the
+        # oracle's own fp32 error (or the plain 1e-4 bound, whichever is larger).
+        for i, k in enumerate(("bin_logits", "density", "probability")):
+            if truth is None:
+                assert_logits_close(got[k], ref[k], what=k, tol=1e-3)
+                continue
+            tr = truth[i + 1]
+            scale = np.maximum(1.0, np.abs(tr))
+            e_hip = np.abs(got[k] - tr) / scale
+            e_orc = np.abs(ref[k] - tr) / scale
+            assert np.all(e_hip <= np.maximum(2 * e_orc.max(), 1e-4)), (k, e_hip.max(), e_orc.max())
 
 
 @pytest.mark.parametrize("config,P,H,W,D,per_axis", SMALL)
@@ -39,13 +62,14 @@ def test_forward_dense_small(gpu, config, P, H, W, D, per_axis):
     si = make_splat_inputs(config, seed=3, P=P, H=H, W=W, D=D)
     pi, mi, radii, cov6 = prep(si, per_axis)
     ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    truth = _truth(si, pi, mi, radii, cov6) if si.variant == "prob" else None
     got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
-    _check_fwd(got, ref, si.variant)
+    _check_fwd(got, ref, si.variant, truth)
     # the trusted-dense and forced-general paths must agree with the automatic one
     from gaussianformer_amd import _lib
     for flags in (_lib.GF_PTS_ASSUME_DENSE, _lib.GF_PTS_GENERAL):
         got2, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
-        _check_fwd(got2, ref, si.variant)
+        _check_fwd(got2, ref, si.variant, truth)
 
 
 @pytest.mark.parametrize("config,per_axis", [("nuscenes_gs25600_solid", False), ("prob_gs6400", True)])
@@ -55,8 +79,9 @@ def test_forward_arbitrary_points(gpu, config, per_axis):
     si = make_splat_inputs(config, seed=4, P=150, H=20, W=24, D=16, dense_pts=False, N=5000)
     pi, mi, radii, cov6 = prep(si, per_axis)
     ref = _oracle_fwd(si, pi, mi, radii, cov6)
+    truth = _truth(si, pi, mi, radii, cov6) if si.variant == "prob" else None
     got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
-    _check_fwd(got, ref, si.variant)
+    _check_fwd(got, ref, si.variant, truth)
 
 
 def test_forward_permuted_grid_falls_back(gpu):
@@ -204,7 +229,15 @@ def test_forward_full_size(gpu, config):
     si2 = make_splat_inputs(config, seed=0)
     si2.semantics *= np.float32(2.0)
     got2, *_ = hip_splat_forward(gpu, si2, pi, mi, radii, cov6)
-    assert np.array_equal(got2["logits"], np.float32(2.0) * got["logits"])  # exact: power-of-two scaling
+    # power-of-two scaling is exact in fp32 except where a product lands in the denormal range
+    assert np.allclose(got2["logits"], np.float32(2.0) * got["logits"], rtol=0, atol=1e-35)
+    # deterministic: same bits on a second run, and the arbitrary-points kernel (same ascending
+    # Gaussian order per voxel) reproduces the dense kernel bit for bit
+    from gaussianformer_amd import _lib
+    again, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    assert np.array_equal(again["logits"], got["logits"])
+    general, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_PTS_GENERAL)
+    assert np.array_equal(general["logits"], got["logits"])
 
 
 def test_backward_full_size(gpu):
