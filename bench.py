@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: Gaussian -> voxel splat forward on synthetic nuScenes-shaped input.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the splat forward (C ABI ``gf_splat_forward``, automatic point-layout
+detection, inputs and outputs resident in HBM) over one frame: P = 25 601 Gaussians
+(``nuscenes_gs25600_solid``: 25 600 + the appended whole-grid "empty" Gaussian) into the
+200x200x16 grid with 18 semantic channels.  With N > 1 ranks every rank splats its own shard of
+P Gaussians into a full partial grid and the partial logits are summed with one RCCL
+all-reduce (weak scaling: per-GPU work is fixed); ``value`` counts the Gaussians
+of all ranks.  Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+
+def algorithmic_bytes(P, N, C=18):
+    """every op input read once + logits written once."""
+    return 128 * P + 24 * N + 4 * C * N
+
+
+def measured_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/traffic_*.json, FETCH_SIZE x2 correction applied there); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get("render_kernel_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(si, pi, mi, radii, cov6, budget_s=20.0):
+    """The CPU oracle (a restatement of the reference kernels, kind "port") timed on this
+    box's host cores on the SAME workload, all OpenMP threads."""
+    import oracle
+    threads = oracle.num_threads()
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        oracle.splat_forward(si.variant, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6,
+                             si.H, si.W, si.D, nthreads=threads)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    P = si.means3D.shape[0]
+    return {"value": P / t, "unit": "Gaussians/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} full forward passes of the same workload (P={P}, N={si.pts.shape[0]}), median",
+            "seconds_per_pass": t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="nuscenes_gs25600_solid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import oracle  # checker side only: host pre-processing restatement + cpu_baseline leg
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import SplatForwardPlan
+    from gaussianformer_amd.synthetic import make_splat_inputs
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X; there is no CPU path for the product")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    lib = _lib.load()
+
+    # each rank owns a different shard of Gaussians (seed = rank); same query grid
+    si = make_splat_inputs(args.config, seed=rank)
+    pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min,
+                                                      si.grid_size, si.scale_multiplier,
+                                                      radii_min=1 if si.variant == "prob" else None)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+         for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
+    variant = _lib.GF_SPLAT_PROB if si.variant == "prob" else _lib.GF_SPLAT_BASE
+    plan = SplatForwardPlan(variant, *t, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO)
+    P, N = plan.P, plan.N
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        plan.run(stream)
+        if world > 1:
+            dist.all_reduce(plan.logits, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    _lib.check(lib.gf_profile_enable(args.steps), "gf_profile_enable")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # dominant kernel (the render kernel): per-launch duration from the hipEvents recorded
+    # around it on the launch stream during the timed region
+    buf = (ctypes.c_float * args.steps)()
+    n_ev = lib.gf_profile_read(buf, args.steps)
+    lib.gf_profile_enable(0)
+    kernel_ms = float(np.mean(buf[:n_ev])) if n_ev > 0 else None
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * P / (elapsed / args.steps)
+        abytes = algorithmic_bytes(P, N)
+        roofline = None
+        if kernel_ms:
+            achieved = abytes / (kernel_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
+                        "kernel": "gf_splat_render_kernel", "kernel_us": kernel_ms * 1e3,
+                        "algorithmic_bytes": abytes}
+        out = {
+            "metric": "Gaussians/sec splatted into 200x200x16x18 voxel grid (fwd)",
+            "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: splat forward, P={P} Gaussians/GPU -> {si.H}x{si.W}x{si.D}x18 "
+                                   f"grid (N={N} voxel-centre points), bs=1",
+                       "P_per_gpu": P, "N": N, "pts_layout": "auto-detected dense grid",
+                       "parallelism": "single GPU" if world == 1 else f"gaussian-shard x{world} + RCCL all-reduce of logits"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(si, pi, mi, radii, cov6)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

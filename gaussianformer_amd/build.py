@@ -32,16 +32,20 @@ def _stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library.  Returns its path."""
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), lib_name=None):
+    """Compile every HIP source into one shared library.  Returns its path.
+    ``extra_flags`` / ``lib_name`` build a development variant (e.g. ``-DGF_TIMELINE=1``)
+    next to the product library without touching it."""
+    if lib_name is None and not force and not _stale():
         return lib_path()
+    out_lib = lib_path() if lib_name is None else os.path.join(CSRC, lib_name)
+    tag = "" if lib_name is None else "." + os.path.splitext(lib_name)[0]
     objs = []
     common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-              "-Wall", "-Wno-unused-function"]
+              "-Wall", "-Wno-unused-function", *extra_flags]
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
         objs.append(obj)
         cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -53,11 +57,11 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path()] + objs
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out_lib] + objs
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc link failed:\n{r.stdout}")
-    return lib_path()
+    return out_lib
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ namespace gf {
 // ---- geometry constants -------------------------------------------------------------
 constexpr int kC = GF_NUM_CHANNELS;  // 18 semantic channels
 constexpr int kTile = 4;             // a tile is 4x4 voxel columns x all z; a brick is 4x4x4
-constexpr int kSuper = 20;           // a supertile is 20x20 voxel columns = 5x5 tiles
+constexpr int kSuper = 8;            // a supertile is 8x8 voxel columns = 2x2 tiles
 constexpr int kTilesPerSuperAxis = kSuper / kTile;
 constexpr int kTilesPerSuper = kTilesPerSuperAxis * kTilesPerSuperAxis;
 constexpr int kRecDwords = 32;       // packed per-Gaussian record, 128 B
@@ -33,21 +33,18 @@ __host__ __device__ __forceinline__ int uz(uint32_t p) { return (int)(p >> 22); 
 
 // workspace carve-up (all sections 256-B aligned)
 struct SplatWorkspace {
-    uint32_t *flags;        // [64]  flags[0] = "pts is not the dense grid"
+    uint32_t *flags;        // [2048] [64..1088) = dense-grid verdicts
     float *records;         // [P][32]
     uint2 *boxes;           // [P]  (lo, hi) packed
     unsigned long long *bitmask;  // [nsuper][nwords]
     int *voxel2pts;         // [V]   (backward, general pts only)
-    uint2 *items;           // [item_cap] backward work items (gaussian, chunk)
-    uint32_t *item_count;   // [1] (inside flags block: flags[16])
+    uint32_t *vols;         // [P]  backward: box volumes
+    uint32_t *bsum;         // [ceil(P/256)] backward: volume sums per 256 Gaussians
     int nwords, nsx, nsy, nsuper;
-    size_t item_cap;
     size_t total_bytes;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-constexpr int kBwdMaxChunks = 32;  // a Gaussian's box is split into at most this many work items
 
 inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, int D)
 {
@@ -57,16 +54,15 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.nsx = (H + kSuper - 1) / kSuper;
     ws.nsy = (W + kSuper - 1) / kSuper;
     ws.nsuper = ws.nsx * ws.nsy;
-    ws.item_cap = (size_t)(P > 0 ? P : 1) * kBwdMaxChunks;
     char *p = (char *)base;
     size_t off = 0;
-    ws.flags = (uint32_t *)(p + off); off += 256;
-    ws.item_count = ws.flags + 16;
+    ws.flags = (uint32_t *)(p + off); off += 8192;
     ws.records = (float *)(p + off); off += align256((size_t)P * kRecDwords * 4);
     ws.boxes = (uint2 *)(p + off); off += align256((size_t)P * 8);
     ws.bitmask = (unsigned long long *)(p + off); off += align256((size_t)ws.nsuper * ws.nwords * 8);
     ws.voxel2pts = (int *)(p + off); off += align256((size_t)H * W * D * 4);
-    ws.items = (uint2 *)(p + off); off += align256(ws.item_cap * 8);
+    ws.vols = (uint32_t *)(p + off); off += align256((size_t)P * 4);
+    ws.bsum = (uint32_t *)(p + off); off += align256((size_t)((P + 255) / 256) * 4);
     ws.total_bytes = off;
     return ws;
 }

@@ -2,19 +2,27 @@
 //
 // The reference (model/head/localagg/src/backward.cu:23-103) runs ONE THREAD per Gaussian
 // over that Gaussian's box voxels: the appended whole-grid "empty" Gaussian is 640 000 x 18
-// serial iterations on a single lane.  Here the work is cut into items of ~4096 voxels
-// (a Gaussian's box is split into at most 32 items), one wave per item, lanes striding
-// over the item's voxels with z fastest (consecutive lanes read consecutive 72-B out_grad
-// rows).  The Gaussian's parameters are wave-uniform (SGPRs); each lane keeps the 28
-// partial gradients in VGPRs and the wave reduces them once per item with DPP adds.
-// Single-item Gaussians store their gradients; split ones combine with fp32 atomics.
+// serial iterations on a single lane.  Here the concatenation of all boxes (R = sum of box
+// volumes, the reference's num_rendered) is cut into equal voxel ranges, one per wave, so
+// every wave does the same amount of work whatever the box sizes are:
 //
-// Launches: [voxel->point map (arbitrary pts only)] -> item table -> gradient kernel.
+//   gf_bwd_vol_kernel    per Gaussian: box volume -> vols[g]; per 256 Gaussians: their sum;
+//                        zeroes the gradient outputs.
+//   gf_splat_bwd_kernel  each wave owns voxel range [w*per, (w+1)*per) of the concatenation.
+//                        It locates its first Gaussian with a binary search over the
+//                        256-Gaussian block prefix (LDS) plus one wave scan, then walks
+//                        Gaussian segments: lanes stride the segment's voxels z-fastest
+//                        (consecutive lanes read consecutive 72-B out_grad rows), the
+//                        Gaussian's parameters are wave-uniform, each lane keeps 28 partial
+//                        gradients, one DPP wave reduction per segment.  A segment covering
+//                        its whole Gaussian stores; partial segments combine with fp32
+//                        atomics (commutative for two parts, so only boxes split over >= 3
+//                        waves -- e.g. the whole-grid Gaussian -- are order-dependent).
+//
+// Launches: [voxel->point map (arbitrary pts only)] -> volumes -> gradient kernel.
 #include "gf_common.hpp"
 
 namespace gf {
-
-constexpr int kBwdChunk = 4096;
 
 struct BwdArgs {
     const float *pts;
@@ -37,10 +45,12 @@ struct BwdArgs {
     float *cov_grad;
     const uint32_t *state;
     int *voxel2pts;
-    uint2 *items;
-    uint32_t *item_count;
-    int P, N, H, W, D, per_axis, force_general, assume_dense;
+    uint32_t *vols;   // [P]
+    uint32_t *bsum;   // [ceil(P/256)]
+    int P, N, H, W, D, per_axis, force_general, assume_dense, nblk;
 };
+
+constexpr int kBwdMaxBlk = 2048;  // LDS prefix capacity: P <= 524 288 Gaussians
 
 __device__ __forceinline__ void box_of(const BwdArgs &a, int g, int lo[3], int hi[3])
 {
@@ -83,49 +93,130 @@ __global__ __launch_bounds__(256) void gf_v2p_scatter_kernel(BwdArgs a)
     atomicMax(a.voxel2pts + ((size_t)x * a.W + y) * a.D + z, n);
 }
 
-// One thread per Gaussian: how many work items its box needs; zero the gradients of
-// Gaussians whose items combine atomically (and of empty ones); append the items.
-__global__ __launch_bounds__(256) void gf_bwd_items_kernel(BwdArgs a)
+// One thread per Gaussian: box volume, 256-Gaussian block sums, zeroed gradient outputs.
+__global__ __launch_bounds__(256) void gf_bwd_vol_kernel(BwdArgs a)
 {
+    __shared__ uint32_t s_w[4];
     const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= a.P) return;
-    int lo[3], hi[3];
-    box_of(a, g, lo, hi);
-    const int nx = hi[0] - lo[0], ny = hi[1] - lo[1], nz = hi[2] - lo[2];
-    const uint32_t vol = (nx > 0 && ny > 0 && nz > 0) ? (uint32_t)nx * (uint32_t)ny * (uint32_t)nz : 0u;
-    const uint32_t n = vol == 0u ? 0u : min((uint32_t)kBwdMaxChunks, (vol + kBwdChunk - 1) / kBwdChunk);
-    if (n != 1u) {
+    uint32_t vol = 0u;
+    if (g < a.P) {
+        int lo[3], hi[3];
+        box_of(a, g, lo, hi);
+        const int nx = hi[0] - lo[0], ny = hi[1] - lo[1], nz = hi[2] - lo[2];
+        vol = (nx > 0 && ny > 0 && nz > 0) ? (uint32_t)nx * (uint32_t)ny * (uint32_t)nz : 0u;
+        a.vols[g] = vol;
         a.means_grad[3 * g] = 0.f; a.means_grad[3 * g + 1] = 0.f; a.means_grad[3 * g + 2] = 0.f;
         a.opa_grad[g] = 0.f;
         for (int ch = 0; ch < kC; ++ch) a.sem_grad[(size_t)kC * g + ch] = 0.f;
         for (int k = 0; k < 6; ++k) a.cov_grad[6 * g + k] = 0.f;
     }
-    if (n > 0u) {
-        const uint32_t base = atomicAdd(a.item_count, n);
-        for (uint32_t c = 0; c < n; ++c) a.items[base + c] = make_uint2((uint32_t)g, c | (n << 16));
-    }
+    uint32_t sum = vol;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) a.bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);
+    return (uint32_t)x;
+}
+
+// DPP add-reduce whose total is valid in lane 63 only (no broadcast)
+__device__ __forceinline__ float wave_sum63(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true));
+    return v;
 }
 
 template <int VARIANT>
 __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
 {
-    const int lane = lane_id();
-    const int wave_global = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    const int nwaves = (int)gridDim.x * 4;
-    const int count = (int)*a.item_count;
+    __shared__ unsigned long long s_pref[kBwdMaxBlk + 1];  // exclusive prefix of the block sums
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    // ---- every workgroup rebuilds the (small) block prefix in LDS
+    {
+        // serial-in-chunks scan by wave 0: 64 block sums per step
+        if (tid < 64) {
+            unsigned long long run = 0ull;
+            for (int b0 = 0; b0 < a.nblk; b0 += 64) {
+                const int b = b0 + lane;
+                const uint32_t vsum = b < a.nblk ? a.bsum[b] : 0u;
+                // 64-bit inclusive scan via two 32-bit halves is unnecessary: a chunk of 64 block
+                // sums (each < 2^31) is accumulated in 64 bits with shuffles (not a hot path)
+                unsigned long long x = vsum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned long long up = __shfl_up(x, d, 64);
+                    if (lane >= d) x += up;
+                }
+                if (b < a.nblk) s_pref[b] = run + x - vsum;
+                run += __shfl(x, 63, 64);
+            }
+            if (lane == 0) s_pref[a.nblk] = run;
+        }
+        __syncthreads();
+    }
+    const unsigned long long R = s_pref[a.nblk];
+    const int wave_global = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (tid >> 6)));
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * 4ull;
+    const unsigned long long per = (((R + nwaves - 1) / nwaves) + 63ull) & ~63ull;
+    unsigned long long r0 = (unsigned long long)wave_global * per;
+    const unsigned long long r1 = min(R, r0 + per);
+    if (r0 >= R) return;
     const bool dense = pts_are_dense(a);
 
-    for (int it = wave_global; it < count; it += nwaves) {
-        const uint2 item = a.items[it];
-        const int g = (int)item.x;
-        const int c = (int)(item.y & 0xFFFFu), n = (int)(item.y >> 16);
+    // ---- locate the Gaussian containing voxel r0: binary search over blocks, then a wave scan
+    int blo = 0, bhi = a.nblk;  // invariant: s_pref[blo] <= r0 < s_pref[bhi]
+    while (bhi - blo > 1) {
+        const int mid = (blo + bhi) >> 1;
+        if (s_pref[mid] <= r0) blo = mid; else bhi = mid;
+    }
+    int g = blo * 256;
+    unsigned long long gstart = s_pref[blo];  // first voxel of Gaussian g in the concatenation
+    for (int k = 0; k < 4; ++k) {
+        const int gi = blo * 256 + k * 64 + lane;
+        const uint32_t vv = gi < a.P ? a.vols[gi] : 0u;
+        const uint32_t incl = wave_inclusive_scan_u32(vv);
+        const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
+        if (r0 - gstart < (unsigned long long)tot) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(gstart + incl > r0);
+            const int j = __builtin_ctzll(m);
+            g = blo * 256 + k * 64 + j;
+            gstart += __builtin_amdgcn_readlane(incl, j) - __builtin_amdgcn_readlane(vv, j);
+            break;
+        }
+        gstart += tot;
+        g = blo * 256 + (k + 1) * 64;
+    }
+
+    // ---- walk Gaussian segments until the range is exhausted
+    while (r0 < r1 && g < a.P) {
+        const int vol = (int)a.vols[g];
+        const int o0 = (int)(r0 - gstart);                                  // first voxel of the segment
+        const int o1 = (int)min((unsigned long long)vol, r1 - gstart);      // one past its last voxel
+        if (vol == 0 || o0 >= vol) {  // empty box (or exactly at its end): next Gaussian
+            gstart += (unsigned long long)vol;
+            ++g;
+            continue;
+        }
         int lo[3], hi[3];
         box_of(a, g, lo, hi);
         const int ny = hi[1] - lo[1], nz = hi[2] - lo[2];
-        const int vol = (hi[0] - lo[0]) * ny * nz;
-        const int cs = (((vol + n - 1) / n) + 63) & ~63;
-        const int start = c * cs;
-        const int end = min(vol, start + cs);
 
         // wave-uniform Gaussian parameters
         const float mx = a.means3D[3 * g], my = a.means3D[3 * g + 1], mz = a.means3D[3 * g + 2];
@@ -148,8 +239,8 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
 #pragma unroll
         for (int ch = 0; ch < kC; ++ch) sg[ch] = 0.f;
 
-        // lane's first voxel of the item, decoded once; then advanced by 64 per iteration
-        int i = start + lane;
+        // lane's first voxel of the segment, decoded once; then advanced by 64 per iteration
+        int i = o0 + lane;
         int z = i % nz;
         int t = i / nz;
         int y = t % ny;
@@ -157,7 +248,7 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
         const int rz = 64 % nz, qz = 64 / nz;
         const int ry = qz % ny, qx = qz / ny;
 
-        for (; i < end; i += 64) {
+        for (; i < o1; i += 64) {
             const size_t v = ((size_t)(lo[0] + x) * a.W + (lo[1] + y)) * a.D + (lo[2] + z);
             const int p = dense ? (int)v : a.voxel2pts[v];
             if (p >= 0) {
@@ -231,15 +322,15 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
             x += qx + carry;
         }
 
-        // reduce across the wave
-        mg0 = wave_sum(mg0); mg1 = wave_sum(mg1); mg2 = wave_sum(mg2);
-        og = wave_sum(og);
-        cg0 = wave_sum(cg0); cg1 = wave_sum(cg1); cg2 = wave_sum(cg2);
-        cg3 = wave_sum(cg3); cg4 = wave_sum(cg4); cg5 = wave_sum(cg5);
+        // reduce across the wave (totals valid in lane 63)
+        mg0 = wave_sum63(mg0); mg1 = wave_sum63(mg1); mg2 = wave_sum63(mg2);
+        og = wave_sum63(og);
+        cg0 = wave_sum63(cg0); cg1 = wave_sum63(cg1); cg2 = wave_sum63(cg2);
+        cg3 = wave_sum63(cg3); cg4 = wave_sum63(cg4); cg5 = wave_sum63(cg5);
 #pragma unroll
-        for (int ch = 0; ch < kC; ++ch) sg[ch] = wave_sum(sg[ch]);
+        for (int ch = 0; ch < kC; ++ch) sg[ch] = wave_sum63(sg[ch]);
         if (VARIANT == GF_SPLAT_PROB) {
-            dg = wave_sum(dg);
+            dg = wave_sum63(dg);
             // deter_grad terms, model/head/localagg_prob/src/backward.cu:102-107
             cg0 += dg * (c1y * c1z - c2y * c2y);
             cg1 += dg * (c1x * c1z - c2z * c2z);
@@ -248,11 +339,11 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
             cg4 += 2 * dg * (c2x * c2z - c1x * c2y);
             cg5 += 2 * dg * (c2x * c2y - c1y * c2z);
         }
-        if (lane == 0) {
+        if (lane == 63) {
             float *pm = a.means_grad + 3 * (size_t)g;
             float *pc = a.cov_grad + 6 * (size_t)g;
             float *ps = a.sem_grad + (size_t)kC * g;
-            if (n == 1) {
+            if (o0 == 0 && o1 == vol) {
                 pm[0] = mg0; pm[1] = mg1; pm[2] = mg2;
                 a.opa_grad[g] = og;
                 pc[0] = cg0; pc[1] = cg1; pc[2] = cg2; pc[3] = cg3; pc[4] = cg4; pc[5] = cg5;
@@ -266,6 +357,11 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
 #pragma unroll
                 for (int ch = 0; ch < kC; ++ch) unsafeAtomicAdd(ps + ch, sg[ch]);
             }
+        }
+        r0 = gstart + (unsigned long long)o1;
+        if (o1 == vol) {
+            gstart += (unsigned long long)vol;
+            ++g;
         }
     }
 }
@@ -291,6 +387,8 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     GF_CHECK_ARG(P >= 0 && N >= 0, "negative size");
     GF_CHECK_ARG(H > 0 && W > 0 && D > 0 && H <= 2047 && W <= 2047 && D <= 1023, "grid size out of range");
     GF_CHECK_ARG((long long)H * W * D < (1ll << 31), "grid too large");
+    GF_CHECK_ARG(P <= 256 * kBwdMaxBlk, "too many Gaussians for the backward block prefix");
+    GF_CHECK_ARG((long long)H * W * D < (1ll << 24), "grid too large for the backward (256-Gaussian volume sums are 32-bit)");
     if (P == 0) return GF_OK;
     GF_CHECK_ARG(means3D && means3D_int && opacity && semantics && radii && cov3D, "null Gaussian pointer");
     GF_CHECK_ARG(means3D_grad && opacity_grad && semantics_grad && cov3D_grad, "null gradient output");
@@ -308,19 +406,18 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     a.semantics = semantics; a.radii = radii; a.cov3D = cov3D; a.logits = logits; a.bin_logits = bin_logits;
     a.probability = probability; a.out_grad = logits_grad; a.bin_grad = bin_logits_grad; a.dens_grad = density_grad;
     a.means_grad = means3D_grad; a.opa_grad = opacity_grad; a.sem_grad = semantics_grad; a.cov_grad = cov3D_grad;
-    a.state = (const uint32_t *)state; a.voxel2pts = ws.voxel2pts; a.items = ws.items; a.item_count = ws.item_count;
-    a.P = P; a.N = N; a.H = H; a.W = W; a.D = D; a.per_axis = radii_per_axis ? 1 : 0;
+    a.state = (const uint32_t *)state; a.voxel2pts = ws.voxel2pts; a.vols = ws.vols; a.bsum = ws.bsum;
+    a.P = P; a.N = N; a.H = H; a.W = W; a.D = D; a.per_axis = radii_per_axis ? 1 : 0; a.nblk = (P + 255) / 256;
     const long long V = (long long)H * W * D;
     a.force_general = ((long long)N != V || (flags & GF_PTS_GENERAL)) ? 1 : 0;
     a.assume_dense = (!a.force_general && (flags & GF_PTS_ASSUME_DENSE)) ? 1 : 0;
 
-    (void)hipMemsetAsync(ws.item_count, 0, sizeof(uint32_t), stream);
     if (!a.assume_dense) {
         hipLaunchKernelGGL(gf_v2p_fill_kernel, dim3(1024), dim3(256), 0, stream, a);
         if (N > 0) hipLaunchKernelGGL(gf_v2p_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
     }
-    hipLaunchKernelGGL(gf_bwd_items_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
-    const int blocks = 2048;
+    hipLaunchKernelGGL(gf_bwd_vol_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
+    const int blocks = 1024;  // 4096 waves, 4 workgroups per CU (VGPR-limited)
     if (variant == GF_SPLAT_BASE)
         hipLaunchKernelGGL(gf_splat_bwd_kernel<GF_SPLAT_BASE>, dim3(blocks), dim3(256), 0, stream, a);
     else

@@ -5,24 +5,33 @@
 // radix-sort them, find per-voxel ranges, then gather per query point (forward.cu:34-82).
 // Seven dependent launches, a blocking D2H copy and ~GBs of sort traffic.
 //
-// What this file does instead (two launches, no host sync, no sort, no atomics,
+// What this file does instead (two launches, no host sync, no sort, no global atomics,
 // deterministic ascending-Gaussian summation order like the reference's stable sort):
 //
 //   1. gf_splat_prep_kernel   one lane per Gaussian: integer box (bit-exact with
-//      src/auxiliary.h:8-20), a packed 128-B record {mean, opa, cov6, box, sem[18]}, and
-//      -- via wave ballots, no atomics -- one 64-bit word per (supertile, wave) of a
-//      bitmask "Gaussian g touches supertile s" (supertile = 20x20 voxel columns).
-//   2. gf_splat_render_dense_kernel   one 256-thread workgroup per tile (4x4 columns x D),
-//      one wave per 4x4x4 brick, one lane per voxel.  The workgroup turns its supertile's
-//      bitmask into an ascending candidate list (popcount scan), filters it against the
-//      tile footprint into an LDS list, and every wave walks that list: Gaussian records
-//      arrive through the scalar cache into SGPRs (wave-uniform), the per-lane box test is
-//      a 64-bit SALU mask applied as EXEC, and the 18 semantic accumulators live in VGPRs.
-//      Rows are transposed through LDS so the 4.6 KB a brick owns is written as 16-B
-//      stores over 288-B contiguous runs.
-//   3. gf_splat_render_general_kernel   arbitrary query points (one lane per point); also
-//      the automatic fallback when the dense kernel finds that pts is not the dense grid.
+//      src/auxiliary.h:8-20), a packed 128-B record {mean, opa, cov6, box, sem[18]}, and a
+//      bitmask "Gaussian g touches supertile s" (supertile = 8x8 voxel columns) built with
+//      LDS atomic-OR and written out as whole words -- order-independent, hence
+//      deterministic.  Extra workgroups of the same launch check whether pts is the dense
+//      voxel-centre grid (point n in voxel n).
+//   2. gf_splat_render_kernel   one 256-thread workgroup per tile (4x4 columns x D), one
+//      wave per 4x4x4 brick, one lane per voxel.  The workgroup filters its supertile's
+//      bitmask against the tile footprint into an ascending LDS list; every wave walks
+//      that list: per 64 entries the brick's lane masks are computed lane-parallel, then
+//      one scalar iteration per hit -- the Gaussian record arrives through the scalar
+//      cache into SGPRs (wave-uniform), the box test is a 64-bit mask applied as EXEC, the
+//      18 semantic accumulators live in VGPRs.  Rows are transposed through LDS so the
+//      4.6 KB a brick owns is written as 16-B stores over 288-B contiguous runs.
+//      If the prep kernel found pts is NOT the dense grid, the same launch runs the
+//      arbitrary-points body instead (one lane per point).
+//   3. gf_splat_render_general_kernel   arbitrary query points when N != H*W*D.
+#include <stdlib.h>
+
 #include "gf_common.hpp"
+
+#ifndef GF_TIMELINE
+#define GF_TIMELINE 0  // -DGF_TIMELINE=1: per-workgroup timestamps of the render kernel (tools/timeline.py)
+#endif
 
 namespace gf {
 
@@ -33,13 +42,16 @@ struct PrepArgs {
     const float *semantics;
     const int *radii;
     const float *cov3D;
+    const int *points_int;
     float *records;
     uint2 *boxes;
     unsigned long long *bitmask;
-    uint32_t *flags;
-    uint32_t *state;
-    int P, H, W, D, nwords, nsx, nsy, per_axis, variant, state_init;
+    uint32_t *verify_flags;  // [kVerifyBlocks]
+    int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify;
 };
+
+constexpr int kVerifyBlocks = 1024;    // verification waves; render thread t reads 4 verdicts
+constexpr int kPrepSuperChunk = 2048;  // supertiles per LDS pass of the prep kernel (16 KB)
 
 // Integer box of Gaussian g: model/head/localagg/src/auxiliary.h:8-20 (scalar radius) and
 // model/head/localagg_prob_fast/src/auxiliary.h:8-20 (per-axis radius).
@@ -58,19 +70,37 @@ __device__ __forceinline__ void gaussian_box(const int *__restrict__ means_int, 
     lo[2] = min(D, max(0, m2 - r2)); hi[2] = min(D, max(0, m2 + r2 + 1));
 }
 
-__global__ __launch_bounds__(256) void gf_splat_prep_kernel(PrepArgs a)
+__global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
 {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    const int wave_global = g >> 6;
-    const int lane = lane_id();
-    if (g == 0) {
-        a.flags[0] = 0u;
-        if (a.state) a.state[0] = (uint32_t)a.state_init;
+    // One wave per workgroup.  Gaussian role: 64 Gaussians -> one bitmask word per supertile.
+    __shared__ unsigned long long s_bits[kPrepSuperChunk];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= a.nprep_blocks) {
+        // ---- verification role: is point n in voxel n for all n?  Each wave reports its own
+        // slice unconditionally (no zero-initialised flag needed).
+        const int vb = (int)blockIdx.x - a.nprep_blocks;
+        bool bad = false;
+        for (long long n = (long long)vb * 64 + lane; n < a.N; n += (long long)kVerifyBlocks * 64) {
+            const int x = a.points_int[3 * n], y = a.points_int[3 * n + 1], z = a.points_int[3 * n + 2];
+            // unique decomposition of n: y in [0,W), z in [0,D) and the key equals n
+            bad |= !(y >= 0 && y < a.W && z >= 0 && z < a.D && ((long long)x * a.W + y) * a.D + z == n);
+        }
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
+        if (lane == 0) a.verify_flags[vb] = any ? 1u : 0u;
+        return;
     }
+    const int g = blockIdx.x * 64 + lane;
     const bool valid = g < a.P;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     if (valid) gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
     const bool nonempty = valid && hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2];
+    // supertile range touched by the box
+    const int sx_lo = lo[0] / kSuper, sx_hi = nonempty ? (hi[0] - 1) / kSuper : -1;
+    const int sy_lo = lo[1] / kSuper, sy_hi = nonempty ? (hi[1] - 1) / kSuper : -1;
+    const int npairs = nonempty ? (sx_hi - sx_lo + 1) * (sy_hi - sy_lo + 1) : 0;
+    const int nsuper = a.nsx * a.nsy;
+    // zero the first LDS chunk while the parameter loads are in flight
+    for (int i = lane; i < min(kPrepSuperChunk, nsuper); i += 64) s_bits[i] = 0ull;
     if (valid) {
         const uint32_t plo = pack3(lo[0], lo[1], lo[2]);
         const uint32_t phi = nonempty ? pack3(hi[0], hi[1], hi[2]) : plo;
@@ -94,28 +124,35 @@ __global__ __launch_bounds__(256) void gf_splat_prep_kernel(PrepArgs a)
         rec[6] = make_float4(sm[12], sm[13], sm[14], sm[15]);
         rec[7] = make_float4(sm[16], sm[17], kdet, 0.f);
     }
-    // supertile range touched by the box
-    const int sx_lo = lo[0] / kSuper, sx_hi = nonempty ? (hi[0] - 1) / kSuper : -1;
-    const int sy_lo = lo[1] / kSuper, sy_hi = nonempty ? (hi[1] - 1) / kSuper : -1;
-    if (wave_global >= a.nwords) return;
-    for (int sx = 0; sx < a.nsx; ++sx) {
-        const bool inx = nonempty && sx >= sx_lo && sx <= sx_hi;
-        const unsigned long long xmask = __builtin_amdgcn_ballot_w64(inx);
-        for (int sy0 = 0; sy0 < a.nsy; sy0 += 64) {
-            // lane l of this pass owns supertile column sy0 + l
-            unsigned long long mine = 0ull;
-            const int nsy_here = min(64, a.nsy - sy0);
-            if (xmask != 0ull) {
-                for (int j = 0; j < nsy_here; ++j) {
-                    const int sy = sy0 + j;
-                    const unsigned long long word =
-                        __builtin_amdgcn_ballot_w64(inx && sy >= sy_lo && sy <= sy_hi);
-                    if (lane == j) mine = word;
+    const unsigned long long mybit = 1ull << lane;
+    for (int s0 = 0; s0 < nsuper; s0 += kPrepSuperChunk) {
+        const int ns = min(kPrepSuperChunk, nsuper - s0);
+        if (s0 > 0)
+            for (int i = lane; i < ns; i += 64) s_bits[i] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // single wave: LDS ops stay ordered
+        // small footprints: each lane ORs its own bit (order-independent => deterministic)
+        if (npairs > 0 && npairs <= 16) {
+            for (int sx = sx_lo; sx <= sx_hi; ++sx)
+                for (int sy = sy_lo; sy <= sy_hi; ++sy) {
+                    const int s = sx * a.nsy + sy - s0;
+                    if (s >= 0 && s < ns) atomicOr(&s_bits[s], mybit);
                 }
-            }
-            if (lane < nsy_here)
-                a.bitmask[((size_t)sx * a.nsy + sy0 + lane) * a.nwords + wave_global] = mine;
         }
+        // large footprints (e.g. the whole-grid "empty" Gaussian): the wave cooperates
+        unsigned long long big = __builtin_amdgcn_ballot_w64(npairs > 16);
+        while (big) {
+            const int j = __builtin_ctzll(big);
+            big &= big - 1;
+            const int bx_lo = __builtin_amdgcn_readlane(sx_lo, j), bx_hi = __builtin_amdgcn_readlane(sx_hi, j);
+            const int by_lo = __builtin_amdgcn_readlane(sy_lo, j), by_hi = __builtin_amdgcn_readlane(sy_hi, j);
+            const int ny = by_hi - by_lo + 1, tot = (bx_hi - bx_lo + 1) * ny;
+            for (int i = lane; i < tot; i += 64) {
+                const int s = (bx_lo + i / ny) * a.nsy + by_lo + i % ny - s0;
+                if (s >= 0 && s < ns) atomicOr(&s_bits[s], 1ull << j);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (int i = lane; i < ns; i += 64) a.bitmask[(size_t)(s0 + i) * a.nwords + blockIdx.x] = s_bits[i];
     }
 }
 
@@ -130,36 +167,58 @@ struct RenderArgs {
     float *out_bin;
     float *out_density;
     float *out_prob;
-    uint32_t *flags;
+    const uint32_t *verify_flags;
     uint32_t *state;
-    int P, N, nwords, H, W, D, nsx, nsy, ntiles_total, only_if_nondense, verify_dense;
+    unsigned long long *timeline;  // debug: 4 timestamps per workgroup (null = off)
+    int P, N, nwords, H, W, D, nsx, nsy, ntiles_total, verify_dense;
 };
 
-constexpr int kCandCap = 2048;   // candidates (bitmask bits) staged per pass
-constexpr int kListCap = 640;    // filtered tile list entries held in LDS (16 B each)
+constexpr int kListCap = 1536;  // tile list entries (12 B each) held in LDS
+constexpr int kRecUsed = 31;    // record dwords the render kernels read (0..30)
 constexpr int kBlock = 256;
+
+// exp flavours: 0 = ocml expf (13 VALU), 1 = v_exp_f32 with a compensated argument
+// (7 VALU, <= ~3 ulp, results below 2^-126 flush to 0), 2 = __expf (rel. err ~2e-6)
+enum { kExpLibm = 0, kExpComp = 1, kExpFast = 2 };
+
+template <int EXP>
+__device__ __forceinline__ float gf_exp(float x)
+{
+    if (EXP == kExpLibm) return expf(x);
+    if (EXP == kExpFast) return __expf(x);
+    const float kL2E = 1.44269504088896340736f;     // fl(log2 e)
+    const float kL2ELo = 1.925963033500011e-08f;    // log2 e - fl(log2 e)
+    const float t = x * kL2E;
+    float r = fmaf(x, kL2E, -t);                    // exact rounding error of the product
+    r = fmaf(x, kL2ELo, r);
+    const float e = __builtin_amdgcn_exp2f(t);      // v_exp_f32
+    return e * fmaf(r, 0.6931471805599453f, 1.0f);  // 2^(t+r) = 2^t * (1 + r ln2 + O(r^2))
+}
 
 struct Acc {
     float c[kC];
     float bin, dens, psum;
 };
 
-template <int VARIANT, bool FASTEXP, typename RecPtr>
+template <int VARIANT, int EXP, typename RecPtr>
 __device__ __forceinline__ void accumulate(Acc &A, RecPtr rec, float px, float py, float pz)
 {
     // model/head/localagg/src/forward.cu:66-74 (base), model/head/localagg_prob/src/forward.cu:73-86 (prob)
     const float dx = rec[kRecMean] - px, dy = rec[kRecMean + 1] - py, dz = rec[kRecMean + 2] - pz;
-    float power = rec[kRecCov] * dx * dx + rec[kRecCov + 1] * dy * dy + rec[kRecCov + 2] * dz * dz;
-    power = -0.5f * power - (rec[kRecCov + 3] * dx * dy + rec[kRecCov + 4] * dy * dz + rec[kRecCov + 5] * dx * dz);
-    const float e = FASTEXP ? __expf(power) : expf(power);
+    // -1/2 d^T Sigma^-1 d, written with explicit fmaf so that every instantiation (SGPR or
+    // VGPR record, dense or arbitrary-points body) rounds identically.
+    const float q = fmaf(rec[kRecCov + 2] * dz, dz, fmaf(rec[kRecCov + 1] * dy, dy, (rec[kRecCov] * dx) * dx));
+    const float r = fmaf(rec[kRecCov + 5] * dx, dz, fmaf(rec[kRecCov + 4] * dy, dz, (rec[kRecCov + 3] * dx) * dy));
+    const float power = fmaf(-0.5f, q, -r);
+    const float e = gf_exp<EXP>(power);
     if (VARIANT == GF_SPLAT_BASE) {
         const float w = rec[kRecOpa] * e;
 #pragma unroll
-        for (int ch = 0; ch < kC; ++ch) A.c[ch] += rec[kRecSem + ch] * w;
+        for (int ch = 0; ch < kC; ++ch) A.c[ch] = fmaf(rec[kRecSem + ch], w, A.c[ch]);
     } else {
         const float prob = rec[kRecKdet] * e * rec[kRecOpa];
 #pragma unroll
-        for (int ch = 0; ch < kC; ++ch) A.c[ch] += rec[kRecSem + ch] * prob;
+        for (int ch = 0; ch < kC; ++ch) A.c[ch] = fmaf(rec[kRecSem + ch], prob, A.c[ch]);
         A.bin = (1 - e) * A.bin;
         A.dens = e + A.dens;
         A.psum = prob + A.psum;
@@ -190,49 +249,158 @@ __device__ __forceinline__ unsigned long long mask_x(int a, int b)
 {
     return bits_below(16 * b) & ~bits_below(16 * a);
 }
-__device__ __forceinline__ unsigned long long mask_y(int a, int b)
+__device__ __forceinline__ uint32_t mask_y32(int a, int b)
 {
-    const unsigned long long m16 = bits_below(4 * b) & ~bits_below(4 * a);  // < 2^16
-    return m16 * 0x0001000100010001ull;
+    const uint32_t m16 = ((1u << (4 * b)) - 1u) & ~((1u << (4 * a)) - 1u);  // a, b <= 4: < 2^16
+    return m16 | (m16 << 16);
 }
-__device__ __forceinline__ unsigned long long mask_z(int a, int b)
+__device__ __forceinline__ uint32_t mask_z32(int a, int b)
 {
-    const unsigned long long m4 = bits_below(b) & ~bits_below(a);  // < 2^4
-    return m4 * 0x1111111111111111ull;
+    const uint32_t m4 = ((1u << b) - 1u) & ~((1u << a) - 1u);  // < 2^4
+    return m4 * 0x11111111u;
 }
+
 // records are read-only for the render kernels: the constant address space makes the
 // wave-uniform record fetch a scalar (SMEM) load straight into SGPRs.
 using crec_t = const float __attribute__((address_space(4))) *;
 
-template <int VARIANT, bool FASTEXP>
-__global__ __launch_bounds__(kBlock, 8) void gf_splat_render_dense_kernel(RenderArgs a)
+// wave-wide inclusive prefix sum with DPP adds (row_shr 1,2,4,8, row_bcast 15/31)
+__device__ __forceinline__ int wave_inclusive_scan(int v)
 {
-    // LDS: candidate ids | tile list (g, lo, hi) | scan scratch; the output staging area
-    // (4 waves x 64 voxels x 18 floats) aliases the first two after the list is consumed.
-    // A list entry is {gaussian id, xy lane mask (64 bit, shared by the tile's bricks), z range}.
-    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kCandCap + 4 * kListCap + 64];
-    uint32_t *s_cand = s_mem;
-    uint4 *s_list = reinterpret_cast<uint4 *>(s_mem + kCandCap);
-    uint32_t *s_scan = s_mem + kCandCap + 4 * kListCap;  // wave sums: [0..3], [8..11], [16..19]
-    static_assert(kCandCap + 4 * kListCap >= 4 * 64 * kC, "staging area must fit");
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+    return v;
+}
+
+// Arbitrary query points: one lane per point, candidates straight from the supertile
+// bitmask in ascending Gaussian order (same per-voxel order as the dense body).
+template <int VARIANT, int EXP>
+__device__ __forceinline__ void general_body(const RenderArgs &a)
+{
+    for (long long n = (long long)blockIdx.x * kBlock + threadIdx.x; n < a.N; n += (long long)gridDim.x * kBlock) {
+        const int X = a.points_int[3 * n], Y = a.points_int[3 * n + 1], Z = a.points_int[3 * n + 2];
+        const float px = a.pts[3 * n], py = a.pts[3 * n + 1], pz = a.pts[3 * n + 2];
+        Acc A;
+#pragma unroll
+        for (int ch = 0; ch < kC; ++ch) A.c[ch] = 0.f;
+        A.bin = 1.f; A.dens = 0.f; A.psum = 0.f;
+        if (X >= 0 && X < a.H && Y >= 0 && Y < a.W && Z >= 0 && Z < a.D) {
+            const int s = (X / kSuper) * a.nsy + (Y / kSuper);
+            const unsigned long long *__restrict__ bm = a.bitmask + (size_t)s * a.nwords;
+            for (int w = 0; w < a.nwords; ++w) {
+                unsigned long long word = bm[w];
+                while (word) {
+                    const int j = __builtin_ctzll(word);
+                    word &= word - 1;
+                    const int g = w * 64 + j;
+                    const uint2 box = a.boxes[g];
+                    if (X >= ux(box.x) && X < ux(box.y) && Y >= uy(box.x) && Y < uy(box.y) && Z >= uz(box.x) &&
+                        Z < uz(box.y)) {
+                        float rec[kRecDwords];
+                        const float4 *r4 = reinterpret_cast<const float4 *>(a.records + (size_t)g * kRecDwords);
+#pragma unroll
+                        for (int q = 0; q < kRecDwords / 4; ++q) {
+                            const float4 t = r4[q];
+                            rec[4 * q] = t.x; rec[4 * q + 1] = t.y; rec[4 * q + 2] = t.z; rec[4 * q + 3] = t.w;
+                        }
+                        accumulate<VARIANT, EXP>(A, rec, px, py, pz);
+                    }
+                }
+            }
+        }
+        if (VARIANT == GF_SPLAT_PROB) {
+            prob_normalise(A);
+            a.out_bin[n] = 1 - A.bin;
+            a.out_density[n] = A.dens;
+            a.out_prob[n] = A.psum;
+        }
+        float *o = a.out_logits + n * kC;
+#pragma unroll
+        for (int ch = 0; ch < kC; ch += 2) *reinterpret_cast<float2 *>(o + ch) = make_float2(A.c[ch], A.c[ch + 1]);
+    }
+}
+
+template <int VARIANT, int EXP>
+__global__ __launch_bounds__(kBlock) void gf_splat_render_general_kernel(RenderArgs a)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.state) a.state[0] = 1u;
+    general_body<VARIANT, EXP>(a);
+}
+
+// Tuning switches (defaults = best measured; see profiles/README.md)
+#ifndef GF_DBUF
+#define GF_DBUF 0      // 1: software-pipeline the hit loop with two SGPR record sets
+#endif
+#ifndef GF_OCC
+#define GF_OCC 8       // waves per SIMD the render kernel is compiled for
+#endif
+#ifndef GF_DIAG
+#define GF_DIAG 0      // development diagnostics (tools/variants.py); 0 in the product
+#endif
+#ifndef GF_OUT_SC1
+#define GF_OUT_SC1 0   // 1: write logits with sc1 (write-through, do not keep the line in L2)
+#endif
+
+__device__ __forceinline__ void store_row4(float *dst, float4 v)
+{
+#if GF_OUT_SC1
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 vv = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+#else
+    *reinterpret_cast<float4 *>(dst) = v;
+#endif
+}
+
+template <int VARIANT, int EXP>
+__global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderArgs a)
+{
+    // LDS: tile list {gaussian id, box lo, box hi} + scan scratch; the output staging area
+    // (4 waves x 64 voxels x 18 floats) aliases the list once it has been consumed.
+    constexpr int kStage = 4 * 64 * kC;
+    constexpr int kMem = kStage > 3 * kListCap ? kStage : 3 * kListCap;
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kMem + 64];
+    uint32_t *s_lg = s_mem, *s_llo = s_mem + kListCap, *s_lhi = s_mem + 2 * kListCap;
+    uint32_t *s_scan = s_mem + kMem;  // [0..3] wave totals, [8..40) group bases (dense chunks)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // XCD-aware tile order: consecutive logical tiles (supertile-major) stay on one XCD so
-    // its L2 keeps that supertile's bitmask, boxes and records.
+    // tile of this workgroup.  XCD-aware order: consecutive logical tiles (supertile-major)
+    // stay on one XCD so its L2 keeps that supertile's bitmask, boxes and records.
     const int per_xcd = (int)(gridDim.x >> 3);
     const int logical = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    if (logical >= a.ntiles_total) return;
     const int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
     const int X0 = ((s / a.nsy) * kTilesPerSuperAxis + t / kTilesPerSuperAxis) * kTile;
     const int Y0 = ((s % a.nsy) * kTilesPerSuperAxis + t % kTilesPerSuperAxis) * kTile;
-    if (X0 >= a.H || Y0 >= a.W) return;
-    const unsigned long long *__restrict__ bm = a.bitmask + (size_t)s * a.nwords;
+    const bool tile_ok = logical < a.ntiles_total && X0 < a.H && Y0 < a.W;
+    const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nwords;
+
+    // issue the first loads before the verdict barrier: verdicts, first bitmask word
+    uint4 vf = make_uint4(0, 0, 0, 0);
+    if (a.verify_dense) vf = reinterpret_cast<const uint4 *>(a.verify_flags)[tid];
+    unsigned long long word_next = (tile_ok && tid < a.nwords) ? bm[tid] : 0ull;
+
+    // Is pts the dense voxel-centre grid?  (verdict of the prep kernel's verification waves)
+    int nondense = 0;
+    if (a.verify_dense) nondense = __syncthreads_or((vf.x | vf.y | vf.z | vf.w) != 0u);
+    if (blockIdx.x == 0 && tid == 0 && a.state) a.state[0] = nondense ? 1u : 0u;
+    if (nondense) {
+        general_body<VARIANT, EXP>(a);
+        return;
+    }
+    if (!tile_ok) return;
 
     const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
     const int X = X0 + lx, Y = Y0 + ly;
+#if GF_TIMELINE
+    if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x] = wall_clock64();
+#endif
 
     for (int zg = 0; zg * 16 < a.D; ++zg) {
         const int Z0 = zg * 16 + wave * 4;  // this wave's brick
@@ -240,148 +408,189 @@ __global__ __launch_bounds__(kBlock, 8) void gf_splat_render_dense_kernel(Render
         const bool lane_valid = X < a.H && Y < a.W && Z < a.D;
         const size_t v = ((size_t)X * a.W + Y) * a.D + Z;
         float px = 0.f, py = 0.f, pz = 0.f;
-        if (lane_valid) {
-            px = a.pts[3 * v]; py = a.pts[3 * v + 1]; pz = a.pts[3 * v + 2];
-            if (a.verify_dense) {
-                const int qx = a.points_int[3 * v], qy = a.points_int[3 * v + 1], qz = a.points_int[3 * v + 2];
-                if (qx != X || qy != Y || qz != Z) {
-                    a.flags[0] = 1u;
-                    if (a.state) a.state[0] = 1u;
-                }
-            }
-        }
+        if (lane_valid) { px = a.pts[3 * v]; py = a.pts[3 * v + 1]; pz = a.pts[3 * v + 2]; }
         Acc A;
 #pragma unroll
         for (int ch = 0; ch < kC; ++ch) A.c[ch] = 0.f;
         A.bin = 1.f; A.dens = 0.f; A.psum = 0.f;
+        if (zg > 0) word_next = tid < a.nwords ? bm[tid] : 0ull;
 
-        // Resumable producer of list entries (all state block-uniform except `word`):
-        //   chunk  = kBlock bitmask words (one per thread)
-        //   pass   = the chunk's set bits -> s_cand in ascending order (a chunk denser than
-        //            kCandCap is split into 8 sub-passes of 32 words, <= 2048 bits each)
-        //   round  = kBlock candidates tested against the tile footprint -> s_list (ascending)
-        // Whenever the list could overflow (or the input is exhausted) every wave consumes it.
-        int w_next = 0, wi = 0, sub = 0, nsub = 0, total = 0, r0 = 0, list_len = 0;
-        unsigned long long word = 0ull;
-        bool exhausted = false;
-        while (true) {
-            list_len = 0;
-            while (list_len + kBlock <= kListCap) {
-                if (r0 >= total) {
-                    if (sub >= nsub) {
-                        if (w_next >= a.nwords) { exhausted = true; break; }
-                        wi = w_next + tid;
-                        w_next += kBlock;
-                        word = wi < a.nwords ? bm[wi] : 0ull;
-                        int csum = __builtin_popcountll(word);
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) csum += __shfl_xor(csum, d, 64);
-                        __syncthreads();  // previous users of s_scan[16..19] are done
-                        if (lane == 0) s_scan[16 + wave] = (uint32_t)csum;
-                        __syncthreads();
-                        const int chunk_total =
-                            __builtin_amdgcn_readfirstlane((int)(s_scan[16] + s_scan[17] + s_scan[18] + s_scan[19]));
-                        nsub = chunk_total == 0 ? 0 : (chunk_total <= kCandCap ? 1 : 8);
-                        sub = 0;
-                        continue;
+        // ---- produce / consume.  Producer: filter the supertile's bitmask against the tile
+        // footprint, one word per thread and kBlock words per chunk; the hits of a chunk are
+        // appended to the LDS list in ascending Gaussian order (popcount scan) as ONE group, or
+        // -- for a chunk denser than the list -- as 32 groups of 8 threads (<= 512 hits each).
+        // Whenever the next group does not fit (or the input is exhausted) every wave consumes
+        // the list.  All control state is block-uniform.
+        int list_len = 0, w_next = 0, wi = 0, grp = 0, ngrp = 0, total = 0, off = 0;
+        unsigned long long hits = 0ull;
+        uint2 box0 = make_uint2(0, 0);  // box of this thread's first hit (the common case: <= 1 hit)
+        bool done = false;
+        auto tile_hit = [&](uint2 box) {
+            return ux(box.x) < X0 + kTile && ux(box.y) > X0 && uy(box.x) < Y0 + kTile && uy(box.y) > Y0 &&
+                   uz(box.x) < zg * 16 + 16 && uz(box.y) > zg * 16;
+        };
+        while (!done) {
+            while (true) {
+                if (grp < ngrp) {
+                    int gb = 0, ge = total;
+                    bool mine = true;
+                    if (ngrp > 1) {
+                        gb = (int)s_scan[8 + grp];
+                        ge = grp == 31 ? total : (int)s_scan[9 + grp];
+                        mine = (tid >> 3) == grp;
                     }
-                    // pass `sub`: ascending candidate ids -> s_cand
-                    unsigned long long sel = (nsub == 1 || (tid >> 5) == sub) ? word : 0ull;
-                    ++sub;
-                    const int cnt = __builtin_popcountll(sel);
-                    int incl = cnt;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const int up = __shfl_up(incl, d, 64);
-                        if (lane >= d) incl += up;
+                    const int n = __builtin_amdgcn_readfirstlane(ge - gb);
+                    if (n > 0) {
+                        if (list_len + n > kListCap) break;  // consume first, then retry this group
+                        if (mine && hits) {
+                            int pos = list_len + off - gb;
+                            const int j0 = __builtin_ctzll(hits);
+                            hits &= hits - 1;
+                            s_lg[pos] = (uint32_t)(wi * 64 + j0); s_llo[pos] = box0.x; s_lhi[pos] = box0.y;
+                            while (hits) {  // rare: several hits in one word -> re-read their boxes
+                                const int j = __builtin_ctzll(hits);
+                                hits &= hits - 1;
+                                const uint32_t g = (uint32_t)(wi * 64 + j);
+                                const uint2 box = a.boxes[g];
+                                ++pos;
+                                s_lg[pos] = g; s_llo[pos] = box.x; s_lhi[pos] = box.y;
+                            }
+                        }
+                        list_len += n;
                     }
-                    __syncthreads();  // s_cand / s_scan[0..3] free (previous rounds finished)
-                    if (lane == 63) s_scan[wave] = (uint32_t)incl;
-                    __syncthreads();
-                    int wbase = 0;
-                    total = 0;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const int c = (int)s_scan[w];
-                        if (w < wave) wbase += c;
-                        total += c;
-                    }
-                    total = __builtin_amdgcn_readfirstlane(total);
-                    int pos = wbase + incl - cnt;
-                    while (sel) {
-                        const int j = __builtin_ctzll(sel);
-                        sel &= sel - 1;
-                        s_cand[pos++] = (uint32_t)(wi * 64 + j);
-                    }
-                    r0 = 0;
-                    __syncthreads();
+                    if (++grp == ngrp) __syncthreads();  // s_scan reusable
                     continue;
                 }
-                // one round: kBlock candidates against the tile footprint
-                const int i = r0 + tid;
-                r0 += kBlock;
-                bool hit = false;
-                uint32_t g = 0;
-                uint2 box = make_uint2(0, 0);
-                if (i < total) {
-                    g = s_cand[i];
-                    box = a.boxes[g];
-                    hit = ux(box.x) < X0 + kTile && ux(box.y) > X0 && uy(box.x) < Y0 + kTile && uy(box.y) > Y0 &&
-                          uz(box.x) < zg * 16 + 16 && uz(box.y) > zg * 16;
+                if (w_next >= a.nwords) {
+                    done = true;
+                    break;
                 }
-                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
-                if (lane == 0) s_scan[8 + wave] = (uint32_t)__builtin_popcountll(hm);
+                wi = w_next + tid;
+                w_next += kBlock;
+                unsigned long long word = word_next;
+                word_next = (w_next + tid) < a.nwords ? bm[w_next + tid] : 0ull;  // prefetch next chunk
+                hits = 0ull;
+                while (word) {
+                    // two candidate boxes in flight per round trip
+                    const int j0 = __builtin_ctzll(word);
+                    word &= word - 1;
+                    const int j1 = word ? __builtin_ctzll(word) : -1;
+                    if (word) word &= word - 1;
+                    const uint2 b0 = a.boxes[wi * 64 + j0];
+                    const uint2 b1 = j1 >= 0 ? a.boxes[wi * 64 + j1] : make_uint2(0, 0);
+                    if (tile_hit(b0)) {
+                        if (!hits) box0 = b0;
+                        hits |= 1ull << j0;
+                    }
+                    if (j1 >= 0 && tile_hit(b1)) {
+                        if (!hits) box0 = b1;
+                        hits |= 1ull << j1;
+                    }
+                }
+                const int cnt = __builtin_popcountll(hits);
+                const int incl = wave_inclusive_scan(cnt);
+                if (lane == 63) s_scan[wave] = (uint32_t)incl;
                 __syncthreads();
-                int off = list_len, tot = 0;
+                off = incl - cnt;
+                total = 0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const int c = (int)s_scan[8 + w];
+                    const int c = (int)s_scan[w];
                     if (w < wave) off += c;
-                    tot += c;
+                    total += c;
                 }
-                if (hit) {
-                    const unsigned long long mxy =
-                        mask_x(clamp04(ux(box.x) - X0), clamp04(ux(box.y) - X0)) &
-                        mask_y(clamp04(uy(box.x) - Y0), clamp04(uy(box.y) - Y0));
-                    s_list[off + mbcnt(hm)] = make_uint4(g, (uint32_t)mxy, (uint32_t)(mxy >> 32),
-                                                         (uint32_t)uz(box.x) | ((uint32_t)uz(box.y) << 16));
-                }
-                list_len += __builtin_amdgcn_readfirstlane(tot);
-                __syncthreads();
+                total = __builtin_amdgcn_readfirstlane(total);
+                grp = 0;
+                ngrp = total == 0 ? 0 : (total <= kListCap ? 1 : 32);
+                if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
+                if (ngrp != 1) __syncthreads();  // group bases visible / s_scan reusable
             }
-            // consume: every wave walks the list for its own brick.  Lane-parallel over
-            // entries (brick mask = xy mask & z mask), then one scalar iteration per hit.
+            // ---- consume: every wave walks list[0, list_len) for its own brick.  Per 64 entries
+            // the brick's lane masks are formed lane-parallel (entry = lane), then one scalar
+            // iteration per entry that touches the brick.
+            __syncthreads();  // list complete
+#if GF_TIMELINE
+            if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+#endif
             for (int base = 0; base < list_len; base += 64) {
                 const int i = base + lane;
                 uint32_t eg = 0, mlo = 0, mhi = 0;
                 if (i < list_len) {
-                    const uint4 e = s_list[i];
-                    const unsigned long long m =
-                        (((unsigned long long)e.z << 32) | e.y) &
-                        mask_z(clamp04((int)(e.w & 0xFFFFu) - Z0), clamp04((int)(e.w >> 16) - Z0));
-                    eg = e.x; mlo = (uint32_t)m; mhi = (uint32_t)(m >> 32);
+                    eg = s_lg[i];
+                    const uint32_t blo = s_llo[i], bhi = s_lhi[i];
+                    const unsigned long long mxx = mask_x(clamp04(ux(blo) - X0), clamp04(ux(bhi) - X0));
+                    const uint32_t myz = mask_y32(clamp04(uy(blo) - Y0), clamp04(uy(bhi) - Y0)) &
+                                         mask_z32(clamp04(uz(blo) - Z0), clamp04(uz(bhi) - Z0));
+                    mlo = (uint32_t)mxx & myz;
+                    mhi = (uint32_t)(mxx >> 32) & myz;
                 }
                 unsigned long long todo = __builtin_amdgcn_ballot_w64((mlo | mhi) != 0u);
-                while (todo) {
+#if GF_DBUF
+                // Software-pipelined walk over the hits: the record of hit k+1 is fetched
+                // (scalar loads into a second SGPR set) before hit k is evaluated.
+                auto next_hit = [&](unsigned long long &mask, float (&r)[kRecUsed]) {
                     const int j = __builtin_ctzll(todo);
                     todo &= todo - 1;
                     const uint32_t g = __builtin_amdgcn_readlane(eg, j);
+                    mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mhi, j) << 32) |
+                           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mlo, j);
+                    crec_t rec = (crec_t)(uintptr_t)(a.records + (size_t)g * kRecDwords);
+#pragma unroll
+                    for (int q = 0; q < kRecUsed; ++q) r[q] = rec[q];
+                };
+                if (todo) {
+                    unsigned long long mA, mB = 0ull;
+                    float rA[kRecUsed], rB[kRecUsed];
+                    next_hit(mA, rA);
+                    while (true) {
+                        const bool moreB = todo != 0ull;
+                        if (moreB) next_hit(mB, rB);
+                        if (__builtin_amdgcn_inverse_ballot_w64(mA)) accumulate<VARIANT, EXP>(A, rA, px, py, pz);
+                        if (!moreB) break;
+                        const bool moreA = todo != 0ull;
+                        if (moreA) next_hit(mA, rA);
+                        if (__builtin_amdgcn_inverse_ballot_w64(mB)) accumulate<VARIANT, EXP>(A, rB, px, py, pz);
+                        if (!moreA) break;
+                    }
+                }
+#else
+                while (todo) {
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+#if GF_DIAG == 1   // diagnostic: always the same record (scalar cache always hits)
+                    const uint32_t g = __builtin_amdgcn_readlane(eg, j) & 1u;
+#else
+                    const uint32_t g = __builtin_amdgcn_readlane(eg, j);
+#endif
                     const unsigned long long m =
                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mhi, j) << 32) |
                         (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mlo, j);
+#if GF_DIAG == 2   // diagnostic: record through the vector memory path (VGPR operands)
+                    const float4 *r4 = reinterpret_cast<const float4 *>(a.records + (size_t)g * kRecDwords);
+                    float rec[kRecDwords];
+#pragma unroll
+                    for (int q = 0; q < kRecDwords / 4; ++q) {
+                        const float4 t4 = r4[q];
+                        rec[4 * q] = t4.x; rec[4 * q + 1] = t4.y; rec[4 * q + 2] = t4.z; rec[4 * q + 3] = t4.w;
+                    }
+#else
                     crec_t rec = (crec_t)(uintptr_t)(a.records + (size_t)g * kRecDwords);
-                    if (__builtin_amdgcn_inverse_ballot_w64(m))
-                        accumulate<VARIANT, FASTEXP>(A, rec, px, py, pz);
+#endif
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) accumulate<VARIANT, EXP>(A, rec, px, py, pz);
                 }
+#endif
             }
-            __syncthreads();  // all waves are done with the list
-            if (exhausted) break;
+            __syncthreads();  // every wave is done with the list
+            list_len = 0;
         }
+#if GF_TIMELINE
+        if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x + 2] = wall_clock64();
+#endif
 
         if (VARIANT == GF_SPLAT_PROB) {
             prob_normalise(A);
             if (lane_valid) {
-                a.out_bin[v] = 1 - A.bin;   // localagg_prob/src/forward.cu:99-101
+                a.out_bin[v] = 1 - A.bin;  // localagg_prob/src/forward.cu:99-101
                 a.out_density[v] = A.dens;
                 a.out_prob[v] = A.psum;
             }
@@ -401,7 +610,7 @@ __global__ __launch_bounds__(kBlock, 8) void gf_splat_render_dense_kernel(Render
                     if (cx < a.H && cy < a.W) {
                         const size_t row0 = ((size_t)cx * a.W + cy) * a.D + Z0;
                         const float4 val = *reinterpret_cast<const float4 *>(stage + i * 4);
-                        *reinterpret_cast<float4 *>(a.out_logits + row0 * kC + k * 4) = val;
+                        store_row4(a.out_logits + row0 * kC + k * 4, val);
                     }
                 }
             } else {
@@ -413,57 +622,11 @@ __global__ __launch_bounds__(kBlock, 8) void gf_splat_render_dense_kernel(Render
                 }
             }
         }
-        __syncthreads();  // staging is reused as candidate/list storage by the next zg
+        __syncthreads();  // staging is reused as list storage by the next zg
+#if GF_TIMELINE
+        if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x + 3] = wall_clock64();
+#endif
     }
-}
-
-// Arbitrary query points: one lane per point, candidates straight from the supertile
-// bitmask in ascending Gaussian order.  Also the automatic fallback of the dense kernel.
-template <int VARIANT, bool FASTEXP>
-__global__ __launch_bounds__(kBlock) void gf_splat_render_general_kernel(RenderArgs a)
-{
-    if (a.only_if_nondense && a.flags[0] == 0u) return;
-    const int n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= a.N) return;
-    const int X = a.points_int[3 * (size_t)n], Y = a.points_int[3 * (size_t)n + 1], Z = a.points_int[3 * (size_t)n + 2];
-    const float px = a.pts[3 * (size_t)n], py = a.pts[3 * (size_t)n + 1], pz = a.pts[3 * (size_t)n + 2];
-    Acc A;
-#pragma unroll
-    for (int ch = 0; ch < kC; ++ch) A.c[ch] = 0.f;
-    A.bin = 1.f; A.dens = 0.f; A.psum = 0.f;
-    const bool inside_grid = X >= 0 && X < a.H && Y >= 0 && Y < a.W && Z >= 0 && Z < a.D;
-    if (inside_grid) {
-        const int s = (X / kSuper) * a.nsy + (Y / kSuper);
-        const unsigned long long *__restrict__ bm = a.bitmask + (size_t)s * a.nwords;
-        for (int w = 0; w < a.nwords; ++w) {
-            unsigned long long word = bm[w];
-            while (word) {
-                const int j = __builtin_ctzll(word);
-                word &= word - 1;
-                const int g = w * 64 + j;
-                const uint2 box = a.boxes[g];
-                if (X >= ux(box.x) && X < ux(box.y) && Y >= uy(box.x) && Y < uy(box.y) && Z >= uz(box.x) && Z < uz(box.y)) {
-                    float rec[kRecDwords];
-                    const float4 *r4 = reinterpret_cast<const float4 *>(a.records + (size_t)g * kRecDwords);
-#pragma unroll
-                    for (int q = 0; q < kRecDwords / 4; ++q) {
-                        const float4 t = r4[q];
-                        rec[4 * q] = t.x; rec[4 * q + 1] = t.y; rec[4 * q + 2] = t.z; rec[4 * q + 3] = t.w;
-                    }
-                    accumulate<VARIANT, FASTEXP>(A, rec, px, py, pz);
-                }
-            }
-        }
-    }
-    if (VARIANT == GF_SPLAT_PROB) {
-        prob_normalise(A);
-        a.out_bin[n] = 1 - A.bin;
-        a.out_density[n] = A.dens;
-        a.out_prob[n] = A.psum;
-    }
-    float *o = a.out_logits + (size_t)n * kC;
-#pragma unroll
-    for (int ch = 0; ch < kC; ch += 2) *reinterpret_cast<float2 *>(o + ch) = make_float2(A.c[ch], A.c[ch + 1]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -492,39 +655,49 @@ __global__ __launch_bounds__(256) void gf_box_volumes_kernel(BoxVolArgs a)
     if (lane_id() == 0 && s) atomicAdd(a.num_rendered, s);
 }
 
-template <int VARIANT>
-static int launch_forward(bool fast_exp, int flags, const RenderArgs &ra, hipStream_t stream)
+// Experiment hook: extra dynamic LDS per render workgroup caps how many workgroups a CU
+// holds at once (GF_RENDER_DYN_LDS bytes; 0 = no cap).
+static unsigned render_dyn_lds()
 {
-    const long long V = (long long)ra.H * ra.W * ra.D;
-    const bool try_dense = (ra.N == V) && !(flags & GF_PTS_GENERAL);
-    RenderArgs r = ra;
-    if (try_dense) {
-        r.verify_dense = (flags & GF_PTS_ASSUME_DENSE) ? 0 : 1;
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GF_RENDER_DYN_LDS");
+        v = e ? atoi(e) : 0;
+    }
+    return (unsigned)v;
+}
+
+template <int VARIANT, int EXP>
+static void launch_render(bool dense_candidate, const RenderArgs &r, hipStream_t stream)
+{
+    if (dense_candidate) {
         const int per_xcd = (r.ntiles_total + 7) / 8;
+        // the embedded arbitrary-points body grid-strides, so the tile grid is enough
         hipEvent_t ev0, ev1;
         const bool prof = profile_slot(&ev0, &ev1);
         if (prof) (void)hipEventRecord(ev0, stream);
-        if (fast_exp)
-            hipLaunchKernelGGL((gf_splat_render_dense_kernel<VARIANT, true>), dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
-        else
-            hipLaunchKernelGGL((gf_splat_render_dense_kernel<VARIANT, false>), dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
+        hipLaunchKernelGGL((gf_splat_render_kernel<VARIANT, EXP>), dim3(per_xcd * 8), dim3(kBlock), render_dyn_lds(),
+                           stream, r);
         if (prof) (void)hipEventRecord(ev1, stream);
-        if (flags & GF_PTS_ASSUME_DENSE) return 0;
-        r.only_if_nondense = 1;
     } else {
-        r.only_if_nondense = 0;
+        const int blocks = (int)min((long long)4096, ((long long)r.N + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL((gf_splat_render_general_kernel<VARIANT, EXP>), dim3(blocks), dim3(kBlock), 0, stream, r);
     }
-    if (ra.N > 0) {
-        const int blocks = (ra.N + kBlock - 1) / kBlock;
-        if (fast_exp)
-            hipLaunchKernelGGL((gf_splat_render_general_kernel<VARIANT, true>), dim3(blocks), dim3(kBlock), 0, stream, r);
-        else
-            hipLaunchKernelGGL((gf_splat_render_general_kernel<VARIANT, false>), dim3(blocks), dim3(kBlock), 0, stream, r);
-    }
-    return 0;
+}
+
+template <int VARIANT>
+static void launch_render_exp(int flags, bool dense_candidate, const RenderArgs &r, hipStream_t stream)
+{
+    if (flags & GF_FAST_EXP) launch_render<VARIANT, kExpFast>(dense_candidate, r, stream);
+    else if (flags & GF_LIBM_EXP) launch_render<VARIANT, kExpLibm>(dense_candidate, r, stream);
+    else launch_render<VARIANT, kExpComp>(dense_candidate, r, stream);
 }
 
 }  // namespace gf
+
+namespace gf { static unsigned long long *g_timeline = nullptr; }
+// debug hook (not in the public header): per-workgroup timestamps of the render kernel
+extern "C" void gf_debug_set_timeline(void *dev_ptr) { gf::g_timeline = (unsigned long long *)dev_ptr; }
 
 extern "C" size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D)
 {
@@ -559,28 +732,33 @@ extern "C" int gf_splat_forward(int variant, int radii_per_axis, int flags, int 
         set_error("gf_splat_forward: workspace too small (%zu < %zu)", workspace_bytes, ws.total_bytes);
         return GF_EWORKSPACE;
     }
+    const bool dense_candidate = ((long long)N == (long long)H * W * D) && !(flags & GF_PTS_GENERAL);
+    const bool verify = dense_candidate && !(flags & GF_PTS_ASSUME_DENSE);
+
     PrepArgs pa;
     pa.means3D = means3D; pa.means_int = means3D_int; pa.opacity = opacity; pa.semantics = semantics;
-    pa.radii = radii; pa.cov3D = cov3D; pa.records = ws.records; pa.boxes = ws.boxes; pa.bitmask = ws.bitmask;
-    pa.flags = ws.flags; pa.P = P; pa.H = H; pa.W = W; pa.D = D; pa.nwords = ws.nwords; pa.nsx = ws.nsx;
-    pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0; pa.variant = variant;
-    pa.state = (uint32_t *)state;
-    pa.state_init = ((long long)N != (long long)H * W * D || (flags & GF_PTS_GENERAL)) ? 1 : 0;
-    // the prep grid always has at least one block so that flags[] are reset
-    hipLaunchKernelGGL(gf_splat_prep_kernel, dim3(ws.nwords > 0 ? (ws.nwords + 3) / 4 : 1), dim3(256), 0, stream, pa);
-    GF_CHECK_LAUNCH();
+    pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.records = ws.records; pa.boxes = ws.boxes;
+    pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
+    pa.nwords = ws.nwords; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
+    pa.variant = variant; pa.nprep_blocks = (P + 63) / 64; pa.verify = verify ? 1 : 0;
+    const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks : 0);
+    if (prep_grid > 0) {
+        hipLaunchKernelGGL(gf_splat_prep_kernel, dim3(prep_grid), dim3(64), 0, stream, pa);
+        GF_CHECK_LAUNCH();
+    }
+    if (N == 0) return GF_OK;
 
     RenderArgs ra;
     ra.pts = pts; ra.points_int = points_int; ra.records = ws.records; ra.boxes = ws.boxes; ra.bitmask = ws.bitmask;
     ra.out_logits = out_logits; ra.out_bin = out_bin_logits; ra.out_density = out_density; ra.out_prob = out_probability;
-    ra.flags = ws.flags; ra.state = (uint32_t *)state; ra.P = P; ra.N = N; ra.nwords = ws.nwords; ra.H = H; ra.W = W; ra.D = D;
-    ra.nsx = ws.nsx; ra.nsy = ws.nsy; ra.ntiles_total = ws.nsuper * kTilesPerSuper; ra.only_if_nondense = 0;
-    ra.verify_dense = 1;
-    const bool fast_exp = (flags & GF_FAST_EXP) != 0;
+    ra.verify_flags = ws.flags + 64; ra.state = (uint32_t *)state; ra.P = P; ra.N = N; ra.nwords = ws.nwords;
+    ra.H = H; ra.W = W; ra.D = D; ra.nsx = ws.nsx; ra.nsy = ws.nsy; ra.ntiles_total = ws.nsuper * kTilesPerSuper;
+    ra.verify_dense = verify ? 1 : 0;
+    ra.timeline = g_timeline;
     if (variant == GF_SPLAT_BASE)
-        launch_forward<GF_SPLAT_BASE>(fast_exp, flags, ra, stream);
+        launch_render_exp<GF_SPLAT_BASE>(flags, dense_candidate, ra, stream);
     else
-        launch_forward<GF_SPLAT_PROB>(fast_exp, flags, ra, stream);
+        launch_render_exp<GF_SPLAT_PROB>(flags, dense_candidate, ra, stream);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

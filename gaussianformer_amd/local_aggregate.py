@@ -74,6 +74,45 @@ def splat_forward(variant, pts, points_int, means3D, means3D_int, opacities, sem
     return logits, bin_logits, density, probability, state
 
 
+class SplatForwardPlan:
+    """Pre-bound forward call for a fixed set of device tensors: outputs, state and workspace
+    are allocated once and ``run()`` is a single C-ABI call (no Python-side allocation).
+    Used by bench.py and by callers that splat the same buffers every frame."""
+
+    def __init__(self, variant, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
+                 H, W, D, flags=_lib.GF_PTS_AUTO):
+        self.lib = _lib.load()
+        _lib.require_gpu(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D)
+        f32, i32 = torch.float32, torch.int32
+        self.inputs = [_contig(t, f32) if t.is_floating_point() else _contig(t, i32)
+                       for t in (pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D)]
+        pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D = self.inputs
+        self.device = pts.device
+        N, P, C = pts.shape[0], means3D.shape[0], semantics.shape[1]
+        self.N, self.P = N, P
+        prob = variant == _lib.GF_SPLAT_PROB
+        self.logits = torch.empty((N, C), dtype=f32, device=self.device)
+        self.bin_logits = torch.empty(N, dtype=f32, device=self.device) if prob else None
+        self.density = torch.empty(N, dtype=f32, device=self.device) if prob else None
+        self.probability = torch.empty(N, dtype=f32, device=self.device) if prob else None
+        self.state = torch.empty(self.lib.gf_splat_state_bytes(), dtype=torch.uint8, device=self.device)
+        self.workspace = torch.empty(self.lib.gf_splat_workspace_bytes(P, N, H, W, D), dtype=torch.uint8,
+                                     device=self.device)
+        self.args = [variant, int(radii.dim() == 2), flags, P, N, C, H, W, D,
+                     *[_lib.ptr(t) for t in self.inputs],
+                     _lib.ptr(self.logits), _lib.ptr(self.bin_logits), _lib.ptr(self.density),
+                     _lib.ptr(self.probability), _lib.ptr(self.state), _lib.ptr(self.workspace),
+                     self.workspace.numel()]
+
+    def run(self, stream=None):
+        if stream is None:
+            stream = _lib.current_stream(self.device)
+        rc = self.lib.gf_splat_forward(*self.args, stream)
+        if rc:
+            _lib.check(rc, "gf_splat_forward")
+        return self.logits
+
+
 def splat_backward(variant, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
                    H, W, D, logits_grad, fwd_outputs=None, bin_logits_grad=None, density_grad=None,
                    state=None, flags=_lib.GF_PTS_AUTO):

@@ -41,7 +41,8 @@ extern "C" {
 #define GF_PTS_AUTO 0          /* verify on device whether pts is the dense voxel-centre grid */
 #define GF_PTS_ASSUME_DENSE 1  /* caller guarantees point n lies in voxel n (N == H*W*D) */
 #define GF_PTS_GENERAL 2       /* always take the arbitrary-points path */
-#define GF_FAST_EXP 4          /* v_exp_f32-based exp (rel. err ~1e-6) instead of full-precision expf */
+#define GF_FAST_EXP 4          /* exp(x) = v_exp_f32(x*log2e): rel. err ~2e-6 */
+#define GF_LIBM_EXP 8          /* ocml expf (13 VALU) instead of the default compensated v_exp_f32 (7 VALU, <= 3 ulp) */
 
 int gf_abi_version(void);
 const char *gf_last_error(void);

@@ -1,0 +1,40 @@
+"""Debug: per-workgroup timeline of the render kernel (start / list built / consumed / stored)."""
+import ctypes, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+import os
+from gaussianformer_amd import build as _b
+os.environ["GF_LIB"] = _b.build(extra_flags=("-DGF_TIMELINE=1",), lib_name="libgf_hip_timeline.so")
+from gaussianformer_amd import _lib
+from gaussianformer_amd.local_aggregate import SplatForwardPlan
+from gaussianformer_amd.synthetic import make_splat_inputs
+import oracle
+config = sys.argv[1] if len(sys.argv) > 1 else "nuscenes_gs25600_solid"
+dev = torch.device("cuda:0")
+si = make_splat_inputs(config, seed=0)
+pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size, si.scale_multiplier)
+t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
+plan = SplatForwardPlan(0, *t, si.H, si.W, si.D, flags=1)
+lib = _lib.load()
+for _ in range(5): plan.run()
+torch.cuda.synchronize()
+nb = 2504
+tl = torch.zeros(nb * 4, dtype=torch.int64, device=dev)
+lib.gf_debug_set_timeline.argtypes = [ctypes.c_void_p]
+lib.gf_debug_set_timeline(tl.data_ptr())
+plan.run(); torch.cuda.synchronize()
+lib.gf_debug_set_timeline(None)
+T = tl.cpu().numpy().reshape(nb, 4).astype(np.float64)
+T = T[T[:, 0] > 0]
+t0 = T[:, 0].min()
+T = (T - t0) / 100.0  # 100 MHz -> us
+print("blocks", len(T), "kernel span us", T[:, 3].max())
+for name, col in (("start", 0), ("list built", 1), ("consumed", 2), ("end", 3)):
+    v = T[:, col]; print(f"{name:12s} min {v.min():7.2f} p50 {np.median(v):7.2f} p90 {np.percentile(v,90):7.2f} max {v.max():7.2f}")
+d_prod = T[:, 1] - T[:, 0]; d_cons = T[:, 2] - T[:, 1]; d_epi = T[:, 3] - T[:, 2]
+for name, v in (("produce", d_prod), ("consume", d_cons), ("epilogue", d_epi), ("total", T[:, 3] - T[:, 0])):
+    print(f"dur {name:9s} mean {v.mean():7.2f} p50 {np.median(v):7.2f} p90 {np.percentile(v,90):7.2f} max {v.max():7.2f}")
+order = np.argsort(T[:, 0])
+first = T[order[:2048]]; late = T[order[2048:]]
+print("first-wave blocks: mean total", (first[:, 3]-first[:, 0]).mean(), " late blocks:", len(late), "mean start", late[:, 0].mean() if len(late) else None, "mean total", (late[:, 3]-late[:, 0]).mean() if len(late) else None)
+hist, edges = np.histogram(T[:, 0], bins=12); print("start hist", hist.tolist(), [round(e,1) for e in edges.tolist()])
