@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GF_LIB") or os.path.join(_HERE, "csrc", "libgf_hip.so
 GF_ABI_VERSION = 1
 GF_SPLAT_BASE, GF_SPLAT_PROB = 0, 1
 GF_NUM_CHANNELS = 18
-GF_PTS_AUTO, GF_PTS_ASSUME_DENSE, GF_PTS_GENERAL, GF_FAST_EXP, GF_LIBM_EXP = 0, 1, 2, 4, 8
+GF_PTS_AUTO, GF_PTS_ASSUME_DENSE, GF_PTS_GENERAL, GF_FAST_EXP, GF_LIBM_EXP, GF_COMP_EXP = 0, 1, 2, 4, 8, 16
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 

@@ -10,10 +10,9 @@ namespace gf {
 
 // ---- geometry constants -------------------------------------------------------------
 constexpr int kC = GF_NUM_CHANNELS;  // 18 semantic channels
-constexpr int kTile = 4;             // a tile is 4x4 voxel columns x all z; a brick is 4x4x4
-constexpr int kSuper = 8;            // a supertile is 8x8 voxel columns = 2x2 tiles
-constexpr int kTilesPerSuperAxis = kSuper / kTile;
-constexpr int kTilesPerSuper = kTilesPerSuperAxis * kTilesPerSuperAxis;
+constexpr int kSuper = 8;            // a supertile is 8x8 voxel columns (the binning granule)
+constexpr int kTileX = 8, kTileY = 4;  // a tile (one workgroup) is 8x4 voxel columns x all z; a brick is 4x4x4
+constexpr int kTilesPerSuper = (kSuper / kTileX) * (kSuper / kTileY);
 constexpr int kRecDwords = 32;       // packed per-Gaussian record, 128 B
 
 // record layout (dwords)
@@ -33,7 +32,7 @@ __host__ __device__ __forceinline__ int uz(uint32_t p) { return (int)(p >> 22); 
 
 // workspace carve-up (all sections 256-B aligned)
 struct SplatWorkspace {
-    uint32_t *flags;        // [2048] [64..1088) = dense-grid verdicts
+    uint32_t *flags;        // [8192] [64..4160) = dense-grid verdicts
     float *records;         // [P][32]
     uint2 *boxes;           // [P]  (lo, hi) packed
     unsigned long long *bitmask;  // [nsuper][nwords]
@@ -56,7 +55,7 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.nsuper = ws.nsx * ws.nsy;
     char *p = (char *)base;
     size_t off = 0;
-    ws.flags = (uint32_t *)(p + off); off += 8192;
+    ws.flags = (uint32_t *)(p + off); off += 32768;
     ws.records = (float *)(p + off); off += align256((size_t)P * kRecDwords * 4);
     ws.boxes = (uint2 *)(p + off); off += align256((size_t)P * 8);
     ws.bitmask = (unsigned long long *)(p + off); off += align256((size_t)ws.nsuper * ws.nwords * 8);

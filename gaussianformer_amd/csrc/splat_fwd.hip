@@ -47,10 +47,10 @@ struct PrepArgs {
     uint2 *boxes;
     unsigned long long *bitmask;
     uint32_t *verify_flags;  // [kVerifyBlocks]
-    int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify;
+    int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale;
 };
 
-constexpr int kVerifyBlocks = 1024;    // verification waves; render thread t reads 4 verdicts
+constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
 constexpr int kPrepSuperChunk = 2048;  // supertiles per LDS pass of the prep kernel (16 KB)
 
 // Integer box of Gaussian g: model/head/localagg/src/auxiliary.h:8-20 (scalar radius) and
@@ -80,10 +80,26 @@ __global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
         // slice unconditionally (no zero-initialised flag needed).
         const int vb = (int)blockIdx.x - a.nprep_blocks;
         bool bad = false;
-        for (long long n = (long long)vb * 64 + lane; n < a.N; n += (long long)kVerifyBlocks * 64) {
-            const int x = a.points_int[3 * n], y = a.points_int[3 * n + 1], z = a.points_int[3 * n + 2];
-            // unique decomposition of n: y in [0,W), z in [0,D) and the key equals n
-            bad |= !(y >= 0 && y < a.W && z >= 0 && z < a.D && ((long long)x * a.W + y) * a.D + z == n);
+        const long long stride = (long long)kVerifyBlocks * 64;
+        for (long long n0 = (long long)vb * 64 + lane; n0 < a.N; n0 += 4 * stride) {
+            // four independent loads in flight per round trip
+            int x[4], y[4], z[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long n = n0 + k * stride;
+                const bool in = n < a.N;
+                x[k] = in ? a.points_int[3 * n] : 0;
+                y[k] = in ? a.points_int[3 * n + 1] : 0;
+                z[k] = in ? a.points_int[3 * n + 2] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long n = n0 + k * stride;
+                // unique decomposition of n: y in [0,W), z in [0,D) and the key equals n
+                if (n < a.N)
+                    bad |= !(y[k] >= 0 && y[k] < a.W && z[k] >= 0 && z[k] < a.D &&
+                             ((long long)x[k] * a.W + y[k]) * a.D + z[k] == n);
+            }
         }
         const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
         if (lane == 0) a.verify_flags[vb] = any ? 1u : 0u;
@@ -116,8 +132,17 @@ __global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
         const float *sm = a.semantics + (size_t)kC * g;
         float4 *rec = reinterpret_cast<float4 *>(a.records + (size_t)g * kRecDwords);
         rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opacity[g]);
-        rec[1] = make_float4(c0, c1, c2, c3);
-        rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
+        if (a.prescale) {
+            // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
+            // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
+            //   p2 = dx(a dx + b dy + c dz) + dy(d dy + e dz) + f dz^2 = log2(e) * (-1/2 d^T S^-1 d)
+            const double L = 1.4426950408889634074;
+            rec[1] = make_float4((float)(-0.5 * L * c0), (float)(-0.5 * L * c1), (float)(-0.5 * L * c2), (float)(-L * c3));
+            rec[2] = make_float4((float)(-L * c4), (float)(-L * c5), __uint_as_float(plo), __uint_as_float(phi));
+        } else {
+            rec[1] = make_float4(c0, c1, c2, c3);
+            rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
+        }
         rec[3] = make_float4(sm[0], sm[1], sm[2], sm[3]);
         rec[4] = make_float4(sm[4], sm[5], sm[6], sm[7]);
         rec[5] = make_float4(sm[8], sm[9], sm[10], sm[11]);
@@ -173,19 +198,21 @@ struct RenderArgs {
     int P, N, nwords, H, W, D, nsx, nsy, ntiles_total, verify_dense;
 };
 
+static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
 constexpr int kListCap = 1536;  // tile list entries (12 B each) held in LDS
 constexpr int kRecUsed = 31;    // record dwords the render kernels read (0..30)
 constexpr int kBlock = 256;
 
 // exp flavours: 0 = ocml expf (13 VALU), 1 = v_exp_f32 with a compensated argument
-// (7 VALU, <= ~3 ulp, results below 2^-126 flush to 0), 2 = __expf (rel. err ~2e-6)
+// (7 VALU, <= ~3 ulp, results below 2^-126 flush to 0), 2 = the quadratic form is
+// pre-multiplied by log2(e) in the prep kernel and the render kernels issue a bare
+// v_exp_f32 (relative error ~1e-6 * |largest term of the form|)
 enum { kExpLibm = 0, kExpComp = 1, kExpFast = 2 };
 
 template <int EXP>
 __device__ __forceinline__ float gf_exp(float x)
 {
     if (EXP == kExpLibm) return expf(x);
-    if (EXP == kExpFast) return __expf(x);
     const float kL2E = 1.44269504088896340736f;     // fl(log2 e)
     const float kL2ELo = 1.925963033500011e-08f;    // log2 e - fl(log2 e)
     const float t = x * kL2E;
@@ -200,29 +227,89 @@ struct Acc {
     float bin, dens, psum;
 };
 
+// exp(-1/2 d^T Sigma^-1 d) of one point: model/head/localagg/src/forward.cu:66-69.  Written with
+// explicit fmaf so that every instantiation (SGPR or VGPR record, dense or arbitrary-points
+// body) rounds identically.
+template <int EXP, typename RecPtr>
+__device__ __forceinline__ float gauss_exp(RecPtr rec, float px, float py, float pz)
+{
+    const float dx = rec[kRecMean] - px, dy = rec[kRecMean + 1] - py, dz = rec[kRecMean + 2] - pz;
+    if (EXP == kExpFast) {
+        // record holds the log2(e)-prescaled form (see the prep kernel): 9 VALU + v_exp_f32
+        const float t1 = fmaf(rec[kRecCov], dx, fmaf(rec[kRecCov + 3], dy, rec[kRecCov + 5] * dz));
+        const float t2 = fmaf(rec[kRecCov + 1], dy, rec[kRecCov + 4] * dz);
+        const float t3 = rec[kRecCov + 2] * dz;
+        return __builtin_amdgcn_exp2f(fmaf(dx, t1, fmaf(dy, t2, dz * t3)));
+    }
+    const float q = fmaf(rec[kRecCov + 2] * dz, dz, fmaf(rec[kRecCov + 1] * dy, dy, (rec[kRecCov] * dx) * dx));
+    const float r = fmaf(rec[kRecCov + 5] * dx, dz, fmaf(rec[kRecCov + 4] * dy, dz, (rec[kRecCov + 3] * dx) * dy));
+    return gf_exp<EXP>(fmaf(-0.5f, q, -r));
+}
+
+// The same evaluation for the two voxels of a lane at once, written on 2-vectors so that it
+// compiles to packed VALU (v_pk_*_f32: 2 results per instruction; measured 4.9 vs 2 x 3.4-4.7
+// cycles per wave instruction on gfx950).  Lane-wise identical to gauss_exp (same operation
+// order), so the dense and the arbitrary-points bodies still agree bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int EXP, typename RecPtr>
+__device__ __forceinline__ f32x2 gauss_exp_pair(RecPtr rec, f32x2 px, f32x2 py, f32x2 pz)
+{
+    const f32x2 dx = rec[kRecMean] - px, dy = rec[kRecMean + 1] - py, dz = rec[kRecMean + 2] - pz;
+    f32x2 e;
+    if (EXP == kExpFast) {
+        const f32x2 t1 = fma2((f32x2)rec[kRecCov], dx, fma2((f32x2)rec[kRecCov + 3], dy, rec[kRecCov + 5] * dz));
+        const f32x2 t2 = fma2((f32x2)rec[kRecCov + 1], dy, rec[kRecCov + 4] * dz);
+        const f32x2 t3 = rec[kRecCov + 2] * dz;
+        const f32x2 p2 = fma2(dx, t1, fma2(dy, t2, dz * t3));
+        e.x = __builtin_amdgcn_exp2f(p2.x);
+        e.y = __builtin_amdgcn_exp2f(p2.y);
+        return e;
+    }
+    const f32x2 q = fma2(rec[kRecCov + 2] * dz, dz, fma2(rec[kRecCov + 1] * dy, dy, (rec[kRecCov] * dx) * dx));
+    const f32x2 r = fma2(rec[kRecCov + 5] * dx, dz, fma2(rec[kRecCov + 4] * dy, dz, (rec[kRecCov + 3] * dx) * dy));
+    const f32x2 power = fma2((f32x2)(-0.5f), q, -r);
+    if (EXP == kExpLibm) {
+        e.x = expf(power.x);
+        e.y = expf(power.y);
+        return e;
+    }
+    const float kL2E = 1.44269504088896340736f, kL2ELo = 1.925963033500011e-08f;
+    const f32x2 t = power * kL2E;
+    f32x2 rr = fma2(power, (f32x2)kL2E, -t);
+    rr = fma2(power, (f32x2)kL2ELo, rr);
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    return e * fma2(rr, (f32x2)0.6931471805599453f, (f32x2)1.0f);
+}
+
+// per-point weight multiplying the semantics: opa*e (base, forward.cu:69) or
+// (2pi)^-1.5 sqrt(det) * e * opa (prob, localagg_prob/src/forward.cu:78)
+template <int VARIANT, typename RecPtr>
+__device__ __forceinline__ float gauss_weight(RecPtr rec, float e)
+{
+    return VARIANT == GF_SPLAT_BASE ? rec[kRecOpa] * e : rec[kRecKdet] * e * rec[kRecOpa];
+}
+
+// forward.cu:71-74 (base) / localagg_prob/src/forward.cu:80-86 (prob)
+template <int VARIANT, typename RecPtr>
+__device__ __forceinline__ void accumulate_w(Acc &A, RecPtr rec, float w, float e)
+{
+#pragma unroll
+    for (int ch = 0; ch < kC; ++ch) A.c[ch] = fmaf(rec[kRecSem + ch], w, A.c[ch]);
+    if (VARIANT == GF_SPLAT_PROB) {
+        A.bin = (1 - e) * A.bin;
+        A.dens = e + A.dens;
+        A.psum = w + A.psum;
+    }
+}
+
 template <int VARIANT, int EXP, typename RecPtr>
 __device__ __forceinline__ void accumulate(Acc &A, RecPtr rec, float px, float py, float pz)
 {
-    // model/head/localagg/src/forward.cu:66-74 (base), model/head/localagg_prob/src/forward.cu:73-86 (prob)
-    const float dx = rec[kRecMean] - px, dy = rec[kRecMean + 1] - py, dz = rec[kRecMean + 2] - pz;
-    // -1/2 d^T Sigma^-1 d, written with explicit fmaf so that every instantiation (SGPR or
-    // VGPR record, dense or arbitrary-points body) rounds identically.
-    const float q = fmaf(rec[kRecCov + 2] * dz, dz, fmaf(rec[kRecCov + 1] * dy, dy, (rec[kRecCov] * dx) * dx));
-    const float r = fmaf(rec[kRecCov + 5] * dx, dz, fmaf(rec[kRecCov + 4] * dy, dz, (rec[kRecCov + 3] * dx) * dy));
-    const float power = fmaf(-0.5f, q, -r);
-    const float e = gf_exp<EXP>(power);
-    if (VARIANT == GF_SPLAT_BASE) {
-        const float w = rec[kRecOpa] * e;
-#pragma unroll
-        for (int ch = 0; ch < kC; ++ch) A.c[ch] = fmaf(rec[kRecSem + ch], w, A.c[ch]);
-    } else {
-        const float prob = rec[kRecKdet] * e * rec[kRecOpa];
-#pragma unroll
-        for (int ch = 0; ch < kC; ++ch) A.c[ch] = fmaf(rec[kRecSem + ch], prob, A.c[ch]);
-        A.bin = (1 - e) * A.bin;
-        A.dens = e + A.dens;
-        A.psum = prob + A.psum;
-    }
+    const float e = gauss_exp<EXP>(rec, px, py, pz);
+    accumulate_w<VARIANT>(A, rec, gauss_weight<VARIANT>(rec, e), e);
 }
 
 // Epilogue of the prob variant: model/head/localagg_prob/src/forward.cu:92-98.
@@ -336,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void gf_splat_render_general_kernel(RenderA
 #define GF_DBUF 0      // 1: software-pipeline the hit loop with two SGPR record sets
 #endif
 #ifndef GF_OCC
-#define GF_OCC 8       // waves per SIMD the render kernel is compiled for
+#define GF_OCC 6       // waves per SIMD the render kernel is compiled for (two voxels per lane: 79 VGPRs)
 #endif
 #ifndef GF_DIAG
 #define GF_DIAG 0      // development diagnostics (tools/variants.py); 0 in the product
@@ -359,8 +446,14 @@ __device__ __forceinline__ void store_row4(float *dst, float4 v)
 template <int VARIANT, int EXP>
 __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderArgs a)
 {
+    // Workgroup = tile of 8x4 voxel columns x 16 z (512 voxels); wave = 4x4x8 "double brick":
+    // lane = (lx, ly, lz) owns the two voxels z = Zw + lz and Zw + 4 + lz.  With two voxels
+    // per lane the whole 200x200x16 grid is 5000 waves -- fewer than the 8192 wave slots of
+    // the chip -- so every tile is resident from the start (no second dispatch round), and
+    // each scalar iteration over a Gaussian feeds two independent evaluation chains.
+    //
     // LDS: tile list {gaussian id, box lo, box hi} + scan scratch; the output staging area
-    // (4 waves x 64 voxels x 18 floats) aliases the list once it has been consumed.
+    // (4 waves x 64 rows x 18 floats, used twice) aliases the list once it has been consumed.
     constexpr int kStage = 4 * 64 * kC;
     constexpr int kMem = kStage > 3 * kListCap ? kStage : 3 * kListCap;
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kMem + 64];
@@ -376,14 +469,19 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
     const int per_xcd = (int)(gridDim.x >> 3);
     const int logical = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
     const int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
-    const int X0 = ((s / a.nsy) * kTilesPerSuperAxis + t / kTilesPerSuperAxis) * kTile;
-    const int Y0 = ((s % a.nsy) * kTilesPerSuperAxis + t % kTilesPerSuperAxis) * kTile;
+    const int X0 = (s / a.nsy) * kSuper;
+    const int Y0 = (s % a.nsy) * kSuper + t * kTileY;
     const bool tile_ok = logical < a.ntiles_total && X0 < a.H && Y0 < a.W;
     const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nwords;
 
     // issue the first loads before the verdict barrier: verdicts, first bitmask word
     uint4 vf = make_uint4(0, 0, 0, 0);
-    if (a.verify_dense) vf = reinterpret_cast<const uint4 *>(a.verify_flags)[tid];
+    if (a.verify_dense) {
+        const uint4 *vp = reinterpret_cast<const uint4 *>(a.verify_flags) + 4 * tid;
+        const uint4 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
+        vf = make_uint4(v0.x | v1.x | v2.x | v3.x, v0.y | v1.y | v2.y | v3.y, v0.z | v1.z | v2.z | v3.z,
+                        v0.w | v1.w | v2.w | v3.w);
+    }
     unsigned long long word_next = (tile_ok && tid < a.nwords) ? bm[tid] : 0ull;
 
     // Is pts the dense voxel-centre grid?  (verdict of the prep kernel's verification waves)
@@ -397,22 +495,33 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
     if (!tile_ok) return;
 
     const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
-    const int X = X0 + lx, Y = Y0 + ly;
+    const int Xw = X0 + 4 * (wave & 1);  // this wave's 4x4 column footprint
+    const int X = Xw + lx, Y = Y0 + ly;
 #if GF_TIMELINE
-    if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x] = wall_clock64();
+    if (a.timeline && tid == 0) {
+        a.timeline[4 * (size_t)blockIdx.x] = wall_clock64();
+        // where did this workgroup land?  HW_ID (reg 4) and XCC_ID (reg 20)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        a.timeline[4 * (size_t)gridDim.x + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+    }
 #endif
 
     for (int zg = 0; zg * 16 < a.D; ++zg) {
-        const int Z0 = zg * 16 + wave * 4;  // this wave's brick
-        const int Z = Z0 + lz;
-        const bool lane_valid = X < a.H && Y < a.W && Z < a.D;
-        const size_t v = ((size_t)X * a.W + Y) * a.D + Z;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (lane_valid) { px = a.pts[3 * v]; py = a.pts[3 * v + 1]; pz = a.pts[3 * v + 2]; }
-        Acc A;
+        const int Zw = zg * 16 + (wave >> 1) * 8;  // this wave's double brick: z in [Zw, Zw+8)
+        const int ZA = Zw + lz, ZB = Zw + 4 + lz;
+        const bool okA = X < a.H && Y < a.W && ZA < a.D;
+        const bool okB = X < a.H && Y < a.W && ZB < a.D;
+        const size_t vA = ((size_t)X * a.W + Y) * a.D + ZA;
+        const size_t vB = vA + 4;
+        float pAx = 0.f, pAy = 0.f, pAz = 0.f, pBx = 0.f, pBy = 0.f, pBz = 0.f;
+        if (okA) { pAx = a.pts[3 * vA]; pAy = a.pts[3 * vA + 1]; pAz = a.pts[3 * vA + 2]; }
+        if (okB) { pBx = a.pts[3 * vB]; pBy = a.pts[3 * vB + 1]; pBz = a.pts[3 * vB + 2]; }
+        Acc A, B;
 #pragma unroll
-        for (int ch = 0; ch < kC; ++ch) A.c[ch] = 0.f;
+        for (int ch = 0; ch < kC; ++ch) { A.c[ch] = 0.f; B.c[ch] = 0.f; }
         A.bin = 1.f; A.dens = 0.f; A.psum = 0.f;
+        B.bin = 1.f; B.dens = 0.f; B.psum = 0.f;
         if (zg > 0) word_next = tid < a.nwords ? bm[tid] : 0ull;
 
         // ---- produce / consume.  Producer: filter the supertile's bitmask against the tile
@@ -426,7 +535,7 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
         uint2 box0 = make_uint2(0, 0);  // box of this thread's first hit (the common case: <= 1 hit)
         bool done = false;
         auto tile_hit = [&](uint2 box) {
-            return ux(box.x) < X0 + kTile && ux(box.y) > X0 && uy(box.x) < Y0 + kTile && uy(box.y) > Y0 &&
+            return ux(box.x) < X0 + kTileX && ux(box.y) > X0 && uy(box.x) < Y0 + kTileY && uy(box.y) > Y0 &&
                    uz(box.x) < zg * 16 + 16 && uz(box.y) > zg * 16;
         };
         while (!done) {
@@ -505,80 +614,55 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
                 if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
                 if (ngrp != 1) __syncthreads();  // group bases visible / s_scan reusable
             }
-            // ---- consume: every wave walks list[0, list_len) for its own brick.  Per 64 entries
-            // the brick's lane masks are formed lane-parallel (entry = lane), then one scalar
-            // iteration per entry that touches the brick.
+            // ---- consume: every wave walks list[0, list_len) for its own double brick.  Per 64
+            // entries the lane masks of the lower and the upper brick are formed lane-parallel
+            // (entry = lane), then one scalar iteration per entry that touches either.
             __syncthreads();  // list complete
 #if GF_TIMELINE
             if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)blockIdx.x + 1] = wall_clock64();
 #endif
             for (int base = 0; base < list_len; base += 64) {
                 const int i = base + lane;
-                uint32_t eg = 0, mlo = 0, mhi = 0;
+                uint32_t eg = 0, mAlo = 0, mAhi = 0, mBlo = 0, mBhi = 0;
                 if (i < list_len) {
                     eg = s_lg[i];
                     const uint32_t blo = s_llo[i], bhi = s_lhi[i];
-                    const unsigned long long mxx = mask_x(clamp04(ux(blo) - X0), clamp04(ux(bhi) - X0));
-                    const uint32_t myz = mask_y32(clamp04(uy(blo) - Y0), clamp04(uy(bhi) - Y0)) &
-                                         mask_z32(clamp04(uz(blo) - Z0), clamp04(uz(bhi) - Z0));
-                    mlo = (uint32_t)mxx & myz;
-                    mhi = (uint32_t)(mxx >> 32) & myz;
+                    const unsigned long long mxx = mask_x(clamp04(ux(blo) - Xw), clamp04(ux(bhi) - Xw));
+                    const uint32_t my = mask_y32(clamp04(uy(blo) - Y0), clamp04(uy(bhi) - Y0));
+                    const uint32_t mzA = my & mask_z32(clamp04(uz(blo) - Zw), clamp04(uz(bhi) - Zw));
+                    const uint32_t mzB = my & mask_z32(clamp04(uz(blo) - Zw - 4), clamp04(uz(bhi) - Zw - 4));
+                    mAlo = (uint32_t)mxx & mzA; mAhi = (uint32_t)(mxx >> 32) & mzA;
+                    mBlo = (uint32_t)mxx & mzB; mBhi = (uint32_t)(mxx >> 32) & mzB;
                 }
-                unsigned long long todo = __builtin_amdgcn_ballot_w64((mlo | mhi) != 0u);
-#if GF_DBUF
-                // Software-pipelined walk over the hits: the record of hit k+1 is fetched
-                // (scalar loads into a second SGPR set) before hit k is evaluated.
-                auto next_hit = [&](unsigned long long &mask, float (&r)[kRecUsed]) {
-                    const int j = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const uint32_t g = __builtin_amdgcn_readlane(eg, j);
-                    mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mhi, j) << 32) |
-                           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mlo, j);
-                    crec_t rec = (crec_t)(uintptr_t)(a.records + (size_t)g * kRecDwords);
-#pragma unroll
-                    for (int q = 0; q < kRecUsed; ++q) r[q] = rec[q];
-                };
-                if (todo) {
-                    unsigned long long mA, mB = 0ull;
-                    float rA[kRecUsed], rB[kRecUsed];
-                    next_hit(mA, rA);
-                    while (true) {
-                        const bool moreB = todo != 0ull;
-                        if (moreB) next_hit(mB, rB);
-                        if (__builtin_amdgcn_inverse_ballot_w64(mA)) accumulate<VARIANT, EXP>(A, rA, px, py, pz);
-                        if (!moreB) break;
-                        const bool moreA = todo != 0ull;
-                        if (moreA) next_hit(mA, rA);
-                        if (__builtin_amdgcn_inverse_ballot_w64(mB)) accumulate<VARIANT, EXP>(A, rB, px, py, pz);
-                        if (!moreA) break;
-                    }
-                }
-#else
+                unsigned long long todo = __builtin_amdgcn_ballot_w64((mAlo | mAhi | mBlo | mBhi) != 0u);
                 while (todo) {
                     const int j = __builtin_ctzll(todo);
                     todo &= todo - 1;
-#if GF_DIAG == 1   // diagnostic: always the same record (scalar cache always hits)
-                    const uint32_t g = __builtin_amdgcn_readlane(eg, j) & 1u;
-#else
                     const uint32_t g = __builtin_amdgcn_readlane(eg, j);
-#endif
-                    const unsigned long long m =
-                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mhi, j) << 32) |
-                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mlo, j);
-#if GF_DIAG == 2   // diagnostic: record through the vector memory path (VGPR operands)
-                    const float4 *r4 = reinterpret_cast<const float4 *>(a.records + (size_t)g * kRecDwords);
-                    float rec[kRecDwords];
+                    const unsigned long long mA =
+                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mAhi, j) << 32) |
+                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mAlo, j);
+                    const unsigned long long mB =
+                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mBhi, j) << 32) |
+                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mBlo, j);
+                    crec_t recp = (crec_t)(uintptr_t)(a.records + (size_t)g * kRecDwords);
+                    float rec[kRecUsed];  // the whole record in SGPRs, one scalar round trip
 #pragma unroll
-                    for (int q = 0; q < kRecDwords / 4; ++q) {
-                        const float4 t4 = r4[q];
-                        rec[4 * q] = t4.x; rec[4 * q + 1] = t4.y; rec[4 * q + 2] = t4.z; rec[4 * q + 3] = t4.w;
+                    for (int q = 0; q < kRecUsed; ++q) rec[q] = recp[q];
+#pragma unroll
+                    for (int q = 0; q < kRecUsed; ++q) asm volatile("" ::"s"(rec[q]));  // one fetch, up front
+                    // both weights under the union mask (two independent chains interleave),
+                    // then the channel FMAs of each brick under its own mask
+                    float wA = 0.f, wB = 0.f, eA = 0.f, eB = 0.f;
+                    if (__builtin_amdgcn_inverse_ballot_w64(mA | mB)) {
+                        const f32x2 e2 = gauss_exp_pair<EXP>(rec, (f32x2){pAx, pBx}, (f32x2){pAy, pBy}, (f32x2){pAz, pBz});
+                        eA = e2.x; eB = e2.y;
+                        wA = gauss_weight<VARIANT>(rec, eA);
+                        wB = gauss_weight<VARIANT>(rec, eB);
                     }
-#else
-                    crec_t rec = (crec_t)(uintptr_t)(a.records + (size_t)g * kRecDwords);
-#endif
-                    if (__builtin_amdgcn_inverse_ballot_w64(m)) accumulate<VARIANT, EXP>(A, rec, px, py, pz);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mA)) accumulate_w<VARIANT>(A, rec, wA, eA);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mB)) accumulate_w<VARIANT>(B, rec, wB, eB);
                 }
-#endif
             }
             __syncthreads();  // every wave is done with the list
             list_len = 0;
@@ -589,38 +673,53 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
 
         if (VARIANT == GF_SPLAT_PROB) {
             prob_normalise(A);
-            if (lane_valid) {
-                a.out_bin[v] = 1 - A.bin;  // localagg_prob/src/forward.cu:99-101
-                a.out_density[v] = A.dens;
-                a.out_prob[v] = A.psum;
+            prob_normalise(B);
+            if (okA) {
+                a.out_bin[vA] = 1 - A.bin;  // localagg_prob/src/forward.cu:99-101
+                a.out_density[vA] = A.dens;
+                a.out_prob[vA] = A.psum;
+            }
+            if (okB) {
+                a.out_bin[vB] = 1 - B.bin;
+                a.out_density[vB] = B.dens;
+                a.out_prob[vB] = B.psum;
             }
         }
-        // rows -> LDS [voxel-in-brick][18]; the brick owns 16 runs of 4 consecutive rows
+        // rows -> LDS [voxel-in-brick][18] (wave-private region), then each brick's 16 runs of 4
+        // consecutive rows (288 B) are written with 16-B stores; lower brick, then upper brick.
         float *stage = reinterpret_cast<float *>(s_mem) + wave * (64 * kC);
 #pragma unroll
-        for (int ch = 0; ch < kC; ch += 2)
-            *reinterpret_cast<float2 *>(stage + lane * kC + ch) = make_float2(A.c[ch], A.c[ch + 1]);
-        __syncthreads();
-        if (Z0 < a.D) {
-            if ((a.D & 3) == 0) {
-                // 16 runs x 18 float4; run r = column (r>>2, r&3), rows Z0..Z0+3
-                for (int i = lane; i < 16 * kC; i += 64) {
-                    const int run = i / kC, k = i - run * kC;
-                    const int cx = X0 + (run >> 2), cy = Y0 + (run & 3);
-                    if (cx < a.H && cy < a.W) {
-                        const size_t row0 = ((size_t)cx * a.W + cy) * a.D + Z0;
-                        const float4 val = *reinterpret_cast<const float4 *>(stage + i * 4);
-                        store_row4(a.out_logits + row0 * kC + k * 4, val);
+        for (int half = 0; half < 2; ++half) {
+            const Acc &S = half == 0 ? A : B;
+            const int Zb = Zw + 4 * half;
+#pragma unroll
+            for (int ch = 0; ch < kC; ch += 2)
+                *reinterpret_cast<float2 *>(stage + lane * kC + ch) = make_float2(S.c[ch], S.c[ch + 1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (Zb < a.D) {
+                if ((a.D & 3) == 0) {
+                    // 16 runs x 18 float4; run r = column (r>>2, r&3), rows Zb..Zb+3
+                    for (int i = lane; i < 16 * kC; i += 64) {
+                        const int run = i / kC, k = i - run * kC;
+                        const int cx = Xw + (run >> 2), cy = Y0 + (run & 3);
+                        if (cx < a.H && cy < a.W) {
+                            const size_t row0 = ((size_t)cx * a.W + cy) * a.D + Zb;
+                            const float4 val = *reinterpret_cast<const float4 *>(stage + i * 4);
+                            store_row4(a.out_logits + row0 * kC + k * 4, val);
+                        }
+                    }
+                } else {
+                    for (int i = lane; i < 64 * kC; i += 64) {
+                        const int l = i / kC, ch = i - l * kC;
+                        const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zb + (l & 3);
+                        if (cx < a.H && cy < a.W && cz < a.D)
+                            a.out_logits[(((size_t)cx * a.W + cy) * a.D + cz) * kC + ch] = stage[i];
                     }
                 }
-            } else {
-                for (int i = lane; i < 64 * kC; i += 64) {
-                    const int l = i / kC, ch = i - l * kC;
-                    const int cx = X0 + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Z0 + (l & 3);
-                    if (cx < a.H && cy < a.W && cz < a.D)
-                        a.out_logits[(((size_t)cx * a.W + cy) * a.D + cz) * kC + ch] = stage[i];
-                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();  // staging is reused as list storage by the next zg
 #if GF_TIMELINE
@@ -688,9 +787,9 @@ static void launch_render(bool dense_candidate, const RenderArgs &r, hipStream_t
 template <int VARIANT>
 static void launch_render_exp(int flags, bool dense_candidate, const RenderArgs &r, hipStream_t stream)
 {
-    if (flags & GF_FAST_EXP) launch_render<VARIANT, kExpFast>(dense_candidate, r, stream);
-    else if (flags & GF_LIBM_EXP) launch_render<VARIANT, kExpLibm>(dense_candidate, r, stream);
-    else launch_render<VARIANT, kExpComp>(dense_candidate, r, stream);
+    if (flags & GF_LIBM_EXP) launch_render<VARIANT, kExpLibm>(dense_candidate, r, stream);
+    else if (flags & GF_COMP_EXP) launch_render<VARIANT, kExpComp>(dense_candidate, r, stream);
+    else launch_render<VARIANT, kExpFast>(dense_candidate, r, stream);
 }
 
 }  // namespace gf
@@ -741,6 +840,7 @@ extern "C" int gf_splat_forward(int variant, int radii_per_axis, int flags, int 
     pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
     pa.nwords = ws.nwords; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
     pa.variant = variant; pa.nprep_blocks = (P + 63) / 64; pa.verify = verify ? 1 : 0;
+    pa.prescale = (flags & (GF_LIBM_EXP | GF_COMP_EXP)) ? 0 : 1;
     const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks : 0);
     if (prep_grid > 0) {
         hipLaunchKernelGGL(gf_splat_prep_kernel, dim3(prep_grid), dim3(64), 0, stream, pa);

@@ -1,7 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > gpurun_out/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/pytest_gpu.log
 cat gpurun_out/pytest_gpu.log
 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json
-timeout 300 python tools/timeline.py > gpurun_out/timeline.log 2>&1; tail -16 gpurun_out/timeline.log
-timeout 300 python tools/quick_time.py > gpurun_out/quick_time.log 2>&1; cat gpurun_out/quick_time.log
+timeout 600 python tools/bench_ops.py > gpurun_out/bench_ops.jsonl 2> gpurun_out/bench_ops.err; cat gpurun_out/bench_ops.jsonl; tail -3 gpurun_out/bench_ops.err

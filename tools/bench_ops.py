@@ -1,0 +1,70 @@
+"""Secondary measurements (not the headline bench): device time of splat backward and of the
+deformable aggregation forward/backward at the BASELINE shapes, with algorithmic-bytes
+roofline fractions.  Prints one JSON line per op."""
+import json
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import oracle  # noqa: E402  (numpy pre-processing restatement only)
+from gaussianformer_amd import _lib  # noqa: E402
+from gaussianformer_amd.deformable_aggregation import (deformable_aggregation_backward,  # noqa: E402
+                                                        deformable_aggregation_forward)
+from gaussianformer_amd.local_aggregate import splat_backward, splat_forward  # noqa: E402
+from gaussianformer_amd.synthetic import make_daf_inputs, make_splat_inputs  # noqa: E402
+
+dev = torch.device("cuda:0")
+PEAK = 8000.0
+
+
+def timed(fn, warm=5, iters=30):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def report(op, config, seconds, abytes, extra=None):
+    d = {"op": op, "config": config, "us": seconds * 1e6, "algorithmic_MB": abytes / 1e6,
+         "achieved_GBs": abytes / seconds / 1e9, "frac_of_8TBs": abytes / seconds / 1e9 / PEAK}
+    d.update(extra or {})
+    print(json.dumps(d), flush=True)
+
+
+for config in ("nuscenes_gs25600_solid", "nuscenes_gs144000", "prob_gs6400"):
+    si = make_splat_inputs(config, seed=0)
+    pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size,
+                                                      si.scale_multiplier, radii_min=1 if si.variant == "prob" else None)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
+         (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
+    variant = _lib.GF_SPLAT_PROB if si.variant == "prob" else _lib.GF_SPLAT_BASE
+    P, N = si.means3D.shape[0], si.pts.shape[0]
+    extra_out = 12 * N if variant else 0
+    sec = timed(lambda: splat_forward(variant, *t, si.H, si.W, si.D))
+    report("splat_forward(module-level call)", config, sec, 128 * P + 24 * N + 72 * N + extra_out, {"P": P, "Gaussians_per_s": P / sec})
+    logits, bl, de, pr, state = splat_forward(variant, *t, si.H, si.W, si.D)
+    g = torch.randn(N, 18, device=dev)
+    gb = torch.randn(N, device=dev) if variant else None
+    sec = timed(lambda: splat_backward(variant, *t, si.H, si.W, si.D, g, fwd_outputs=(logits, bl, de, pr) if variant else None,
+                                       bin_logits_grad=gb, density_grad=gb, state=state), iters=10)
+    report("splat_backward", config, sec, 128 * P + 24 * N + 72 * N + 112 * P, {"P": P})
+
+for pts, name in ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000")):
+    d = make_daf_inputs(num_pts=pts, seed=0)
+    feat, ss, st, loc, w = (torch.from_numpy(d[k]).to(dev) for k in
+                            ("mc_ms_feat", "spatial_shape", "scale_start_index", "sampling_location", "weights"))
+    fbytes = 4 * feat.numel() + pts * (8 * 6 + 4 * 6 * 4 * 4 + 4 * 128)
+    sec = timed(lambda: deformable_aggregation_forward(feat, ss, st, loc, w))
+    report("daf_forward", name, sec, fbytes, {"sample_points": pts})
+    go = torch.randn(1, pts, 128, device=dev)
+    gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(loc), torch.zeros_like(w)
+    sec = timed(lambda: deformable_aggregation_backward(feat, ss, st, loc, w, go, gf, gl, gw), iters=10)
+    report("daf_backward", name, sec, 2 * 4 * feat.numel() + 2 * pts * (8 * 6 + 4 * 6 * 4 * 4) + 4 * 128 * pts, {"sample_points": pts})

@@ -16,7 +16,8 @@ for config in sys.argv[1:] or ["nuscenes_gs25600_solid", "nuscenes_gs144000"]:
     t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
          (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
     variant = _lib.GF_SPLAT_PROB if si.variant == "prob" else _lib.GF_SPLAT_BASE
-    for name, flags in (("auto", 0), ("assume_dense", 1), ("assume_dense+fastexp", 5), ("general", 2)):
+    ref = None
+    for name, flags in (("auto", 0), ("auto+comp_exp", 16), ("auto+libm_exp", 8), ("assume_dense", 1), ("general", 2)):
         for _ in range(5):
             out = splat_forward(variant, *t, si.H, si.W, si.D, flags=flags)
         torch.cuda.synchronize()
@@ -29,7 +30,11 @@ for config in sys.argv[1:] or ["nuscenes_gs25600_solid", "nuscenes_gs144000"]:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         P = si.means3D.shape[0]
-        print(f"{config} fwd[{name}]: {ms*1e3:.1f} us/call  {P/ms/1e6:.3f} G Gaussians/s", flush=True)
+        if ref is None:
+            ref = oracle.splat_forward(si.variant, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6,
+                                       si.H, si.W, si.D)["logits"]
+        err = np.abs(out[0].cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref))
+        print(f"{config} fwd[{name}]: {ms*1e3:.1f} us/call  {P/ms/1e6:.3f} G Gaussians/s   max scaled err vs oracle {err.max():.2e}", flush=True)
     g = torch.randn(si.pts.shape[0], 18, device=dev)
     logits, bl, de, pr, state = splat_forward(variant, *t, si.H, si.W, si.D)
     for _ in range(3):

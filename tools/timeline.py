@@ -18,13 +18,17 @@ plan = SplatForwardPlan(0, *t, si.H, si.W, si.D, flags=1)
 lib = _lib.load()
 for _ in range(5): plan.run()
 torch.cuda.synchronize()
-nb = 2504
-tl = torch.zeros(nb * 4, dtype=torch.int64, device=dev)
+nb = 1256
+tl = torch.zeros(nb * 5, dtype=torch.int64, device=dev)
 lib.gf_debug_set_timeline.argtypes = [ctypes.c_void_p]
 lib.gf_debug_set_timeline(tl.data_ptr())
 plan.run(); torch.cuda.synchronize()
 lib.gf_debug_set_timeline(None)
-T = tl.cpu().numpy().reshape(nb, 4).astype(np.float64)
+raw = tl.cpu().numpy()
+ids = raw[4 * nb:]
+T = raw[:4 * nb].reshape(nb, 4).astype(np.float64)
+valid = T[:, 0] > 0
+ids = ids[valid]
 T = T[T[:, 0] > 0]
 t0 = T[:, 0].min()
 T = (T - t0) / 100.0  # 100 MHz -> us
@@ -38,3 +42,16 @@ order = np.argsort(T[:, 0])
 first = T[order[:2048]]; late = T[order[2048:]]
 print("first-wave blocks: mean total", (first[:, 3]-first[:, 0]).mean(), " late blocks:", len(late), "mean start", late[:, 0].mean() if len(late) else None, "mean total", (late[:, 3]-late[:, 0]).mean() if len(late) else None)
 hist, edges = np.histogram(T[:, 0], bins=12); print("start hist", hist.tolist(), [round(e,1) for e in edges.tolist()])
+
+hw = ids & 0xFFFFFFFF; xcc = (ids >> 32) & 0xF
+cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
+key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+uniq, cnt = np.unique(key, return_counts=True)
+print("distinct CUs used", len(uniq), "blocks per CU: min", cnt.min(), "max", cnt.max(), "hist", np.bincount(cnt).tolist())
+endt = T[:, 3]
+per_cu_end = {k: endt[key == k].max() for k in uniq}
+ends = np.array(list(per_cu_end.values()))
+print("per-CU finish time us: min %.1f p50 %.1f max %.1f" % (ends.min(), np.median(ends), ends.max()))
+for c in sorted(set(cnt.tolist())):
+    sel = [per_cu_end[k] for k, n in zip(uniq, cnt) if n == c]
+    print("  CUs with %d blocks: %d, mean finish %.1f us" % (c, len(sel), np.mean(sel)))
