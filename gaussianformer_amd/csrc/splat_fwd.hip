@@ -51,7 +51,7 @@ struct PrepArgs {
 };
 
 constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
-constexpr int kPrepSuperChunk = 1024;  // supertiles per LDS pass of the prep kernel (128 KB)
+constexpr int kPrepSuperChunk = 2048;  // supertiles per LDS pass of the prep kernel (16 KB)
 
 // Integer box of Gaussian g: model/head/localagg/src/auxiliary.h:8-20 (scalar radius) and
 // model/head/localagg_prob_fast/src/auxiliary.h:8-20 (per-axis radius).
@@ -70,22 +70,15 @@ __device__ __forceinline__ void gaussian_box(const int *__restrict__ means_int, 
     lo[2] = min(D, max(0, m2 - r2)); hi[2] = min(D, max(0, m2 + r2 + 1));
 }
 
-constexpr int kPrepThreads = 1024;  // Gaussian role: 1024 Gaussians = 16 bitmask words per workgroup
-constexpr int kPrepWords = kPrepThreads / 64;
-
-__global__ __launch_bounds__(kPrepThreads) void gf_splat_prep_kernel(PrepArgs a)
+__global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
 {
-    // Gaussian role: 16 waves x 64 Gaussians.  The 16 words a workgroup produces for one
-    // supertile are contiguous in the bitmask row (128 B = one full line), so the write-out is
-    // whole-line stores.
-    __shared__ unsigned long long s_bits[kPrepSuperChunk * kPrepWords];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // One wave per workgroup.  Gaussian role: 64 Gaussians -> one bitmask word per supertile.
+    __shared__ unsigned long long s_bits[kPrepSuperChunk];
+    const int lane = threadIdx.x;
     if ((int)blockIdx.x >= a.nprep_blocks) {
         // ---- verification role: is point n in voxel n for all n?  Each wave reports its own
         // slice unconditionally (no zero-initialised flag needed).
-        const int vb = ((int)blockIdx.x - a.nprep_blocks) * kPrepWords + wave;
+        const int vb = (int)blockIdx.x - a.nprep_blocks;
         bool bad = false;
         const long long stride = (long long)kVerifyBlocks * 64;
         for (long long n0 = (long long)vb * 64 + lane; n0 < a.N; n0 += 4 * stride) {
@@ -112,7 +105,7 @@ __global__ __launch_bounds__(kPrepThreads) void gf_splat_prep_kernel(PrepArgs a)
         if (lane == 0) a.verify_flags[vb] = any ? 1u : 0u;
         return;
     }
-    const int g = blockIdx.x * kPrepThreads + tid;
+    const int g = blockIdx.x * 64 + lane;
     const bool valid = g < a.P;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     if (valid) gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
@@ -123,7 +116,7 @@ __global__ __launch_bounds__(kPrepThreads) void gf_splat_prep_kernel(PrepArgs a)
     const int npairs = nonempty ? (sx_hi - sx_lo + 1) * (sy_hi - sy_lo + 1) : 0;
     const int nsuper = a.nsx * a.nsy;
     // zero the first LDS chunk while the parameter loads are in flight
-    for (int i = tid; i < min(kPrepSuperChunk, nsuper) * kPrepWords; i += kPrepThreads) s_bits[i] = 0ull;
+    for (int i = lane; i < min(kPrepSuperChunk, nsuper); i += 64) s_bits[i] = 0ull;
     if (valid) {
         const uint32_t plo = pack3(lo[0], lo[1], lo[2]);
         const uint32_t phi = nonempty ? pack3(hi[0], hi[1], hi[2]) : plo;
@@ -159,17 +152,15 @@ __global__ __launch_bounds__(kPrepThreads) void gf_splat_prep_kernel(PrepArgs a)
     const unsigned long long mybit = 1ull << lane;
     for (int s0 = 0; s0 < nsuper; s0 += kPrepSuperChunk) {
         const int ns = min(kPrepSuperChunk, nsuper - s0);
-        if (s0 > 0) {
-            __syncthreads();
-            for (int i = tid; i < ns * kPrepWords; i += kPrepThreads) s_bits[i] = 0ull;
-        }
-        __syncthreads();
+        if (s0 > 0)
+            for (int i = lane; i < ns; i += 64) s_bits[i] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // single wave: LDS ops stay ordered
         // small footprints: each lane ORs its own bit (order-independent => deterministic)
         if (npairs > 0 && npairs <= 16) {
             for (int sx = sx_lo; sx <= sx_hi; ++sx)
                 for (int sy = sy_lo; sy <= sy_hi; ++sy) {
                     const int s = sx * a.nsy + sy - s0;
-                    if (s >= 0 && s < ns) atomicOr(&s_bits[s * kPrepWords + wave], mybit);
+                    if (s >= 0 && s < ns) atomicOr(&s_bits[s], mybit);
                 }
         }
         // large footprints (e.g. the whole-grid "empty" Gaussian): the wave cooperates
@@ -182,15 +173,11 @@ __global__ __launch_bounds__(kPrepThreads) void gf_splat_prep_kernel(PrepArgs a)
             const int ny = by_hi - by_lo + 1, tot = (bx_hi - bx_lo + 1) * ny;
             for (int i = lane; i < tot; i += 64) {
                 const int s = (bx_lo + i / ny) * a.nsy + by_lo + i % ny - s0;
-                if (s >= 0 && s < ns) atomicOr(&s_bits[s * kPrepWords + wave], 1ull << j);
+                if (s >= 0 && s < ns) atomicOr(&s_bits[s], 1ull << j);
             }
         }
-        __syncthreads();
-        // write-out: 16 consecutive words per supertile = one 128-B line
-        for (int i = tid; i < ns * kPrepWords; i += kPrepThreads) {
-            const int w = blockIdx.x * kPrepWords + (i & (kPrepWords - 1));
-            if (w < a.nwords) a.bitmask[(size_t)(s0 + i / kPrepWords) * a.nwords + w] = s_bits[i];
-        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (int i = lane; i < ns; i += 64) a.bitmask[(size_t)(s0 + i) * a.nwords + blockIdx.x] = s_bits[i];
     }
 }
 
@@ -852,11 +839,11 @@ extern "C" int gf_splat_forward(int variant, int radii_per_axis, int flags, int 
     pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.records = ws.records; pa.boxes = ws.boxes;
     pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
     pa.nwords = ws.nwords; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
-    pa.variant = variant; pa.nprep_blocks = (P + kPrepThreads - 1) / kPrepThreads; pa.verify = verify ? 1 : 0;
+    pa.variant = variant; pa.nprep_blocks = (P + 63) / 64; pa.verify = verify ? 1 : 0;
     pa.prescale = (flags & (GF_LIBM_EXP | GF_COMP_EXP)) ? 0 : 1;
-    const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / kPrepWords : 0);
+    const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks : 0);
     if (prep_grid > 0) {
-        hipLaunchKernelGGL(gf_splat_prep_kernel, dim3(prep_grid), dim3(kPrepThreads), 0, stream, pa);
+        hipLaunchKernelGGL(gf_splat_prep_kernel, dim3(prep_grid), dim3(64), 0, stream, pa);
         GF_CHECK_LAUNCH();
     }
     if (N == 0) return GF_OK;

@@ -1,0 +1,11 @@
+#!/bin/bash
+# full GPU evidence run: tests, smoke, bench, secondary ops, profiles
+R=${1:-r01}
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/pytest_gpu_$R.log; cat gpurun_out/pytest_gpu_$R.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$R.log 2>&1; tail -2 gpurun_out/smoke_$R.log
+bash tools/collect_profiles.sh $R > gpurun_out/collect_$R.log 2>&1; head -3 gpurun_out/collect_$R.log | cut -c1-600
+timeout 600 python tools/bench_ops.py > gpurun_out/profiles_$R/bench_ops_$R.jsonl 2> gpurun_out/bench_ops.err; cat gpurun_out/profiles_$R/bench_ops_$R.jsonl
+timeout 300 python tools/timeline.py > gpurun_out/profiles_$R/timeline_render_$R.txt 2>&1; tail -20 gpurun_out/profiles_$R/timeline_render_$R.txt
+./tools/microbench/valu > gpurun_out/profiles_$R/microbench_valu_$R.txt 2>&1
+cp gpurun_out/pytest_gpu_$R.log gpurun_out/smoke_$R.log gpurun_out/profiles_$R/
