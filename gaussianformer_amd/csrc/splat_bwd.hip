@@ -22,6 +22,22 @@
 // Launches: [voxel->point map (arbitrary pts only)] -> volumes -> gradient kernel.
 #include "gf_common.hpp"
 
+#ifndef GF_BWD_OCC_BASE
+#define GF_BWD_OCC_BASE 4
+#endif
+#ifndef GF_BWD_OCC_PROB
+#define GF_BWD_OCC_PROB 2
+#endif
+#ifndef GF_BWD_XCD
+#define GF_BWD_XCD 1
+#endif
+#ifndef GF_BWD_PHASES
+#define GF_BWD_PHASES 1
+#endif
+#ifndef GF_BWD_LG_STAGE
+#define GF_BWD_LG_STAGE 1
+#endif
+
 namespace gf {
 
 struct BwdArgs {
@@ -33,7 +49,7 @@ struct BwdArgs {
     const float *semantics;
     const int *radii;
     const float *cov3D;
-    const float *logits;       // prob only
+    const float *logits;       // prob only, [N,18]
     const float *bin_logits;   // prob only
     const float *probability;  // prob only
     const float *out_grad;     // [N,18]
@@ -50,7 +66,50 @@ struct BwdArgs {
     int P, N, H, W, D, per_axis, force_general, assume_dense, nblk;
 };
 
-constexpr int kBwdMaxBlk = 2048;  // LDS prefix capacity: P <= 524 288 Gaussians
+constexpr int kBwdMaxBlk = 1024;  // LDS prefix capacity: P <= 262 144 Gaussians
+
+// Wave-cooperative fetch of 64 rows of 18 floats from a row-major [N,18] array.  A row-per-lane
+// load is a 72-B-strided access that touches ~36 cache lines per instruction; instead lane L
+// of load k fetches the 8-byte piece q = L + 64k (row q/9, piece q%9): consecutive lanes read
+// consecutive pieces of consecutive rows (~8 lines per instruction).  stage_issue() only
+// ISSUES the 9 loads (so they can overlap the previous iteration's arithmetic);
+// stage_finish() transposes them through LDS into row-per-lane registers.
+__device__ __forceinline__ void stage_issue(const float *__restrict__ src, int p, float2 (&raw)[9], int *s_pidx, int lane)
+{
+    s_pidx[lane] = p;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int q = lane + 64 * k;
+        const int r = q / 9, part = q - 9 * r;
+        const int pr = s_pidx[r];
+        raw[k] = make_float2(0.f, 0.f);
+        if (pr >= 0) raw[k] = *reinterpret_cast<const float2 *>(src + (size_t)pr * kC + 2 * part);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void stage_finish(const float2 (&raw)[9], float (&row)[kC], float *s_rows, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 9; ++k)  // row r, piece part -> float offset 18 r + 2 part = 2 q
+        *reinterpret_cast<float2 *>(s_rows + 2 * (lane + 64 * k)) = raw[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < kC / 2; ++j) {
+        const float2 t = *reinterpret_cast<const float2 *>(s_rows + lane * kC + 2 * j);
+        row[2 * j] = t.x; row[2 * j + 1] = t.y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Gaussian parameters are read-only here: the constant address space turns the wave-uniform
+// fetches into scalar loads (SGPR operands, no VGPRs spent on them).
+using cfloat_t = const float __attribute__((address_space(4))) *;
 
 __device__ __forceinline__ void box_of(const BwdArgs &a, int g, int lo[3], int hi[3])
 {
@@ -143,11 +202,15 @@ __device__ __forceinline__ float wave_sum63(float v)
 }
 
 template <int VARIANT>
-__global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
+__global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? GF_BWD_OCC_BASE : GF_BWD_OCC_PROB) void gf_splat_bwd_kernel(BwdArgs a)
 {
     __shared__ unsigned long long s_pref[kBwdMaxBlk + 1];  // exclusive prefix of the block sums
+    __shared__ __attribute__((aligned(16))) float s_rows_all[4 * 64 * kC];
+    __shared__ int s_pidx_all[4 * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    float *s_rows = s_rows_all + (tid >> 6) * 64 * kC;
+    int *s_pidx = s_pidx_all + (tid >> 6) * 64;
     // ---- every workgroup rebuilds the (small) block prefix in LDS
     {
         // serial-in-chunks scan by wave 0: 64 block sums per step
@@ -172,13 +235,23 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
         __syncthreads();
     }
     const unsigned long long R = s_pref[a.nblk];
-    const int wave_global = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (tid >> 6)));
-    const unsigned long long nwaves = (unsigned long long)gridDim.x * 4ull;
-    const unsigned long long per = (((R + nwaves - 1) / nwaves) + 63ull) & ~63ull;
-    unsigned long long r0 = (unsigned long long)wave_global * per;
-    const unsigned long long r1 = min(R, r0 + per);
-    if (r0 >= R) return;
     const bool dense = pts_are_dense(a);
+    // Range schedule.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and every workgroup is
+    // resident at once, so XCD k is given the k-th eighth of the concatenation (with the
+    // Gaussians in spatial order that is one compact region of the grid whose dL rows stay in
+    // that XCD's 4 MB L2), walked in kBwdPhases successive sub-regions.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const unsigned long long nranges = (unsigned long long)gridDim.x * 4ull * GF_BWD_PHASES;
+    const unsigned long long per = (((R + nranges - 1) / nranges) + 63ull) & ~63ull;
+    for (int phase = 0; phase < GF_BWD_PHASES; ++phase) {
+#if GF_BWD_XCD
+    const int range_id = __builtin_amdgcn_readfirstlane(((xcd * GF_BWD_PHASES + phase) * per_xcd + slot) * 4 + (tid >> 6));
+#else
+    const int range_id = __builtin_amdgcn_readfirstlane((int)((phase * gridDim.x + blockIdx.x) * 4 + (tid >> 6)));
+#endif
+    unsigned long long r0 = (unsigned long long)range_id * per;
+    const unsigned long long r1 = min(R, r0 + per);
+    if (r0 >= R) continue;
 
     // ---- locate the Gaussian containing voxel r0: binary search over blocks, then a wave scan
     int blo = 0, bhi = a.nblk;  // invariant: s_pref[blo] <= r0 < s_pref[bhi]
@@ -219,13 +292,15 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
         const int ny = hi[1] - lo[1], nz = hi[2] - lo[2];
 
         // wave-uniform Gaussian parameters
-        const float mx = a.means3D[3 * g], my = a.means3D[3 * g + 1], mz = a.means3D[3 * g + 2];
-        const float *cv = a.cov3D + 6 * (size_t)g;
+        cfloat_t mp = (cfloat_t)(uintptr_t)(a.means3D + 3 * (size_t)g);
+        const float mx = mp[0], my = mp[1], mz = mp[2];
+        cfloat_t cv = (cfloat_t)(uintptr_t)(a.cov3D + 6 * (size_t)g);
         const float c1x = cv[0], c1y = cv[1], c1z = cv[2], c2x = cv[3], c2y = cv[4], c2z = cv[5];
-        const float opa = a.opacity[g];
+        const float opa = ((cfloat_t)(uintptr_t)(a.opacity + g))[0];
+        cfloat_t sp = (cfloat_t)(uintptr_t)(a.semantics + (size_t)kC * g);
         float sem[kC];
 #pragma unroll
-        for (int ch = 0; ch < kC; ++ch) sem[ch] = a.semantics[(size_t)kC * g + ch];
+        for (int ch = 0; ch < kC; ++ch) sem[ch] = sp[ch];
         float deter = 1.f, kdet = 0.f;
         if (VARIANT == GF_SPLAT_PROB) {
             // model/head/localagg_prob/src/backward.cu:78-79
@@ -248,21 +323,60 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
         const int rz = 64 % nz, qz = 64 / nz;
         const int ry = qz % ny, qx = qz / ny;
 
-        for (; i < o1; i += 64) {
-            const size_t v = ((size_t)(lo[0] + x) * a.W + (lo[1] + y)) * a.D + (lo[2] + z);
-            const int p = dense ? (int)v : a.voxel2pts[v];
+        // Software-pipelined walk: the point index, position and gradient rows of the NEXT 64
+        // voxels are requested (coalesced, see stage_issue) before the current 64 are evaluated,
+        // so the ~microsecond L2 / Infinity-Cache latency overlaps the arithmetic.
+        auto point_of = [&](int ii, int fx, int fy, int fz) {
+            int q = -1;
+            if (ii < o1) {
+                const size_t v = ((size_t)(lo[0] + fx) * a.W + (lo[1] + fy)) * a.D + (lo[2] + fz);
+                q = dense ? (int)v : a.voxel2pts[v];
+            }
+            return q;
+        };
+        auto advance = [&]() {  // (x, y, z) += 64 voxels in z-fastest order
+            z += rz;
+            int carry = 0;
+            if (z >= nz) { z -= nz; carry = 1; }
+            y += ry + carry;
+            carry = 0;
+            if (y >= ny) { y -= ny; carry = 1; }
+            x += qx + carry;
+        };
+        float2 raw[9];
+        float dL[kC];
+        float ptx = 0.f, pty = 0.f, ptz = 0.f, ptx_n = 0.f, pty_n = 0.f, ptz_n = 0.f;
+        int p = point_of(i, x, y, z), p_n = -1;
+        stage_issue(a.out_grad, p, raw, s_pidx, lane);
+        if (p >= 0) { ptx = a.pts[3 * (size_t)p]; pty = a.pts[3 * (size_t)p + 1]; ptz = a.pts[3 * (size_t)p + 2]; }
+        for (int base = o0; base < o1; base += 64) {  // wave-uniform trip count
+            stage_finish(raw, dL, s_rows, lane);
+            float lg[kC];
+            if (VARIANT == GF_SPLAT_PROB) {
+#if GF_BWD_LG_STAGE
+                float2 raw2[9];
+                stage_issue(a.logits, p, raw2, s_pidx, lane);
+                stage_finish(raw2, lg, s_rows, lane);
+#else
+                if (p >= 0) {
+#pragma unroll
+                    for (int j = 0; j < kC / 2; ++j) {
+                        const float2 t = *reinterpret_cast<const float2 *>(a.logits + (size_t)p * kC + 2 * j);
+                        lg[2 * j] = t.x; lg[2 * j + 1] = t.y;
+                    }
+                }
+#endif
+            }
+            advance();
+            i += 64;
+            p_n = point_of(i, x, y, z);
+            stage_issue(a.out_grad, p_n, raw, s_pidx, lane);
+            if (p_n >= 0) { ptx_n = a.pts[3 * (size_t)p_n]; pty_n = a.pts[3 * (size_t)p_n + 1]; ptz_n = a.pts[3 * (size_t)p_n + 2]; }
             if (p >= 0) {
-                const float dx = mx - a.pts[3 * (size_t)p], dy = my - a.pts[3 * (size_t)p + 1], dz = mz - a.pts[3 * (size_t)p + 2];
+                const float dx = mx - ptx, dy = my - pty, dz = mz - ptz;
                 float power = c1x * dx * dx + c1y * dy * dy + c1z * dz * dz;
                 power = -0.5f * power - (c2x * dx * dy + c2y * dy * dz + c2z * dx * dz);
                 const float e = expf(power);
-                float dL[kC];
-                const float2 *row = reinterpret_cast<const float2 *>(a.out_grad + (size_t)p * kC);
-#pragma unroll
-                for (int q = 0; q < kC / 2; ++q) {
-                    const float2 tq = row[q];
-                    dL[2 * q] = tq.x; dL[2 * q + 1] = tq.y;
-                }
                 const float sx = c1x * dx + c2x * dy + c2z * dz;  // (Sigma^-1 d)
                 const float sy = c2x * dx + c1y * dy + c2y * dz;
                 const float sz = c2z * dx + c2y * dy + c1z * dz;
@@ -288,16 +402,12 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
                     const float psum = a.probability[p];
                     float prob_grad = 0.f;
                     if ((double)psum > 1e-9) {
-                        const float2 *lrow = reinterpret_cast<const float2 *>(a.logits + (size_t)p * kC);
                         const float coef = prob * opa / psum;
                         float Asum = 0.f;
 #pragma unroll
-                        for (int q = 0; q < kC / 2; ++q) {
-                            const float2 lq = lrow[q];
-                            sg[2 * q] += dL[2 * q] * coef;
-                            sg[2 * q + 1] += dL[2 * q + 1] * coef;
-                            Asum += dL[2 * q] * (sem[2 * q] - lq.x);
-                            Asum += dL[2 * q + 1] * (sem[2 * q + 1] - lq.y);
+                        for (int ch = 0; ch < kC; ++ch) {
+                            sg[ch] += dL[ch] * coef;
+                            Asum += dL[ch] * (sem[ch] - lg[ch]);
                         }
                         prob_grad = Asum * opa / psum;
                         og += Asum * prob / psum;
@@ -312,14 +422,7 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
                     cg3 += pg * (-dx * dy); cg4 += pg * (-dy * dz); cg5 += pg * (-dx * dz);
                 }
             }
-            // advance (x, y, z) by 64 voxels in z-fastest order
-            z += rz;
-            int carry = 0;
-            if (z >= nz) { z -= nz; carry = 1; }
-            y += ry + carry;
-            carry = 0;
-            if (y >= ny) { y -= ny; carry = 1; }
-            x += qx + carry;
+            p = p_n; ptx = ptx_n; pty = pty_n; ptz = ptz_n;
         }
 
         // reduce across the wave (totals valid in lane 63)
@@ -364,6 +467,7 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_kernel(BwdArgs a)
             ++g;
         }
     }
+    }  // phase
 }
 
 }  // namespace gf
@@ -404,7 +508,8 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     BwdArgs a;
     a.pts = pts; a.points_int = points_int; a.means3D = means3D; a.means_int = means3D_int; a.opacity = opacity;
     a.semantics = semantics; a.radii = radii; a.cov3D = cov3D; a.logits = logits; a.bin_logits = bin_logits;
-    a.probability = probability; a.out_grad = logits_grad; a.bin_grad = bin_logits_grad; a.dens_grad = density_grad;
+    a.probability = probability; a.bin_grad = bin_logits_grad; a.dens_grad = density_grad;
+    a.out_grad = logits_grad;
     a.means_grad = means3D_grad; a.opa_grad = opacity_grad; a.sem_grad = semantics_grad; a.cov_grad = cov3D_grad;
     a.state = (const uint32_t *)state; a.voxel2pts = ws.voxel2pts; a.vols = ws.vols; a.bsum = ws.bsum;
     a.P = P; a.N = N; a.H = H; a.W = W; a.D = D; a.per_axis = radii_per_axis ? 1 : 0; a.nblk = (P + 255) / 256;

@@ -268,3 +268,26 @@ def test_exp_modes(gpu, mode):
         assert_logits_close(got["logits"], ref["logits"], tol=2e-5)  # 5x margin on the 1e-4 bound
         gen, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags | _lib.GF_PTS_GENERAL)
         assert np.array_equal(gen["logits"], got["logits"])
+
+
+def test_backward_channel_major_gradient(gpu):
+    """The gradient autograd produces when the loss consumed logits[None].transpose(1, 2)
+    ([1,18,N], gaussian_head.py:176) is a transposed (non-contiguous) view; the wrapper must
+    handle it and give the same result as a contiguous [N,18] gradient."""
+    import torch
+    import local_aggregate
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=19, P=400, H=24, W=24, D=16)
+    agg = local_aggregate.LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)
+    tt = lambda a, g=False: torch.from_numpy(a).to(gpu)[None].requires_grad_(g)
+    wgt = torch.from_numpy(np.random.default_rng(20).standard_normal((1, 18, si.pts.shape[0])).astype(np.float32)).to(gpu)
+    grads = []
+    for transposed in (True, False):
+        means, opa, sem, cov = tt(si.means3D, True), tt(si.opacities, True), tt(si.semantics, True), tt(si.cov3D, True)
+        logits = agg(tt(si.pts), means, opa, sem, tt(si.scales), cov)
+        if transposed:
+            (logits[None].transpose(1, 2) * wgt).sum().backward()      # grad arrives as a [N,18] view of [18,N]
+        else:
+            logits.backward(wgt[0].t().contiguous())
+        grads.append([t.grad.clone() for t in (means, opa, sem, cov)])
+    for a, b in zip(*grads):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))

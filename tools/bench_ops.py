@@ -57,7 +57,8 @@ for config in ("nuscenes_gs25600_solid", "nuscenes_gs144000", "prob_gs6400"):
                                        bin_logits_grad=gb, density_grad=gb, state=state), iters=10)
     report("splat_backward", config, sec, 128 * P + 24 * N + 72 * N + 112 * P, {"P": P})
 
-for pts, name in ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000")):
+DAF_CASES = () if "--splat-only" in sys.argv else ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000"))
+for pts, name in DAF_CASES:
     d = make_daf_inputs(num_pts=pts, seed=0)
     feat, ss, st, loc, w = (torch.from_numpy(d[k]).to(dev) for k in
                             ("mc_ms_feat", "spatial_shape", "scale_start_index", "sampling_location", "weights"))
