@@ -14,9 +14,11 @@ LIB_PATH = os.environ.get("GF_LIB") or os.path.join(_HERE, "csrc", "libgf_hip.so
 GF_ABI_VERSION = 1
 GF_SPLAT_BASE, GF_SPLAT_PROB = 0, 1
 GF_NUM_CHANNELS = 18
+GF_RADII_SCALAR, GF_RADII_SCALAR_CLAMPED, GF_RADII_PER_AXIS = 0, 1, 2
+GF_PREPARE_MEAN_OUT_OF_GRID, GF_PREPARE_RADIUS_BELOW_ONE = 1, 2
 GF_PTS_AUTO, GF_PTS_ASSUME_DENSE, GF_PTS_GENERAL, GF_FAST_EXP, GF_LIBM_EXP, GF_COMP_EXP = 0, 1, 2, 4, 8, 16
 
-_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_vp, _i, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
 
 # name -> (restype, argtypes); must list every symbol include/gf_hip.h declares
 SIGNATURES = {
@@ -29,6 +31,8 @@ SIGNATURES = {
     "gf_splat_box_volumes": (_i, [_i] * 5 + [_vp] * 5),
     "gf_daf_forward": (_i, [_i] * 7 + [_vp] * 7),
     "gf_daf_backward": (_i, [_i] * 7 + [_vp] * 10),
+    "gf_gaussian_prepare": (_i, [_i] * 4 + [_vp, _f, _f, _i, _i] + [_vp] * 8 + [_vp]),
+    "gf_gaussian_prepare_backward": (_i, [_i] * 2 + [_vp] * 5 + [_vp]),
     "gf_profile_enable": (_i, [_i]),
     "gf_profile_read": (_i, [_vp, _i]),
 }

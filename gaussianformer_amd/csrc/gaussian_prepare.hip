@@ -1,0 +1,215 @@
+// Fused Gaussian pre-processing for the splat: everything GaussianHead.prepare_gaussian_args
+// (model/head/gaussian_head.py:108-120) and LocalAggregator.forward
+// (model/head/localagg/local_aggregate/__init__.py:137-143) compute per Gaussian before the
+// rasteriser is called, in one pass, on the device, with no host synchronisation.
+//
+// The reference builds S and R as dense 3x3 tensors, forms Cov = (S R)^T (S R), ships it to the
+// host for a LAPACK inverse and back, and then runs ~10 elementwise kernels with five
+// `.min()/.max()` host syncs.  Here one thread per Gaussian produces the packed Sigma^-1, the
+// integer cell, the integer radius and a status word for the range checks.
+//
+// HBM traffic: 40 B in (mean 12, scale 12, quaternion 16), 40-84 B out per Gaussian.
+#include "gf_common.hpp"
+
+namespace gf {
+
+struct PrepareArgs {
+    const float *means;      // [P,3]
+    const float *scales;     // [P,3]
+    const float *rotations;  // [P,4] (w,x,y,z), any norm
+    int *means_int;          // [P,3]
+    int *radii;              // [P] or [P,3]
+    float *cov6;             // [P,6] (xx,yy,zz,xy,yz,xz) of Sigma^-1
+    float *cov9;             // [P,9] optional full Sigma^-1
+    int *status;             // [1] optional, OR of GF_PREPARE_* bits
+    const float *cov_grad;   // backward: [P,6] or [P,9]
+    float *scales_grad;      // backward: [P,3]
+    float *rot_grad;         // backward: [P,4]
+    float pc_min[3];
+    float grid_size, scale_multiplier;
+    int P, H, W, D, radii_mode, radii_min, grad_is_full;
+};
+
+struct Quat {
+    float w, x, y, z, inv_norm;
+};
+
+// F.normalize(q, dim=-1) (model/utils/utils.py:23): q / max(||q||, 1e-12)
+__device__ __forceinline__ Quat load_unit_quat(const float *q)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(q);
+    const float n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    Quat r;
+    r.inv_norm = 1.f / fmaxf(n, 1e-12f);
+    r.w = v.x * r.inv_norm; r.x = v.y * r.inv_norm; r.y = v.z * r.inv_norm; r.z = v.w * r.inv_norm;
+    return r;
+}
+
+// mat1 @ mat2^T without the first row/column (model/utils/utils.py:24-69)
+__device__ __forceinline__ void rotation_of(const Quat &q, float (&R)[3][3])
+{
+    const float w = q.w, x = q.x, y = q.y, z = q.z;
+    R[0][0] = w * w + x * x - y * y - z * z; R[0][1] = 2.f * (x * y - w * z); R[0][2] = 2.f * (x * z + w * y);
+    R[1][0] = 2.f * (x * y + w * z); R[1][1] = w * w - x * x + y * y - z * z; R[1][2] = 2.f * (y * z - w * x);
+    R[2][0] = 2.f * (x * z - w * y); R[2][1] = 2.f * (y * z + w * x); R[2][2] = w * w - x * x - y * y + z * z;
+}
+
+__global__ __launch_bounds__(256) void gf_gaussian_prepare_kernel(PrepareArgs a)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.P) return;
+    const float sx = a.scales[3 * (size_t)g], sy = a.scales[3 * (size_t)g + 1], sz = a.scales[3 * (size_t)g + 2];
+    int bad = 0;
+    if (a.cov6 || a.cov9) {
+        // Cov = (S R)^T (S R) = R^T S^2 R (gaussian_head.py:111-118), so with R orthonormal
+        // Cov^-1 = R^T S^-2 R: the closed form replaces the host LAPACK inverse (:119).
+        float R[3][3];
+        rotation_of(load_unit_quat(a.rotations + 4 * (size_t)g), R);
+        const float i0 = 1.f / (sx * sx), i1 = 1.f / (sy * sy), i2 = 1.f / (sz * sz);
+        float A[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j) A[i][j] = A[j][i] = R[0][i] * R[0][j] * i0 + R[1][i] * R[1][j] * i1 + R[2][i] * R[2][j] * i2;
+        if (a.cov6) {
+            float *c = a.cov6 + 6 * (size_t)g;  // flatten(1)[:, [0,4,8,1,5,2]] (local_aggregate/__init__.py:143)
+            c[0] = A[0][0]; c[1] = A[1][1]; c[2] = A[2][2]; c[3] = A[0][1]; c[4] = A[1][2]; c[5] = A[0][2];
+        }
+        if (a.cov9) {
+            float *c = a.cov9 + 9 * (size_t)g;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) c[3 * i + j] = A[i][j];
+        }
+    }
+    if (a.means_int) {
+        // ((means3D - pc_min) / grid_size).to(torch.int)   (local_aggregate/__init__.py:139)
+        const int dims[3] = {a.H, a.W, a.D};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int c = (int)((a.means[3 * (size_t)g + k] - a.pc_min[k]) / a.grid_size);
+            a.means_int[3 * (size_t)g + k] = c;
+            if (c < 0 || c >= dims[k]) bad |= GF_PREPARE_MEAN_OUT_OF_GRID;
+        }
+    }
+    if (a.radii) {
+        if (a.radii_mode == GF_RADII_PER_AXIS) {
+            // ceil(scales * m / grid).clamp(min)   (local_aggregate_prob_fast/__init__.py:168-169)
+            const float s[3] = {sx, sy, sz};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int r = (int)ceilf(s[k] * a.scale_multiplier / a.grid_size);
+                r = max(r, a.radii_min);
+                a.radii[3 * (size_t)g + k] = r;
+                if (r < 1) bad |= GF_PREPARE_RADIUS_BELOW_ONE;
+            }
+        } else {
+            // ceil(scales.max(-1) * m / grid)   (local_aggregate/__init__.py:141; _prob :152-153 clamps)
+            int r = (int)ceilf(fmaxf(fmaxf(sx, sy), sz) * a.scale_multiplier / a.grid_size);
+            if (a.radii_mode == GF_RADII_SCALAR_CLAMPED) r = max(r, a.radii_min);
+            a.radii[g] = r;
+            if (r < 1) bad |= GF_PREPARE_RADIUS_BELOW_ONE;
+        }
+    }
+    if (bad && a.status) atomicOr(a.status, bad);
+}
+
+// d(Sigma^-1)/d(scales, quaternion).  With r_k = row k of R and A = sum_k s_k^-2 r_k r_k^T:
+//   dL/ds_k = -2 s_k^-3 r_k^T G r_k,   dL/dr_k = s_k^-2 (G + G^T) r_k,
+// then through R(q^) and q^ = q/||q||.  Same function of (scales, rotations) as the reference's
+// autograd graph through torch.inverse (gaussian_head.py:111-119), hence the same gradient.
+__global__ __launch_bounds__(256) void gf_gaussian_prepare_bwd_kernel(PrepareArgs a)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.P) return;
+    float G[3][3];
+    if (a.grad_is_full) {
+        const float *c = a.cov_grad + 9 * (size_t)g;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) G[i][j] = c[3 * i + j];
+    } else {
+        // the packed entries are elements (0,0),(1,1),(2,2),(0,1),(1,2),(0,2) of the 3x3
+        const float *c = a.cov_grad + 6 * (size_t)g;
+        G[0][0] = c[0]; G[1][1] = c[1]; G[2][2] = c[2]; G[0][1] = c[3]; G[1][2] = c[4]; G[0][2] = c[5];
+        G[1][0] = 0.f; G[2][1] = 0.f; G[2][0] = 0.f;
+    }
+    const Quat q = load_unit_quat(a.rotations + 4 * (size_t)g);
+    float R[3][3];
+    rotation_of(q, R);
+    const float s[3] = {a.scales[3 * (size_t)g], a.scales[3 * (size_t)g + 1], a.scales[3 * (size_t)g + 2]};
+    float Dm[3][3];  // dL/dR
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float is2 = 1.f / (s[k] * s[k]);
+        float Gs[3];  // (G + G^T) r_k
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            Gs[i] = (G[i][0] + G[0][i]) * R[k][0] + (G[i][1] + G[1][i]) * R[k][1] + (G[i][2] + G[2][i]) * R[k][2];
+        const float rGr = 0.5f * (R[k][0] * Gs[0] + R[k][1] * Gs[1] + R[k][2] * Gs[2]);
+        a.scales_grad[3 * (size_t)g + k] = -2.f * rGr * is2 / s[k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Dm[k][i] = is2 * Gs[i];
+    }
+    const float w = q.w, x = q.x, y = q.y, z = q.z;
+    const float gw = 2.f * (w * Dm[0][0] - z * Dm[0][1] + y * Dm[0][2] + z * Dm[1][0] + w * Dm[1][1] - x * Dm[1][2] - y * Dm[2][0] + x * Dm[2][1] + w * Dm[2][2]);
+    const float gx = 2.f * (x * Dm[0][0] + y * Dm[0][1] + z * Dm[0][2] + y * Dm[1][0] - x * Dm[1][1] - w * Dm[1][2] + z * Dm[2][0] + w * Dm[2][1] - x * Dm[2][2]);
+    const float gy = 2.f * (-y * Dm[0][0] + x * Dm[0][1] + w * Dm[0][2] + x * Dm[1][0] + y * Dm[1][1] + z * Dm[1][2] - w * Dm[2][0] + z * Dm[2][1] - y * Dm[2][2]);
+    const float gz = 2.f * (-z * Dm[0][0] - w * Dm[0][1] + x * Dm[0][2] + w * Dm[1][0] - z * Dm[1][1] + y * Dm[1][2] + x * Dm[2][0] + y * Dm[2][1] + z * Dm[2][2]);
+    // through q^ = q / ||q||: (I - q^ q^T) / ||q||
+    const float dot = gw * w + gx * x + gy * y + gz * z;
+    float4 out;
+    out.x = (gw - w * dot) * q.inv_norm; out.y = (gx - x * dot) * q.inv_norm;
+    out.z = (gy - y * dot) * q.inv_norm; out.w = (gz - z * dot) * q.inv_norm;
+    *reinterpret_cast<float4 *>(a.rot_grad + 4 * (size_t)g) = out;
+}
+
+}  // namespace gf
+
+extern "C" int gf_gaussian_prepare(int P, int H, int W, int D, const float *pc_min, float grid_size,
+                                   float scale_multiplier, int radii_mode, int radii_min,
+                                   const float *means3D, const float *scales, const float *rotations,
+                                   int *means3D_int, int *radii, float *cov6, float *cov9, int *status,
+                                   void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    GF_CHECK_ARG(P >= 0 && H > 0 && W > 0 && D > 0, "bad sizes");
+    GF_CHECK_ARG(radii_mode == GF_RADII_SCALAR || radii_mode == GF_RADII_SCALAR_CLAMPED || radii_mode == GF_RADII_PER_AXIS,
+                 "unknown radii mode");
+    GF_CHECK_ARG(grid_size > 0.f, "grid_size must be positive");
+    if (P == 0) return GF_OK;
+    GF_CHECK_ARG(pc_min && scales, "null pointer");
+    GF_CHECK_ARG(!means3D_int || means3D, "means3D_int requested without means3D");
+    GF_CHECK_ARG((!cov6 && !cov9) || rotations, "Sigma^-1 requested without rotations");
+    GF_CHECK_ARG(((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
+    PrepareArgs a{};
+    a.means = means3D; a.scales = scales; a.rotations = rotations; a.means_int = means3D_int; a.radii = radii;
+    a.cov6 = cov6; a.cov9 = cov9; a.status = status;
+    a.pc_min[0] = pc_min[0]; a.pc_min[1] = pc_min[1]; a.pc_min[2] = pc_min[2];
+    a.grid_size = grid_size; a.scale_multiplier = scale_multiplier;
+    a.P = P; a.H = H; a.W = W; a.D = D; a.radii_mode = radii_mode; a.radii_min = radii_min;
+    hipLaunchKernelGGL(gf_gaussian_prepare_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" int gf_gaussian_prepare_backward(int P, int grad_is_full, const float *scales, const float *rotations,
+                                            const float *cov_grad, float *scales_grad, float *rotations_grad,
+                                            void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    GF_CHECK_ARG(P >= 0, "bad sizes");
+    if (P == 0) return GF_OK;
+    GF_CHECK_ARG(scales && rotations && cov_grad && scales_grad && rotations_grad, "null pointer");
+    GF_CHECK_ARG((((uintptr_t)rotations | (uintptr_t)rotations_grad) & 15) == 0, "rotations must be 16-byte aligned");
+    PrepareArgs a{};
+    a.scales = scales; a.rotations = rotations; a.cov_grad = cov_grad; a.scales_grad = scales_grad;
+    a.rot_grad = rotations_grad; a.P = P; a.grad_is_full = grad_is_full;
+    hipLaunchKernelGGL(gf_gaussian_prepare_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

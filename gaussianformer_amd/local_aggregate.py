@@ -240,6 +240,30 @@ class _AggregatorBase(nn.Module):
                 and means3D_int[:, 1].max() < self.W and means3D_int[:, 2].max() < self.D
         return pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D
 
+    _radii_mode = _lib.GF_RADII_SCALAR
+
+    def forward_from_rotations(self, pts, means3D, opacities, semantics, scales, rotations):
+        """Fused entry: takes the Gaussians' ``rotations [1,g,4]`` instead of
+        ``CovInv`` and computes Sigma^-1, ``means3D_int`` and ``radii`` in one kernel
+        (``gf_gaussian_prepare``) -- no 3x3 tensors, no host inverse (gaussian_head.py:111-119),
+        no per-call syncs.  Returns what ``forward`` returns; gradients reach ``scales`` and
+        ``rotations`` through Sigma^-1 exactly as in the reference graph."""
+        from .gaussian_prepare import _GaussianPrepare
+        assert pts.shape[0] == 1
+        pts = pts.squeeze(0)
+        assert not pts.requires_grad
+        means3D, opacities, semantics = means3D.squeeze(0), opacities.squeeze(0), semantics.squeeze(0)
+        status = None
+        if self.check_inputs:
+            status = torch.zeros(1, dtype=torch.int32, device=pts.device)
+        means3D_int, radii, cov6 = _GaussianPrepare.apply(
+            means3D, scales.squeeze(0), rotations.squeeze(0), self._pc_min_host, self.grid_size,
+            self.scale_multiplier, self.H, self.W, self.D, self._radii_mode, getattr(self, "radii_min", 1), status)
+        points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
+        if self.check_inputs:
+            assert int(status.item()) == 0, f"gaussian_prepare status {int(status.item())} (GF_PREPARE_* bits)"
+        return self._splat(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov6)
+
 
 class LocalAggregator(_AggregatorBase):
     """Drop-in for ``local_aggregate.LocalAggregator``
@@ -255,6 +279,10 @@ class LocalAggregator(_AggregatorBase):
         self.grid_size = grid_size
         self.inv_softmax = inv_softmax
         self.check_inputs = check_inputs
+        self._pc_min_host = [float(v) for v in pc_min]
+
+    def _splat(self, *args):
+        return _LocalAggregate.apply(*args, self.H, self.W, self.D)
 
     def forward(self, pts, means3D, opacities, semantics, scales, cov3D):
         pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D = self._prepare(
@@ -287,6 +315,14 @@ class LocalAggregatorProb(_AggregatorBase):
         self.grid_size = grid_size
         self.radii_min = radii_min
         self.check_inputs = check_inputs
+        self._pc_min_host = [float(v) for v in pc_min]
+
+    @property
+    def _radii_mode(self):
+        return _lib.GF_RADII_PER_AXIS if self.per_axis_radii else _lib.GF_RADII_SCALAR_CLAMPED
+
+    def _splat(self, *args):
+        return _LocalAggregateProb.apply(*args, self.H, self.W, self.D)
 
     def forward(self, pts, means3D, opas, semantics, scales, cov3D):
         pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D = self._prepare(

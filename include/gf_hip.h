@@ -115,6 +115,44 @@ int gf_splat_box_volumes(int radii_per_axis, int P, int H, int W, int D,
                          const int *means3D_int, const int *radii, uint32_t *tiles_touched,
                          unsigned long long *num_rendered, void *stream);
 
+/* radii_mode of gf_gaussian_prepare */
+#define GF_RADII_SCALAR 0          /* local_aggregate:       ceil(max(scales) m / grid)              */
+#define GF_RADII_SCALAR_CLAMPED 1  /* local_aggregate_prob:  ... .clamp(min=radii_min)               */
+#define GF_RADII_PER_AXIS 2        /* local_aggregate_prob_fast: ceil(scales m / grid).clamp(min), [P,3] */
+/* bits OR-ed into *status (the reference's host-side asserts, evaluated on the device) */
+#define GF_PREPARE_MEAN_OUT_OF_GRID 1  /* means3D_int outside [0,H)x[0,W)x[0,D) */
+#define GF_PREPARE_RADIUS_BELOW_ONE 2  /* radii.min() < 1 */
+
+/*
+ * Fused per-Gaussian pre-processing for the splat, no host synchronisation.
+ * Replaces  GaussianHead.prepare_gaussian_args   model/head/gaussian_head.py:108-120
+ *             (S, R = get_rotation_matrix(q) model/utils/utils.py:20-69, Cov = (SR)^T(SR),
+ *              CovInv = Cov.cpu().inverse().cuda())
+ *           LocalAggregator.forward integer path  model/head/localagg/local_aggregate/__init__.py:139-143
+ *             (means3D_int, radii, the [0,4,8,1,5,2] packing and the .min()/.max() asserts)
+ *   means3D f32 [P,3]   scales f32 [P,3]   rotations f32 [P,4] (w,x,y,z; normalised inside)
+ *   pc_min: 3 floats on the HOST.  Any output pointer may be NULL to skip it:
+ *   means3D_int i32 [P,3]   radii i32 [P] ([P,3] for GF_RADII_PER_AXIS)
+ *   cov6 f32 [P,6] = Sigma^-1 as (xx,yy,zz,xy,yz,xz)   cov9 f32 [P,9] = full Sigma^-1
+ *   status i32 [1] (device, caller-zeroed): GF_PREPARE_* bits, checked by the caller when it wants to
+ * Sigma^-1 = R^T S^-2 R in closed form; differs from the reference's fp32 LAPACK inverse by
+ * O(cond(Sigma) * 2^-24) relative.
+ */
+int gf_gaussian_prepare(int P, int H, int W, int D, const float *pc_min, float grid_size,
+                        float scale_multiplier, int radii_mode, int radii_min,
+                        const float *means3D, const float *scales, const float *rotations,
+                        int *means3D_int, int *radii, float *cov6, float *cov9, int *status,
+                        void *stream);
+
+/*
+ * Gradient of Sigma^-1 with respect to scales [P,3] and (un-normalised) rotations [P,4]: what
+ * autograd computes through gaussian_head.py:108-119.  cov_grad is [P,6] (gradient of the packed
+ * entries, as gf_splat_backward's cov3D_grad) or, with grad_is_full, an arbitrary [P,9].
+ */
+int gf_gaussian_prepare_backward(int P, int grad_is_full, const float *scales, const float *rotations,
+                                 const float *cov_grad, float *scales_grad, float *rotations_grad,
+                                 void *stream);
+
 /*
  * Multi-camera multi-level deformable aggregation, forward.
  * Replaces  deformable_aggregation_forward  model/encoder/gaussian_encoder/ops/src/deformable_aggregation.cpp:41-71

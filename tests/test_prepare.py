@@ -1,0 +1,195 @@
+"""Fused Gaussian pre-processing: oracle vs the reference-generated golden
+fixture on the CPU, HIP kernels vs the oracle on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prepare_ref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "prepare.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD))
+
+
+# ------------------------------------------------------------------ CPU: pin the oracle
+def test_oracle_rotation_matches_reference_fixture(gold):
+    R = prepare_ref.rotation_matrix(torch.from_numpy(gold["rotations"]))
+    assert np.allclose(R.numpy(), gold["R"], rtol=0, atol=2e-7)
+    # proper rotations
+    RtR = torch.matmul(R.transpose(-1, -2), R)
+    assert torch.allclose(RtR, torch.eye(3).expand_as(RtR), atol=1e-5)
+
+
+def test_oracle_covinv_matches_reference_fixture(gold):
+    A = prepare_ref.covariance_inverse(torch.from_numpy(gold["scales"]), torch.from_numpy(gold["rotations"])).numpy()
+    ref = gold["CovInv"]
+    scale = np.abs(ref).max(axis=(-1, -2), keepdims=True)
+    cond = (gold["scales"].max(-1) / gold["scales"].min(-1)) ** 2
+    assert (np.abs(A - ref) / scale).max() <= 1e-6 * cond.max()
+    assert np.array_equal(prepare_ref.pack6(torch.from_numpy(ref))[0].numpy(), gold["cov6"])
+
+
+def test_closed_form_equals_inverse_fp64(gold):
+    """The kernel's closed form R^T S^-2 R is the inverse the reference computes."""
+    s = torch.from_numpy(gold["scales"]).double()
+    q = torch.from_numpy(gold["rotations"]).double()
+    A = prepare_ref.covariance_inverse(s, q)
+    R = prepare_ref.rotation_matrix(q)
+    closed = torch.einsum("...ki,...k,...kj->...ij", R, 1.0 / s ** 2, R)
+    assert torch.allclose(A, closed, rtol=1e-9, atol=1e-9)
+
+
+def test_fixture_integer_path_matches_numpy_restatement(gold):
+    import oracle
+    pts = np.zeros((1, 3), np.float32) + gold["pc_min"]
+    _, mi, radii, _ = oracle.prepare_splat_inputs(pts, gold["means"][0], gold["scales"][0], gold["CovInv"][0],
+                                                  gold["pc_min"][0].tolist(), float(gold["grid_size"]),
+                                                  float(gold["scale_multiplier"]))
+    assert np.array_equal(mi, gold["means3D_int"]) and np.array_equal(radii, gold["radii"])
+
+
+# ------------------------------------------------------------------ GPU: kernels vs oracle
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _dev(gold, dev, *names):
+    return [torch.from_numpy(gold[n][0] if gold[n].ndim == 3 else gold[n]).to(dev) for n in names]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("full", [False, True])
+def test_prepare_forward(gpu, gold, full):
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.gaussian_prepare import gaussian_prepare
+    means, scales, rot = _dev(gold, gpu, "means", "scales", "rotations")
+    status = torch.zeros(1, dtype=torch.int32, device=gpu)
+    mi, radii, cov = gaussian_prepare(means, scales, rot, gold["pc_min"][0].tolist(), float(gold["grid_size"]),
+                                      float(gold["scale_multiplier"]), 200, 200, 16, full_cov=full, status=status)
+    assert np.array_equal(mi.cpu().numpy(), gold["means3D_int"])      # integer path: bit-exact
+    assert np.array_equal(radii.cpu().numpy(), gold["radii"])
+    assert int(status.item()) == 0
+    truth = prepare_ref.covariance_inverse(scales.double().cpu(), rot.double().cpu())
+    ref = (truth if full else prepare_ref.pack6(truth)).numpy()
+    got = cov.cpu().numpy().astype(np.float64)
+    scale = np.abs(truth.numpy()).max(axis=(-1, -2)).reshape(-1, *([1] * (ref.ndim - 1)))
+    assert (np.abs(got - ref) / scale).max() <= 4e-6          # closed form: a few fp32 ulps of the largest entry
+    # and against the reference's own fp32 LAPACK result, within its conditioning
+    lap = gold["CovInv"][0] if full else gold["cov6"]
+    cond = ((gold["scales"][0].max(-1) / gold["scales"][0].min(-1)) ** 2).reshape(scale.shape)
+    assert (np.abs(got - lap) / scale / cond).max() <= 1e-6
+    # per-axis / clamped radii of the prob variants
+    _, r_axis, _ = gaussian_prepare(means, scales, rot, gold["pc_min"][0].tolist(), float(gold["grid_size"]),
+                                    float(gold["scale_multiplier"]), 200, 200, 16, radii_mode=_lib.GF_RADII_PER_AXIS,
+                                    radii_min=1)
+    assert np.array_equal(r_axis.cpu().numpy(), gold["radii_axis"])
+    _, r_cl, _ = gaussian_prepare(means, scales, rot, gold["pc_min"][0].tolist(), float(gold["grid_size"]),
+                                  float(gold["scale_multiplier"]), 200, 200, 16,
+                                  radii_mode=_lib.GF_RADII_SCALAR_CLAMPED, radii_min=4)
+    assert np.array_equal(r_cl.cpu().numpy(), np.maximum(gold["radii"], 4))
+
+
+@pytest.mark.gpu
+def test_prepare_status_bits(gpu):
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.gaussian_prepare import gaussian_prepare
+    means = torch.tensor([[0.0, 0.0, 0.0], [41.0, 0.0, 0.0], [0.0, 0.0, -1.5]], device=gpu)
+    scales = torch.tensor([[0.3, 0.2, 0.1], [0.3, 0.2, 0.1], [0.3, 0.2, 0.1]], device=gpu)
+    rot = torch.tensor([[1.0, 0, 0, 0]] * 3, device=gpu)
+    st = torch.zeros(1, dtype=torch.int32, device=gpu)
+    gaussian_prepare(means[:1], scales[:1], rot[:1], [-40, -40, -1], 0.4, 3, 200, 200, 16, status=st)
+    assert int(st.item()) == 0
+    gaussian_prepare(means, scales, rot, [-40, -40, -1], 0.4, 3, 200, 200, 16, status=st)
+    assert int(st.item()) == _lib.GF_PREPARE_MEAN_OUT_OF_GRID
+    st.zero_()
+    gaussian_prepare(means[:1], scales[:1] * 0.0, rot[:1], [-40, -40, -1], 0.4, 3, 200, 200, 16, status=st)
+    assert int(st.item()) & _lib.GF_PREPARE_RADIUS_BELOW_ONE
+    # empty input is a no-op
+    e = torch.empty(0, 3, device=gpu)
+    mi, r, c = gaussian_prepare(e, e, torch.empty(0, 4, device=gpu), [-40, -40, -1], 0.4, 3, 200, 200, 16)
+    assert mi.shape == (0, 3) and r.shape == (0,) and c.shape == (0, 6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed", [True, False])
+def test_prepare_backward_matches_autograd(gpu, gold, packed):
+    from gaussianformer_amd.gaussian_prepare import covariance_inverse
+    scales, rot = _dev(gold, gpu, "scales", "rotations")
+    s = scales.clone().requires_grad_(True)
+    q = rot.clone().requires_grad_(True)
+    cov = covariance_inverse(s, q, packed=packed)
+    g = torch.randn(cov.shape, generator=torch.Generator().manual_seed(5)).to(gpu)
+    cov.backward(g)
+    s64 = scales.double().cpu().requires_grad_(True)
+    q64 = rot.double().cpu().requires_grad_(True)
+    A = prepare_ref.covariance_inverse(s64, q64)
+    (prepare_ref.pack6(A) if packed else A).backward(g.double().cpu())
+    # fp32 rounding acts on the individual terms, which are as large as |G| / s_min^2 (and a
+    # further 1/s_min for the scale gradient) before they cancel
+    smin = scales.double().cpu().amin(dim=-1, keepdim=True)
+    bound = g.abs().max().item() / smin ** 2
+    for got, ref, extra in ((s.grad, s64.grad, 1.0 / smin), (q.grad, q64.grad, 1.0)):
+        got = got.double().cpu()
+        tol = 2e-5 * ref.abs().amax(dim=-1, keepdim=True) + 2e-6 * bound * extra
+        assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max()
+
+
+@pytest.mark.gpu
+def test_gaussian_args_module_and_fused_aggregator(gpu):
+    """GaussianArgs (= prepare_gaussian_args) feeding LocalAggregator.forward gives the same
+    logits and gradients as LocalAggregator.forward_from_rotations (the one-kernel route)."""
+    from gaussianformer_amd.gaussian_prepare import GaussianArgs
+    from gaussianformer_amd.local_aggregate import LocalAggregator
+    from gaussianformer_amd.synthetic import make_splat_inputs
+    H, W, D, P = 24, 20, 8, 300
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=3, P=P, H=H, W=W, D=D)
+    rng = np.random.default_rng(4)
+    pts = torch.from_numpy(si.pts).to(gpu)[None]
+    means = torch.from_numpy(si.means3D).to(gpu)[None]
+    scales = torch.from_numpy(si.scales).to(gpu)[None]
+    P = means.shape[1]
+    rot = torch.from_numpy(rng.standard_normal((1, P, 4)).astype(np.float32)).to(gpu)
+    sem = torch.from_numpy(np.abs(rng.standard_normal((1, P, 17))).astype(np.float32)).to(gpu)
+    opa = torch.from_numpy(rng.random((1, P, 1)).astype(np.float32)).to(gpu)
+    ext = np.array([H, W, D]) * si.grid_size
+    args = GaussianArgs(num_classes=18, with_empty=True, empty_label=17,
+                        empty_args=dict(mean=(np.array(si.pc_min) + ext / 2).tolist(), scale=(ext / 2).tolist())).to(gpu)
+    agg = LocalAggregator(si.scale_multiplier, H, W, D, si.pc_min, si.grid_size, check_inputs=True).to(gpu)
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_(True) for t in (means, scales, rot, sem, opa)]
+        m, s, q, se, o = leaves
+        m2, o2, se2, s2, cov = args(m, s, q, se, o)
+        if fused:
+            # the module's cats are reused; only the geometry goes through the fused kernel
+            q2 = torch.cat([q, args.empty_rot], dim=1)
+            out = agg.forward_from_rotations(pts, m2, o2.reshape(1, -1), se2, s2, q2)
+        else:
+            out = agg(pts, m2, o2.reshape(1, -1), se2, s2, cov)
+        out.backward(torch.ones_like(out) * 0.01)
+        return out.detach(), [t.grad for t in leaves]
+
+    out_a, grads_a = run(False)
+    out_b, grads_b = run(True)
+    assert out_a.shape == (H * W * D, 18)
+    assert torch.equal(out_a, out_b)
+    for ga, gb in zip(grads_a, grads_b):
+        assert torch.isfinite(ga).all()
+        # same inputs to the same backward kernels; Gaussians split across work items are
+        # summed with fp32 atomics, so allow summation-order noise
+        assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-5 * ga.abs().max().item())
+    # against the fp64 restatement of prepare_gaussian_args
+    A = prepare_ref.covariance_inverse(torch.cat([scales, args.empty_scale], 1).double().cpu(),
+                                       torch.cat([rot, args.empty_rot], 1).double().cpu())
+    _, _, _, _, cov = args(means, scales, rot, sem, opa)
+    assert cov.shape == (1, P + 1, 3, 3)
+    rel = (cov.double().cpu() - A).abs().amax(dim=(-1, -2)) / A.abs().amax(dim=(-1, -2))
+    assert rel.max() <= 4e-6

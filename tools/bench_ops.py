@@ -57,6 +57,14 @@ for config in ("nuscenes_gs25600_solid", "nuscenes_gs144000", "prob_gs6400"):
                                        bin_logits_grad=gb, density_grad=gb, state=state), iters=10)
     report("splat_backward", config, sec, 128 * P + 24 * N + 72 * N + 112 * P, {"P": P})
 
+from gaussianformer_amd.gaussian_prepare import gaussian_prepare  # noqa: E402
+for P in (25601, 144000):
+    m = torch.rand(P, 3, device=dev) * torch.tensor([79.9, 79.9, 6.3], device=dev) + torch.tensor([-40.0, -40.0, -1.0], device=dev)
+    sc = 0.08 + 0.5 * torch.rand(P, 3, device=dev)
+    q = torch.randn(P, 4, device=dev)
+    sec = timed(lambda: gaussian_prepare(m, sc, q, [-40.0, -40.0, -1.0], 0.4, 3, 200, 200, 16))
+    report("gaussian_prepare(module-level call)", f"P={P}", sec, 80 * P, {"P": P})
+
 DAF_CASES = () if "--splat-only" in sys.argv else ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000"))
 for pts, name in DAF_CASES:
     d = make_daf_inputs(num_pts=pts, seed=0)
