@@ -134,7 +134,8 @@ __device__ __forceinline__ float group_sum(float v, int width)
 
 // LPG = lanes per channel group, LPP = lanes per point (both powers of two <= 64 on the
 // fast path).  REDUCE = false falls back to the reference's per-lane atomics.
-template <int VEC, bool REDUCE>
+// FEAT = false leaves grad_mc_ms_feat to the pixel-major kernels below (gf_daf_backward_sorted).
+template <int VEC, bool REDUCE, bool FEAT = true>
 __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int lpp)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -183,10 +184,10 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
                 const float top = go[j] * wt;  // top_grad_mc_ms_feat, :84
                 // bilinear_sampling_grad :87-121
                 float grad_h_weight = 0.f, grad_w_weight = 0.f;
-                if (t.ok1) { grad_h_weight -= t.hw * v1[j]; grad_w_weight -= t.hh * v1[j]; unsafeAtomicAdd(a.grad_feat + o1 + j, t.w1 * top); }
-                if (t.ok2) { grad_h_weight -= t.lw * v2[j]; grad_w_weight += t.hh * v2[j]; unsafeAtomicAdd(a.grad_feat + o2 + j, t.w2 * top); }
-                if (t.ok3) { grad_h_weight += t.hw * v3[j]; grad_w_weight -= t.lh * v3[j]; unsafeAtomicAdd(a.grad_feat + o3 + j, t.w3 * top); }
-                if (t.ok4) { grad_h_weight += t.lw * v4[j]; grad_w_weight += t.lh * v4[j]; unsafeAtomicAdd(a.grad_feat + o4 + j, t.w4 * top); }
+                if (t.ok1) { grad_h_weight -= t.hw * v1[j]; grad_w_weight -= t.hh * v1[j]; if (FEAT) unsafeAtomicAdd(a.grad_feat + o1 + j, t.w1 * top); }
+                if (t.ok2) { grad_h_weight -= t.lw * v2[j]; grad_w_weight += t.hh * v2[j]; if (FEAT) unsafeAtomicAdd(a.grad_feat + o2 + j, t.w2 * top); }
+                if (t.ok3) { grad_h_weight += t.hw * v3[j]; grad_w_weight -= t.lh * v3[j]; if (FEAT) unsafeAtomicAdd(a.grad_feat + o3 + j, t.w3 * top); }
+                if (t.ok4) { grad_h_weight += t.lw * v4[j]; grad_w_weight += t.lh * v4[j]; if (FEAT) unsafeAtomicAdd(a.grad_feat + o4 + j, t.w4 * top); }
                 const float val = (t.w1 * v1[j] + t.w2 * v2[j] + t.w3 * v3[j] + t.w4 * v4[j]);
                 gw += go[j] * val;                      // :119
                 gw_part += w * grad_w_weight * top;     // :120
@@ -211,6 +212,314 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
             unsafeAtomicAdd(gl + 1, gl_h);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pixel-major grad_mc_ms_feat (gf_daf_backward_sorted).
+//
+// The reference (and gf_daf_backward) scatter one fp32 atomic per (point, camera, level,
+// corner, channel): 614 M atomics at the nuScenes shape, with >1000 points landing on each
+// pixel of the coarse levels -- same-address atomics serialise in L2 (18 ms measured).
+//
+// Here the feature pyramid of one batch element is cut into TILES of 8192/C consecutive pixel
+// rows (32 KB of fp32 gradients) and the bilinear taps are bucketed by tile:
+//   count : kDafBucketWgs workgroups histogram their share of the samples in LDS -> M[wg][tile]
+//   scan  : per-tile prefix over the workgroups, then over the tiles; work items = chunks of
+//           <= kDafChunk taps of one tile
+//   fill  : the same traversal writes 4-byte tap ids at LDS cursors seeded from the scan
+//   accumulate : one workgroup per work item keeps the tile's gradients in LDS, walks the taps
+//           (C/4 lanes per tap: one coalesced C*4-byte grad_output row each), adds with LDS
+//           atomics, and flushes the tile once (plain add, or global atomics for the few tiles
+//           that were split into several items).
+// Global atomics drop from 614 M scattered to a few 100 K coalesced ones; bucketing uses LDS
+// atomics only.
+constexpr int kDafTileFloats = 8192;   // 32 KB of fp32 per tile
+constexpr int kDafChunk = 2048;        // taps per work item
+constexpr int kDafBucketWgs = 256;     // workgroups of the count / fill passes
+constexpr int kDafMaxTiles = 8192;     // LDS histogram capacity (per batch element)
+
+struct DafSortArgs {
+    const int *spatial_shape;
+    const int *scale_start;
+    const float *loc;         // this batch element: [pts, cams, 2]
+    const float *weights;     // [pts, cams, L, G]
+    const float *grad_out;    // [pts, C]
+    float *grad_feat;         // [cams * num_feat, C]
+    uint32_t *header;         // [0] number of work items
+    uint32_t *M;              // [kDafBucketWgs][ntiles] taps of workgroup wg in tile t -> prefix within the tile
+    uint32_t *tile_start;     // [ntiles+1]
+    uint32_t *item_start;     // [ntiles+1]
+    uint32_t *item_tile;      // [max_items]
+    uint32_t *taps;           // [max_taps] ids: ((point << cam_bits | cam) << lvl_bits | level) << 2 | corner
+    int cams, num_feat, C, L, pts, G;
+    int cam_bits, lvl_bits, tile_rows, ntiles;
+    long long samples;        // pts * cams
+};
+
+// Visits the in-bounds taps of samples [s0, s1): f(tile, id).
+template <typename F>
+__device__ __forceinline__ void daf_for_each_tap(const DafSortArgs &a, long long s0, long long s1, F &&f)
+{
+    for (long long q = s0 + threadIdx.x; q < s1; q += blockDim.x) {
+        const float loc_w = a.loc[2 * q], loc_h = a.loc[2 * q + 1];
+        if (!(loc_w > 0 && loc_w < 1 && loc_h > 0 && loc_h < 1)) continue;  // deformable_aggregation_cuda.cu:166
+        const uint32_t pt = (uint32_t)(q / a.cams);
+        const uint32_t cam = (uint32_t)(q - (long long)pt * a.cams);
+        const uint32_t row_cam = cam * (uint32_t)a.num_feat;
+        const uint32_t id_base = (pt << a.cam_bits | cam) << a.lvl_bits;
+        for (int s = 0; s < a.L; ++s) {
+            const int h = a.spatial_shape[2 * s], w = a.spatial_shape[2 * s + 1];
+            const Taps t = make_taps(loc_h * h - 0.5f, loc_w * w - 0.5f, h, w);
+            const uint32_t r1 = row_cam + (uint32_t)a.scale_start[s] + (uint32_t)(t.h_low * w + t.w_low);
+            const uint32_t rows[4] = {r1, r1 + 1u, r1 + (uint32_t)w, r1 + (uint32_t)w + 1u};
+            const bool ok[4] = {t.ok1, t.ok2, t.ok3, t.ok4};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) f(rows[k] / (uint32_t)a.tile_rows, ((id_base | (uint32_t)s) << 2) | (uint32_t)k);
+        }
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(1024) void gf_daf_bucket_kernel(DafSortArgs a)
+{
+    __shared__ uint32_t s_bin[kDafMaxTiles];
+    const int wg = blockIdx.x;
+    uint32_t *row = a.M + (size_t)wg * a.ntiles;
+    for (int t = threadIdx.x; t < a.ntiles; t += blockDim.x) s_bin[t] = FILL ? a.tile_start[t] + row[t] : 0u;
+    __syncthreads();
+    const long long per = (a.samples + gridDim.x - 1) / gridDim.x;
+    const long long s0 = min(a.samples, (long long)wg * per), s1 = min(a.samples, s0 + per);
+    daf_for_each_tap(a, s0, s1, [&](uint32_t tile, uint32_t id) {
+        if (FILL) a.taps[atomicAdd(&s_bin[tile], 1u)] = id;
+        else atomicAdd(&s_bin[tile], 1u);
+    });
+    if (!FILL) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < a.ntiles; t += blockDim.x) row[t] = s_bin[t];
+    }
+}
+
+// One thread per tile: exclusive prefix of M[.][tile] over the workgroups; total -> tile_start[tile].
+__global__ __launch_bounds__(256) void gf_daf_colscan_kernel(DafSortArgs a)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.ntiles) return;
+    uint32_t run = 0;
+#pragma unroll 8
+    for (int wg = 0; wg < kDafBucketWgs; ++wg) {
+        const uint32_t c = a.M[(size_t)wg * a.ntiles + t];
+        a.M[(size_t)wg * a.ntiles + t] = run;
+        run += c;
+    }
+    a.tile_start[t] = run;  // per-tile total; turned into a prefix by gf_daf_tilescan_kernel
+}
+
+// Single workgroup: prefix over the tiles, work-item table.
+__global__ __launch_bounds__(1024) void gf_daf_tilescan_kernel(DafSortArgs a)
+{
+    __shared__ uint32_t s_t[1024], s_i[1024];
+    const int tid = threadIdx.x;
+    const int per = (a.ntiles + 1023) / 1024;
+    const int t0 = min(a.ntiles, tid * per), t1 = min(a.ntiles, t0 + per);
+    uint32_t st = 0, si = 0;
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t c = a.tile_start[t];
+        st += c;
+        si += (c + kDafChunk - 1) / kDafChunk;
+    }
+    s_t[tid] = st; s_i[tid] = si;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t ut = tid >= d ? s_t[tid - d] : 0u, ui = tid >= d ? s_i[tid - d] : 0u;
+        __syncthreads();
+        s_t[tid] += ut; s_i[tid] += ui;
+        __syncthreads();
+    }
+    uint32_t run_t = s_t[tid] - st, run_i = s_i[tid] - si;
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t c = a.tile_start[t];
+        const uint32_t ni = (c + kDafChunk - 1) / kDafChunk;
+        a.tile_start[t] = run_t;
+        a.item_start[t] = run_i;
+        for (uint32_t i = 0; i < ni; ++i) a.item_tile[run_i + i] = (uint32_t)t;
+        run_t += c;
+        run_i += ni;
+    }
+    if (tid == 1023) {
+        a.tile_start[a.ntiles] = s_t[1023];
+        a.item_start[a.ntiles] = s_i[1023];
+        a.header[0] = s_i[1023];
+    }
+}
+
+// One workgroup per work item (<= kDafChunk taps of one tile).  Phase 1 sorts the item's taps
+// by pixel row inside LDS (rank by LDS integer atomics, 128-entry scan); phase 2 gives every
+// row to one group of LPT lanes (4 channels per lane) which walks the row's taps -- one
+// coalesced C*4-byte grad_output row per tap, UNR taps in flight -- and accumulates in
+// registers: no floating-point atomics in LDS, one store per (row, item).
+constexpr int kDafMaxTileRows = 128;  // 8192 / 64 channels
+
+template <int LPT>
+__global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
+{
+    constexpr int NG = 256 / LPT;            // lane groups per workgroup
+    constexpr int PER = kDafChunk / 256;     // taps per thread in phase 1
+    constexpr int UNR = 4;
+    __shared__ uint32_t s_id[kDafChunk];
+    __shared__ float s_cw[kDafChunk];
+    __shared__ uint32_t s_cnt[kDafMaxTileRows + 1];
+    const int tid = threadIdx.x;
+    const int gi = tid / LPT, cl = tid - gi * LPT;
+    const int c0 = 4 * cl;
+    const int group = c0 / (a.C / a.G);
+    const uint32_t lvl_mask = (1u << a.lvl_bits) - 1u, cam_mask = (1u << a.cam_bits) - 1u;
+    const uint32_t nitems = a.header[0];
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const uint32_t tile = a.item_tile[item];
+        const uint32_t chunk = item - a.item_start[tile];
+        const uint32_t seg0 = a.tile_start[tile], seg1 = a.tile_start[tile + 1];
+        const uint32_t t0 = seg0 + chunk * kDafChunk, t1 = min(seg1, t0 + kDafChunk);
+        const uint32_t row_base = tile * (uint32_t)a.tile_rows;
+        if (tid <= kDafMaxTileRows) s_cnt[tid] = 0u;
+        __syncthreads();
+        // ---- phase 1: bilinear coefficient, local row and rank-within-row of every tap
+        uint32_t id[PER], rank[PER];
+        int lrow[PER];
+        float cw[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t ti = t0 + tid + 256 * j;
+            lrow[j] = -1;
+            if (ti < t1) id[j] = a.taps[ti];
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t ti = t0 + tid + 256 * j;
+            if (ti >= t1) continue;
+            const int k = id[j] & 3u;
+            const uint32_t q = id[j] >> 2;                  // (point, cam, level)
+            const int s = (int)(q & lvl_mask);
+            const uint32_t pc = q >> a.lvl_bits;            // (point, cam)
+            const uint32_t cam = pc & cam_mask, pt = pc >> a.cam_bits;
+            const size_t sample = (size_t)pt * a.cams + cam;
+            const float loc_w = a.loc[2 * sample], loc_h = a.loc[2 * sample + 1];
+            const int h = a.spatial_shape[2 * s], w = a.spatial_shape[2 * s + 1];
+            const float h_im = loc_h * h - 0.5f, w_im = loc_w * w - 0.5f;
+            const float fh = floorf(h_im), fw = floorf(w_im);
+            const float lh = h_im - fh, lw = w_im - fw, hh = 1 - lh, hw = 1 - lw;
+            cw[j] = k == 0 ? hh * hw : k == 1 ? hh * lw : k == 2 ? lh * hw : lh * lw;
+            const uint32_t row = cam * (uint32_t)a.num_feat + (uint32_t)a.scale_start[s] +
+                                 (uint32_t)(((int)fh + (k >> 1)) * w + (int)fw + (k & 1));
+            lrow[j] = (int)(row - row_base);
+            rank[j] = atomicAdd(&s_cnt[lrow[j]], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan of the <= 128 row counts: two per lane
+            const uint32_t c0r = s_cnt[2 * tid], c1r = s_cnt[2 * tid + 1];
+            uint32_t incl = c0r + c1r;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (tid >= d) incl += up;
+            }
+            const uint32_t excl = incl - (c0r + c1r);
+            s_cnt[2 * tid] = excl;
+            s_cnt[2 * tid + 1] = excl + c0r;
+            if (tid == 63) s_cnt[kDafMaxTileRows] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (lrow[j] < 0) continue;
+            const uint32_t pos = s_cnt[lrow[j]] + rank[j];
+            s_id[pos] = id[j];
+            s_cw[pos] = cw[j];
+        }
+        __syncthreads();
+        // ---- phase 2: one lane group per row
+        const bool shared_tile = seg1 - seg0 > kDafChunk;  // several work items add to this tile
+        for (int r = gi; r < a.tile_rows; r += NG) {
+            const uint32_t p0 = s_cnt[r], p1 = s_cnt[r + 1];
+            if (p0 == p1) continue;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t pb = p0; pb < p1; pb += UNR) {
+                float4 go[UNR];
+                float wt[UNR], c[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    go[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    wt[u] = 0.f; c[u] = 0.f;
+                    if (pb + u < p1) {
+                        const uint32_t q = s_id[pb + u] >> 2;
+                        const int s = (int)(q & lvl_mask);
+                        const uint32_t pc = q >> a.lvl_bits;
+                        const uint32_t cam = pc & cam_mask, pt = pc >> a.cam_bits;
+                        c[u] = s_cw[pb + u];
+                        wt[u] = a.weights[(((size_t)pt * a.cams + cam) * a.L + s) * a.G + group];
+                        go[u] = *reinterpret_cast<const float4 *>(a.grad_out + (size_t)pt * a.C + c0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    // top_grad = grad_output * weight (:84), then the bilinear coefficient (:92-110)
+                    acc.x += c[u] * (go[u].x * wt[u]); acc.y += c[u] * (go[u].y * wt[u]);
+                    acc.z += c[u] * (go[u].z * wt[u]); acc.w += c[u] * (go[u].w * wt[u]);
+                }
+            }
+            float *dst = a.grad_feat + ((size_t)row_base + r) * a.C + c0;
+            if (!shared_tile) {
+                float4 cur = *reinterpret_cast<float4 *>(dst);
+                cur.x += acc.x; cur.y += acc.y; cur.z += acc.z; cur.w += acc.w;
+                *reinterpret_cast<float4 *>(dst) = cur;
+            } else {
+                unsafeAtomicAdd(dst, acc.x); unsafeAtomicAdd(dst + 1, acc.y);
+                unsafeAtomicAdd(dst + 2, acc.z); unsafeAtomicAdd(dst + 3, acc.w);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int bits_for(int n)
+{
+    int b = 0;
+    while ((1 << b) < n) ++b;
+    return b;
+}
+
+struct DafSortPlan {
+    bool eligible;
+    int cam_bits, lvl_bits, tile_rows, ntiles;
+    unsigned long long max_taps, max_items;
+    size_t off_M, off_tile_start, off_item_start, off_item_tile, off_taps, bytes;
+};
+
+// plan for ONE batch element (the entry point loops over the batch and reuses the workspace)
+static DafSortPlan daf_sort_plan(int cams, int num_feat, int C, int L, int pts, int G)
+{
+    DafSortPlan p{};
+    const int lpt = C / 4;
+    const unsigned long long rows = (unsigned long long)cams * num_feat;
+    p.cam_bits = bits_for(cams);
+    p.lvl_bits = bits_for(L);
+    p.max_taps = (unsigned long long)pts * cams * L * 4ull;
+    const int id_bits = 2 + p.lvl_bits + p.cam_bits;
+    p.tile_rows = C > 0 && C <= kDafTileFloats ? kDafTileFloats / C : 1;
+    const unsigned long long ntiles = (rows + p.tile_rows - 1) / p.tile_rows;
+    p.eligible = C % 4 == 0 && (lpt == 16 || lpt == 32 || lpt == 64) && (C / G) % 4 == 0 && ntiles <= (unsigned)kDafMaxTiles &&
+                 p.max_taps < (1ull << 32) && ((unsigned long long)pts << id_bits) <= (1ull << 32);
+    p.ntiles = (int)ntiles;
+    p.max_items = p.max_taps / kDafChunk + ntiles + 1;
+    size_t off = 256;  // header
+    auto take = [&](size_t n) { const size_t o = off; off += (n + 255) & ~(size_t)255; return o; };
+    p.off_M = take((size_t)kDafBucketWgs * ntiles * 4);
+    p.off_tile_start = take((ntiles + 1) * 4);
+    p.off_item_start = take((ntiles + 1) * 4);
+    p.off_item_tile = take(p.max_items * 4);
+    p.off_taps = take(p.max_taps * 4);
+    p.bytes = off;
+    return p;
 }
 
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -291,5 +600,73 @@ extern "C" int gf_daf_backward(int B, int num_cams, int num_feat, int C, int L, 
         else hipLaunchKernelGGL((gf_daf_bwd_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, 1, 1);
     }
     GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" size_t gf_daf_backward_workspace_bytes(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G)
+{
+    using namespace gf;
+    if (B < 0 || num_cams <= 0 || num_feat <= 0 || C <= 0 || L <= 0 || num_pts < 0 || G <= 0 || C % G) return 0;
+    const DafSortPlan p = daf_sort_plan(num_cams, num_feat, C, L, num_pts, G);
+    return p.eligible ? p.bytes : 0;
+}
+
+extern "C" int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,
+                                      const float *mc_ms_feat, const int *spatial_shape,
+                                      const int *scale_start_index, const float *sampling_location,
+                                      const float *weights, const float *grad_output, float *grad_mc_ms_feat,
+                                      float *grad_sampling_location, float *grad_weights, void *workspace,
+                                      size_t workspace_bytes, void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = daf_check(B, num_cams, num_feat, C, L, num_pts, G)) return rc;
+    if ((long long)B * num_pts == 0) return GF_OK;
+    GF_CHECK_ARG(mc_ms_feat && spatial_shape && scale_start_index && sampling_location && weights && grad_output &&
+                     grad_mc_ms_feat && grad_sampling_location && grad_weights, "null pointer");
+    const DafSortPlan p = daf_sort_plan(num_cams, num_feat, C, L, num_pts, G);
+    GF_CHECK_ARG(p.eligible, "shape not supported by the pixel-major backward (gf_daf_backward_workspace_bytes == 0): use gf_daf_backward");
+    GF_CHECK_ARG(workspace && workspace_bytes >= p.bytes, "workspace too small (gf_daf_backward_workspace_bytes)");
+    GF_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+
+    // (1) grad_weights / grad_sampling_location: point-major, reduced in-wave, no atomics
+    DafArgs a{};
+    a.feat = mc_ms_feat; a.spatial_shape = spatial_shape; a.scale_start = scale_start_index; a.loc = sampling_location;
+    a.weights = weights; a.grad_out = grad_output; a.grad_feat = grad_mc_ms_feat; a.grad_loc = grad_sampling_location;
+    a.grad_weights = grad_weights; a.B = B; a.cams = num_cams; a.num_feat = num_feat; a.C = C; a.L = L;
+    a.pts = num_pts; a.G = G;
+    a.total = (long long)B * num_pts * (C / 4);
+    const long long blocks = (a.total + 255) / 256;
+    GF_CHECK_ARG(blocks < (1ll << 31), "problem too large");
+    const int lpp = C / 4, lpg = (C / G) / 4;
+    if (is_pow2(lpg)) hipLaunchKernelGGL((gf_daf_bwd_kernel<4, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, lpg, lpp);
+    else hipLaunchKernelGGL((gf_daf_bwd_kernel<4, false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, 1, 1);
+    GF_CHECK_LAUNCH();
+
+    // (2) grad_mc_ms_feat, one batch element at a time: bucket the taps by tile, accumulate per tile in LDS
+    char *ws = (char *)workspace;
+    DafSortArgs sa{};
+    sa.spatial_shape = spatial_shape; sa.scale_start = scale_start_index;
+    sa.header = (uint32_t *)ws; sa.M = (uint32_t *)(ws + p.off_M); sa.tile_start = (uint32_t *)(ws + p.off_tile_start);
+    sa.item_start = (uint32_t *)(ws + p.off_item_start); sa.item_tile = (uint32_t *)(ws + p.off_item_tile);
+    sa.taps = (uint32_t *)(ws + p.off_taps);
+    sa.cams = num_cams; sa.num_feat = num_feat; sa.C = C; sa.L = L; sa.pts = num_pts; sa.G = G;
+    sa.cam_bits = p.cam_bits; sa.lvl_bits = p.lvl_bits; sa.tile_rows = p.tile_rows; sa.ntiles = p.ntiles;
+    sa.samples = (long long)num_pts * num_cams;
+    for (int b = 0; b < B; ++b) {
+        sa.loc = sampling_location + (size_t)b * num_pts * num_cams * 2;
+        sa.weights = weights + (size_t)b * num_pts * num_cams * L * G;
+        sa.grad_out = grad_output + (size_t)b * num_pts * C;
+        sa.grad_feat = grad_mc_ms_feat + (size_t)b * num_cams * num_feat * C;
+        hipLaunchKernelGGL(gf_daf_bucket_kernel<false>, dim3(kDafBucketWgs), dim3(1024), 0, stream, sa);
+        hipLaunchKernelGGL(gf_daf_colscan_kernel, dim3((p.ntiles + 255) / 256), dim3(256), 0, stream, sa);
+        hipLaunchKernelGGL(gf_daf_tilescan_kernel, dim3(1), dim3(1024), 0, stream, sa);
+        hipLaunchKernelGGL(gf_daf_bucket_kernel<true>, dim3(kDafBucketWgs), dim3(1024), 0, stream, sa);
+        const unsigned gblocks = 256 * 8;  // persistent, item-strided
+        if (lpp == 16) hipLaunchKernelGGL(gf_daf_accumulate_kernel<16>, dim3(gblocks), dim3(256), 0, stream, sa);
+        else if (lpp == 32) hipLaunchKernelGGL(gf_daf_accumulate_kernel<32>, dim3(gblocks), dim3(256), 0, stream, sa);
+        else hipLaunchKernelGGL(gf_daf_accumulate_kernel<64>, dim3(gblocks), dim3(256), 0, stream, sa);
+        GF_CHECK_LAUNCH();
+    }
     return GF_OK;
 }

@@ -26,15 +26,42 @@ def deformable_aggregation_forward(mc_ms_feat, spatial_shape, scale_start_index,
     return out
 
 
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only per-device scratch for the sorted backward (tap ids + counters)."""
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
 def deformable_aggregation_backward(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights,
-                                    grad_output, grad_mc_ms_feat, grad_sampling_location, grad_weights):
+                                    grad_output, grad_mc_ms_feat, grad_sampling_location, grad_weights,
+                                    pixel_major=True):
     """Counterpart of ``deformable_aggregation_ext.deformable_aggregation_backward``
     (ops/src/deformable_aggregation.cpp:73-110): accumulates in place into the three
-    caller-zeroed gradient tensors."""
+    caller-zeroed gradient tensors.  ``pixel_major`` selects ``gf_daf_backward_sorted`` (no
+    per-channel atomic scatter) whenever the shape supports it; ``False`` forces the
+    reference's scatter formulation (``gf_daf_backward``)."""
     lib = _lib.load()
     _lib.require_gpu(mc_ms_feat, grad_output, grad_mc_ms_feat, grad_sampling_location, grad_weights)
     B, cams, num_feat, C = mc_ms_feat.shape
     L, pts, G = spatial_shape.shape[0], sampling_location.shape[1], weights.shape[4]
+    nbytes = lib.gf_daf_backward_workspace_bytes(B, cams, num_feat, C, L, pts, G) if pixel_major else 0
+    if nbytes:
+        with torch.cuda.device(mc_ms_feat.device):
+            ws = _workspace(mc_ms_feat.device, nbytes)
+            rc = lib.gf_daf_backward_sorted(B, cams, num_feat, C, L, pts, G, _lib.ptr(mc_ms_feat),
+                                            _lib.ptr(spatial_shape), _lib.ptr(scale_start_index),
+                                            _lib.ptr(sampling_location), _lib.ptr(weights), _lib.ptr(grad_output),
+                                            _lib.ptr(grad_mc_ms_feat), _lib.ptr(grad_sampling_location),
+                                            _lib.ptr(grad_weights), _lib.ptr(ws), nbytes,
+                                            _lib.current_stream(mc_ms_feat.device))
+        _lib.check(rc, "gf_daf_backward_sorted")
+        return
     with torch.cuda.device(mc_ms_feat.device):
         rc = lib.gf_daf_backward(B, cams, num_feat, C, L, pts, G, _lib.ptr(mc_ms_feat), _lib.ptr(spatial_shape),
                                  _lib.ptr(scale_start_index), _lib.ptr(sampling_location), _lib.ptr(weights),

@@ -179,6 +179,25 @@ int gf_daf_backward(int B, int num_cams, int num_feat, int C, int L, int num_pts
                     float *grad_sampling_location, float *grad_weights, void *stream);
 
 /*
+ * Deformable aggregation backward, pixel-major gradient of the feature maps.  Same arguments,
+ * results and accumulate-into-zeroed-buffers contract as gf_daf_backward, plus a device
+ * workspace.  grad_weights / grad_sampling_location come from the same point-major kernel;
+ * grad_mc_ms_feat is produced without the reference's per-channel atomic scatter
+ * (deformable_aggregation_cuda.cu:92-110): taps are bucketed by destination pixel row with a
+ * counting sort and every row is gathered (summation order within a row is unspecified, as
+ * with the atomics).  gf_daf_backward_workspace_bytes returns 0 for shapes this path does not
+ * support (it needs C % 4 == 0, C/4 in {16,32,64}, (C/G) % 4 == 0 and 32-bit tap ids); use
+ * gf_daf_backward for those.
+ */
+size_t gf_daf_backward_workspace_bytes(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G);
+int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,
+                           const float *mc_ms_feat, const int *spatial_shape,
+                           const int *scale_start_index, const float *sampling_location,
+                           const float *weights, const float *grad_output, float *grad_mc_ms_feat,
+                           float *grad_sampling_location, float *grad_weights, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/*
  * Kernel-level timing for bench.py's roofline leg.  gf_profile_enable(n) pre-creates n
  * hipEvent pairs; while enabled, every gf_splat_forward call brackets its dominant kernel
  * (the dense render kernel) with hipEventRecord on the caller's stream (asynchronous, no

@@ -15,6 +15,9 @@ CASES = [
     dict(num_pts=300, B=2, cams=3, C=32, G=4, levels=((6, 9), (3, 5))),                        # 8 lanes per point
     dict(num_pts=200, B=1, cams=2, C=24, G=4, levels=((5, 4),)),                               # vec 2, non-pow2 lanes -> atomic fallback
     dict(num_pts=100, B=1, cams=2, C=12, G=4, levels=((5, 4), (3, 3))),                        # vec 1
+    dict(num_pts=500, B=2, cams=6, C=64, G=4, levels=((9, 16), (5, 8), (2, 3))),               # pixel-major, 16 lanes per tap
+    dict(num_pts=300, B=1, cams=3, C=256, G=8, levels=((6, 9), (3, 5))),                       # pixel-major, 64 lanes per tap
+    dict(num_pts=4000, B=1, cams=2, C=128, G=4, levels=((2, 2), (1, 1))),                      # thousands of taps per pixel row
 ]
 
 
@@ -65,6 +68,44 @@ def test_daf_full_feature_pyramid(gpu):
     o2 = DAF.apply(feat, ss, st, loc, w * 2)
     assert torch.equal(o2, o1 * 2)
     assert torch.isfinite(o1).all()
+
+
+def test_daf_backward_pixel_major_vs_scatter(gpu):
+    """gs25600-sized backward (230 400 sample points, nuScenes pyramid): the pixel-major path
+    (counting sort + gather) against the reference's atomic scatter formulation, and against
+    the oracle on a 20 000-point subset."""
+    import torch
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.deformable_aggregation import deformable_aggregation_backward as bwd
+    d = make_daf_inputs(num_pts=230400, seed=25)
+    feat, ss, st, loc, w = to_dev(gpu, d["mc_ms_feat"], d["spatial_shape"], d["scale_start_index"],
+                                  d["sampling_location"], d["weights"])
+    B, cams, num_feat, C = feat.shape
+    assert _lib.load().gf_daf_backward_workspace_bytes(B, cams, num_feat, C, ss.shape[0], loc.shape[1], w.shape[4]) > 0
+    go = torch.randn(1, 230400, 128, device=gpu, generator=torch.Generator(device=gpu).manual_seed(26))
+    res = []
+    for pixel_major in (True, False):
+        gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(loc), torch.zeros_like(w)
+        bwd(feat, ss, st, loc, w, go, gf, gl, gw, pixel_major=pixel_major)
+        res.append((gf, gl, gw))
+    (gf1, gl1, gw1), (gf0, gl0, gw0) = res
+    # same point-major kernel (two instantiations: fp contraction may differ in the last bit)
+    assert torch.allclose(gl1, gl0, rtol=1e-5, atol=1e-5 * gl0.abs().max().item())
+    assert torch.allclose(gw1, gw0, rtol=1e-5, atol=1e-5 * gw0.abs().max().item())
+    scale = gf0.abs().max().item()
+    assert (gf1 - gf0).abs().max().item() <= 2e-5 * scale          # fp32 summation order only
+    # accumulate-into semantics: a second call doubles the result
+    bwd(feat, ss, st, loc, w, go, gf1, gl1, gw1)
+    assert (gf1 - 2 * gf0).abs().max().item() <= 4e-5 * scale
+    # oracle on a subset
+    n = 20000
+    gfs, gls, gws = torch.zeros_like(feat), torch.zeros_like(loc[:, :n]), torch.zeros_like(w[:, :n])
+    bwd(feat, ss, st, loc[:, :n].contiguous(), w[:, :n].contiguous(), go[:, :n].contiguous(), gfs, gls, gws)
+    of, ol, ow = oracle.daf_backward(d["mc_ms_feat"], d["spatial_shape"], d["scale_start_index"],
+                                     d["sampling_location"][:, :n], d["weights"][:, :n], go[:, :n].cpu().numpy())
+    assert_grad_close(gfs.cpu().numpy(), of, "grad_mc_ms_feat")
+    assert_grad_close(gls.cpu().numpy(), ol, "grad_sampling_location")
+    assert_grad_close(gws.cpu().numpy(), ow, "grad_weights")
 
 
 def test_feature_maps_format_roundtrip(gpu):
