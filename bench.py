@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PROFILE_STRIDE = 8
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 
 
@@ -116,6 +117,9 @@ def main():
         step()
     torch.cuda.synchronize()
 
+    # the dominant kernel is timed with hipEvents on every PROFILE_STRIDE-th launch of the timed
+    # region (an event pair costs ~3 us of stream time; sampling keeps the region representative)
+    _lib.check(lib.gf_profile_stride(PROFILE_STRIDE), "gf_profile_stride")
     _lib.check(lib.gf_profile_enable(args.steps), "gf_profile_enable")
     if world > 1:
         dist.barrier()
@@ -137,6 +141,7 @@ def main():
     buf = (ctypes.c_float * args.steps)()
     n_ev = lib.gf_profile_read(buf, args.steps)
     lib.gf_profile_enable(0)
+    lib.gf_profile_stride(1)
     kernel_ms = float(np.mean(buf[:n_ev])) if n_ev > 0 else None
 
     if rank == 0:
@@ -149,6 +154,7 @@ def main():
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
                         "kernel": "gf_splat_render_kernel", "kernel_us": kernel_ms * 1e3,
+                        "kernel_launches_timed": n_ev,
                         "algorithmic_bytes": abytes}
         out = {
             "metric": "Gaussians/sec splatted into 200x200x16x18 voxel grid (fwd)",

@@ -36,6 +36,7 @@ SIGNATURES = {
     "gf_gaussian_prepare": (_i, [_i] * 4 + [_vp, _f, _f, _i, _i] + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare_backward": (_i, [_i] * 2 + [_vp] * 5 + [_vp]),
     "gf_profile_enable": (_i, [_i]),
+    "gf_profile_stride": (_i, [_i]),
     "gf_profile_read": (_i, [_vp, _i]),
 }
 

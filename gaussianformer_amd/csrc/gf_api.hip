@@ -19,8 +19,11 @@ void set_error(const char *fmt, ...)
 namespace gf {
 static std::vector<hipEvent_t> g_events;  // pairs: [2i] before, [2i+1] after
 static int g_used = 0;
+static int g_stride = 1, g_calls = 0;  // every g_stride-th launch is timed
 bool profile_slot(hipEvent_t *before, hipEvent_t *after)
 {
+    if (g_events.empty()) return false;
+    if (g_calls++ % g_stride != 0) return false;
     if ((size_t)(2 * g_used + 2) > g_events.size()) return false;
     *before = g_events[2 * g_used];
     *after = g_events[2 * g_used + 1];
@@ -34,6 +37,7 @@ extern "C" int gf_profile_enable(int max_records)
     for (hipEvent_t e : gf::g_events) (void)hipEventDestroy(e);
     gf::g_events.clear();
     gf::g_used = 0;
+    gf::g_calls = 0;
     for (int i = 0; i < 2 * max_records; ++i) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) {
@@ -42,6 +46,17 @@ extern "C" int gf_profile_enable(int max_records)
         }
         gf::g_events.push_back(e);
     }
+    return GF_OK;
+}
+
+extern "C" int gf_profile_stride(int every)
+{
+    if (every < 1) {
+        gf::set_error("gf_profile_stride: stride must be >= 1");
+        return GF_EINVAL;
+    }
+    gf::g_stride = every;
+    gf::g_calls = 0;
     return GF_OK;
 }
 

@@ -27,6 +27,8 @@
 //   3. gf_splat_render_general_kernel   arbitrary query points when N != H*W*D.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "gf_common.hpp"
 
 #ifndef GF_TIMELINE
@@ -73,7 +75,9 @@ __device__ __forceinline__ void gaussian_box(const int *__restrict__ means_int, 
 __global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
 {
     // One wave per workgroup.  Gaussian role: 64 Gaussians -> one bitmask word per supertile.
-    __shared__ unsigned long long s_bits[kPrepSuperChunk];
+    // LDS is sized at launch to min(#supertiles, kPrepSuperChunk) words: with the static 16 KB
+    // only 10 of the 4497 single-wave workgroups fit a CU and the grid needed two dispatch rounds.
+    extern __shared__ unsigned long long s_bits[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= a.nprep_blocks) {
         // ---- verification role: is point n in voxel n for all n?  Each wave reports its own
@@ -199,7 +203,7 @@ struct RenderArgs {
 };
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
-constexpr int kListCap = 1536;  // tile list entries (12 B each) held in LDS
+constexpr int kListCap = 4608;  // tile list entries (Gaussian ids, 4 B each) held in LDS
 constexpr int kRecUsed = 31;    // record dwords the render kernels read (0..30)
 constexpr int kBlock = 256;
 
@@ -452,12 +456,12 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
     // the chip -- so every tile is resident from the start (no second dispatch round), and
     // each scalar iteration over a Gaussian feeds two independent evaluation chains.
     //
-    // LDS: tile list {gaussian id, box lo, box hi} + scan scratch; the output staging area
+    // LDS: tile list of Gaussian ids + scan scratch; the output staging area
     // (4 waves x 64 rows x 18 floats, used twice) aliases the list once it has been consumed.
     constexpr int kStage = 4 * 64 * kC;
-    constexpr int kMem = kStage > 3 * kListCap ? kStage : 3 * kListCap;
+    constexpr int kMem = kStage > kListCap ? kStage : kListCap;
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kMem + 64];
-    uint32_t *s_lg = s_mem, *s_llo = s_mem + kListCap, *s_lhi = s_mem + 2 * kListCap;
+    uint32_t *s_lg = s_mem;
     uint32_t *s_scan = s_mem + kMem;  // [0..3] wave totals, [8..40) group bases (dense chunks)
 
     const int tid = threadIdx.x;
@@ -524,20 +528,15 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
         B.bin = 1.f; B.dens = 0.f; B.psum = 0.f;
         if (zg > 0) word_next = tid < a.nwords ? bm[tid] : 0ull;
 
-        // ---- produce / consume.  Producer: filter the supertile's bitmask against the tile
-        // footprint, one word per thread and kBlock words per chunk; the hits of a chunk are
-        // appended to the LDS list in ascending Gaussian order (popcount scan) as ONE group, or
+        // ---- produce / consume.  Producer: one bitmask word of the supertile per thread and
+        // kBlock words per chunk; the set bits of a chunk (every Gaussian whose box touches the
+        // supertile) are appended to the LDS list in ascending order (popcount scan) as ONE group, or
         // -- for a chunk denser than the list -- as 32 groups of 8 threads (<= 512 hits each).
         // Whenever the next group does not fit (or the input is exhausted) every wave consumes
         // the list.  All control state is block-uniform.
         int list_len = 0, w_next = 0, wi = 0, grp = 0, ngrp = 0, total = 0, off = 0;
         unsigned long long hits = 0ull;
-        uint2 box0 = make_uint2(0, 0);  // box of this thread's first hit (the common case: <= 1 hit)
         bool done = false;
-        auto tile_hit = [&](uint2 box) {
-            return ux(box.x) < X0 + kTileX && ux(box.y) > X0 && uy(box.x) < Y0 + kTileY && uy(box.y) > Y0 &&
-                   uz(box.x) < zg * 16 + 16 && uz(box.y) > zg * 16;
-        };
         while (!done) {
             while (true) {
                 if (grp < ngrp) {
@@ -551,18 +550,12 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
                     const int n = __builtin_amdgcn_readfirstlane(ge - gb);
                     if (n > 0) {
                         if (list_len + n > kListCap) break;  // consume first, then retry this group
-                        if (mine && hits) {
+                        if (mine) {
                             int pos = list_len + off - gb;
-                            const int j0 = __builtin_ctzll(hits);
-                            hits &= hits - 1;
-                            s_lg[pos] = (uint32_t)(wi * 64 + j0); s_llo[pos] = box0.x; s_lhi[pos] = box0.y;
-                            while (hits) {  // rare: several hits in one word -> re-read their boxes
+                            while (hits) {
                                 const int j = __builtin_ctzll(hits);
                                 hits &= hits - 1;
-                                const uint32_t g = (uint32_t)(wi * 64 + j);
-                                const uint2 box = a.boxes[g];
-                                ++pos;
-                                s_lg[pos] = g; s_llo[pos] = box.x; s_lhi[pos] = box.y;
+                                s_lg[pos++] = (uint32_t)(wi * 64 + j);
                             }
                         }
                         list_len += n;
@@ -578,24 +571,10 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
                 w_next += kBlock;
                 unsigned long long word = word_next;
                 word_next = (w_next + tid) < a.nwords ? bm[w_next + tid] : 0ull;  // prefetch next chunk
-                hits = 0ull;
-                while (word) {
-                    // two candidate boxes in flight per round trip
-                    const int j0 = __builtin_ctzll(word);
-                    word &= word - 1;
-                    const int j1 = word ? __builtin_ctzll(word) : -1;
-                    if (word) word &= word - 1;
-                    const uint2 b0 = a.boxes[wi * 64 + j0];
-                    const uint2 b1 = j1 >= 0 ? a.boxes[wi * 64 + j1] : make_uint2(0, 0);
-                    if (tile_hit(b0)) {
-                        if (!hits) box0 = b0;
-                        hits |= 1ull << j0;
-                    }
-                    if (j1 >= 0 && tile_hit(b1)) {
-                        if (!hits) box0 = b1;
-                        hits |= 1ull << j1;
-                    }
-                }
+                // every Gaussian whose box touches the supertile is listed; the per-wave brick
+                // masks (consume) drop the ones that miss this tile, so the producer needs no
+                // box loads and its only memory round trip is the bitmask word itself
+                hits = word;
                 const int cnt = __builtin_popcountll(hits);
                 const int incl = wave_inclusive_scan(cnt);
                 if (lane == 63) s_scan[wave] = (uint32_t)incl;
@@ -621,12 +600,23 @@ __global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderA
 #if GF_TIMELINE
             if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)blockIdx.x + 1] = wall_clock64();
 #endif
+            uint32_t eg_n = 0;
+            uint2 box_n = make_uint2(0, 0);
+            if (lane < list_len) {
+                eg_n = s_lg[lane];
+                box_n = a.boxes[eg_n];
+            }
             for (int base = 0; base < list_len; base += 64) {
                 const int i = base + lane;
-                uint32_t eg = 0, mAlo = 0, mAhi = 0, mBlo = 0, mBhi = 0;
+                const uint32_t eg = eg_n;
+                const uint2 box = box_n;
+                if (i + 64 < list_len) {  // next 64 entries' boxes: in flight during this batch
+                    eg_n = s_lg[i + 64];
+                    box_n = a.boxes[eg_n];
+                }
+                uint32_t mAlo = 0, mAhi = 0, mBlo = 0, mBhi = 0;
                 if (i < list_len) {
-                    eg = s_lg[i];
-                    const uint32_t blo = s_llo[i], bhi = s_lhi[i];
+                    const uint32_t blo = box.x, bhi = box.y;
                     const unsigned long long mxx = mask_x(clamp04(ux(blo) - Xw), clamp04(ux(bhi) - Xw));
                     const uint32_t my = mask_y32(clamp04(uy(blo) - Y0), clamp04(uy(bhi) - Y0));
                     const uint32_t mzA = my & mask_z32(clamp04(uz(blo) - Zw), clamp04(uz(bhi) - Zw));
@@ -843,7 +833,8 @@ extern "C" int gf_splat_forward(int variant, int radii_per_axis, int flags, int 
     pa.prescale = (flags & (GF_LIBM_EXP | GF_COMP_EXP)) ? 0 : 1;
     const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks : 0);
     if (prep_grid > 0) {
-        hipLaunchKernelGGL(gf_splat_prep_kernel, dim3(prep_grid), dim3(64), 0, stream, pa);
+        const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy, kPrepSuperChunk);
+        hipLaunchKernelGGL(gf_splat_prep_kernel, dim3(prep_grid), dim3(64), prep_lds, stream, pa);
         GF_CHECK_LAUNCH();
     }
     if (N == 0) return GF_OK;

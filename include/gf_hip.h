@@ -206,6 +206,9 @@ int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, int L, int 
  * gf_profile_enable(0) disables and frees.  Not part of the reference interface.
  */
 int gf_profile_enable(int max_records);
+/* Time only every `every`-th dominant-kernel launch (default 1): the two event records cost a few
+ * microseconds of stream time each, so sampling keeps the timed region close to the un-instrumented one. */
+int gf_profile_stride(int every);
 int gf_profile_read(float *ms_out, int capacity);
 
 #ifdef __cplusplus
