@@ -61,8 +61,11 @@ struct BwdArgs {
     float *cov_grad;
     const uint32_t *state;
     int *voxel2pts;
-    uint32_t *vols;   // [P]
-    uint32_t *bsum;   // [ceil(P/256)]
+    uint32_t *vols;   // [P] box volumes in sorted order
+    uint32_t *bsum;   // [ceil(P/256)] sums of 256 consecutive sorted volumes
+    uint32_t *vols_in;    // [P] box volumes in input order
+    int *order;           // [P] input index of the Gaussian at each sorted position
+    uint32_t *sort_hist;  // [kSortCells][nblk]
     int P, N, H, W, D, per_axis, force_general, assume_dense, nblk;
 };
 
@@ -135,47 +138,7 @@ __device__ __forceinline__ bool pts_are_dense(const BwdArgs &a)
 // voxel2pts = -1, then voxel2pts[voxel(n)] = n with the highest point index winning
 // (BACKWARD::preprocessCUDA, model/head/localagg/src/backward.cu:8-20, is a racy
 // last-writer-wins scatter; any winner is a legal outcome, we pick a deterministic one).
-__global__ __launch_bounds__(256) void gf_v2p_fill_kernel(BwdArgs a)
-{
-    if (pts_are_dense(a)) return;
-    const size_t V = (size_t)a.H * a.W * a.D;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) a.voxel2pts[i] = -1;
-}
-
-__global__ __launch_bounds__(256) void gf_v2p_scatter_kernel(BwdArgs a)
-{
-    if (pts_are_dense(a)) return;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= a.N) return;
-    const int x = a.points_int[3 * (size_t)n], y = a.points_int[3 * (size_t)n + 1], z = a.points_int[3 * (size_t)n + 2];
-    if (x < 0 || x >= a.H || y < 0 || y >= a.W || z < 0 || z >= a.D) return;
-    atomicMax(a.voxel2pts + ((size_t)x * a.W + y) * a.D + z, n);
-}
-
-// One thread per Gaussian: box volume, 256-Gaussian block sums, zeroed gradient outputs.
-__global__ __launch_bounds__(256) void gf_bwd_vol_kernel(BwdArgs a)
-{
-    __shared__ uint32_t s_w[4];
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    uint32_t vol = 0u;
-    if (g < a.P) {
-        int lo[3], hi[3];
-        box_of(a, g, lo, hi);
-        const int nx = hi[0] - lo[0], ny = hi[1] - lo[1], nz = hi[2] - lo[2];
-        vol = (nx > 0 && ny > 0 && nz > 0) ? (uint32_t)nx * (uint32_t)ny * (uint32_t)nz : 0u;
-        a.vols[g] = vol;
-        a.means_grad[3 * g] = 0.f; a.means_grad[3 * g + 1] = 0.f; a.means_grad[3 * g + 2] = 0.f;
-        a.opa_grad[g] = 0.f;
-        for (int ch = 0; ch < kC; ++ch) a.sem_grad[(size_t)kC * g + ch] = 0.f;
-        for (int k = 0; k < 6; ++k) a.cov_grad[6 * g + k] = 0.f;
-    }
-    uint32_t sum = vol;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-    if (lane_id() == 0) s_w[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) a.bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
+// Both steps ride along with the sort kernels below.
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
 {
@@ -187,6 +150,132 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
     x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);
     return (uint32_t)x;
+}
+
+// The range-partitioned kernel below walks the Gaussians in SPATIAL order: a stable counting
+// sort by grid cell (kSortCells = 8x8 cells over H x W) in three small kernels.  With that order
+// and the XCD-aware range schedule each XCD works on one compact region of the grid, whose
+// dL/dlogits rows then stay in its 4 MB L2 (measured 215 -> 161 us at gs25600 with pre-sorted
+// input).  The sort is stable, so the partition -- and with it every rounding -- is reproducible.
+constexpr int kSortCells = 64;
+
+__device__ __forceinline__ int sort_cell(const BwdArgs &a, int g)
+{
+    const int cx = min(a.H - 1, max(0, a.means_int[3 * g])), cy = min(a.W - 1, max(0, a.means_int[3 * g + 1]));
+    return (cx * 8 / a.H) * 8 + cy * 8 / a.W;
+}
+
+// One thread per Gaussian: box volume, per-(cell, block) histogram, zeroed outputs.
+__global__ __launch_bounds__(256) void gf_bwd_vol_kernel(BwdArgs a)
+{
+    __shared__ uint32_t s_hist[kSortCells];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < kSortCells) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    if (g < a.P) {
+        int lo[3], hi[3];
+        box_of(a, g, lo, hi);
+        const int nx = hi[0] - lo[0], ny = hi[1] - lo[1], nz = hi[2] - lo[2];
+        a.vols_in[g] = (nx > 0 && ny > 0 && nz > 0) ? (uint32_t)nx * (uint32_t)ny * (uint32_t)nz : 0u;
+        atomicAdd(&s_hist[sort_cell(a, g)], 1u);
+        a.means_grad[3 * g] = 0.f; a.means_grad[3 * g + 1] = 0.f; a.means_grad[3 * g + 2] = 0.f;
+        a.opa_grad[g] = 0.f;
+        for (int ch = 0; ch < kC; ++ch) a.sem_grad[(size_t)kC * g + ch] = 0.f;
+        for (int k = 0; k < 6; ++k) a.cov_grad[6 * g + k] = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSortCells) a.sort_hist[threadIdx.x * a.nblk + blockIdx.x] = s_hist[threadIdx.x];
+    // arbitrary points only: voxel2pts = -1 (the scatter rides along with the scan kernel)
+    if (!pts_are_dense(a)) {
+        const size_t V = (size_t)a.H * a.W * a.D;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) a.voxel2pts[i] = -1;
+    }
+}
+
+// Workgroup c < kSortCells: exclusive scan of cell c's per-block counts (in place) and the cell
+// total; the prefix over the 64 cell totals is taken by the scatter kernel.  Workgroups
+// kSortCells.. carry the voxel2pts scatter (independent work, one launch less).
+__global__ __launch_bounds__(256) void gf_bwd_sort_scan_kernel(BwdArgs a)
+{
+    if (blockIdx.x >= kSortCells) {
+        if (pts_are_dense(a)) return;
+        const long long nb = gridDim.x - kSortCells;
+        for (long long n = (long long)(blockIdx.x - kSortCells) * 256 + threadIdx.x; n < a.N; n += nb * 256) {
+            const int x = a.points_int[3 * n], y = a.points_int[3 * n + 1], z = a.points_int[3 * n + 2];
+            if (x < 0 || x >= a.H || y < 0 || y >= a.W || z < 0 || z >= a.D) continue;
+            atomicMax(a.voxel2pts + ((size_t)x * a.W + y) * a.D + z, (int)n);
+        }
+        return;
+    }
+    __shared__ uint32_t s_w[4];
+    uint32_t *row = a.sort_hist + (size_t)blockIdx.x * a.nblk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t c[4], sum = 0;  // nblk <= kBwdMaxBlk = 4 * 256
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = 4 * tid + k;
+        c[k] = i < a.nblk ? row[i] : 0u;
+        sum += c[k];
+    }
+    const uint32_t incl = wave_inclusive_scan_u32(sum);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = 4 * tid + k;
+        if (i < a.nblk) row[i] = run;
+        run += c[k];
+    }
+    if (tid == 255) a.sort_hist[(size_t)kSortCells * a.nblk + blockIdx.x] = run;  // cell total
+}
+
+// Stable scatter: rank within the block = number of same-cell Gaussians with a smaller index.
+// The lanes of a wave that share a cell are found with six ballots (one per bit of the cell
+// id); per-(wave, cell) counts in LDS give the offset of the wave inside the block.
+__global__ __launch_bounds__(256) void gf_bwd_sort_scatter_kernel(BwdArgs a)
+{
+    __shared__ uint32_t s_wc[4][kSortCells];
+    __shared__ uint32_t s_base[kSortCells];
+    const int g = blockIdx.x * 256 + threadIdx.x, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {  // exclusive prefix of the 64 cell totals
+        const uint32_t t = a.sort_hist[(size_t)kSortCells * a.nblk + threadIdx.x];
+        s_base[threadIdx.x] = wave_inclusive_scan_u32(t) - t;
+    }
+    const bool valid = g < a.P;
+    const int cell = valid ? sort_cell(a, g) : 0;
+    s_wc[threadIdx.x >> 6][threadIdx.x & 63] = 0u;  // 4 x 64 counters, one per thread
+    unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+        const unsigned long long has = __builtin_amdgcn_ballot_w64((cell >> bit) & 1);
+        same &= ((cell >> bit) & 1) ? has : ~has;
+    }
+    const uint32_t rank = (uint32_t)mbcnt(same);
+    __syncthreads();
+    if (valid && rank == 0) s_wc[wave][cell] = (uint32_t)__builtin_popcountll(same);
+    __syncthreads();
+    if (valid) {
+        uint32_t pos = s_base[cell] + a.sort_hist[cell * a.nblk + blockIdx.x] + rank;
+        for (int w = 0; w < wave; ++w) pos += s_wc[w][cell];
+        const uint32_t v = a.vols_in[g];
+        a.order[pos] = g;
+        a.vols[pos] = v;
+    }
+}
+
+// Sums of 256 consecutive sorted volumes (the coarse level of the range search).
+__global__ __launch_bounds__(256) void gf_bwd_bsum_kernel(BwdArgs a)
+{
+    __shared__ uint32_t s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t sum = i < a.P ? a.vols[i] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) a.bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // DPP add-reduce whose total is valid in lane 63 only (no broadcast)
@@ -287,17 +376,19 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? GF_BWD_OCC_BASE : G
             ++g;
             continue;
         }
+        // g is a position in the sorted order; gid is the Gaussian it holds
+        const int gid = __builtin_amdgcn_readfirstlane(((const int __attribute__((address_space(4))) *)(uintptr_t)a.order)[g]);
         int lo[3], hi[3];
-        box_of(a, g, lo, hi);
+        box_of(a, gid, lo, hi);
         const int ny = hi[1] - lo[1], nz = hi[2] - lo[2];
 
         // wave-uniform Gaussian parameters
-        cfloat_t mp = (cfloat_t)(uintptr_t)(a.means3D + 3 * (size_t)g);
+        cfloat_t mp = (cfloat_t)(uintptr_t)(a.means3D + 3 * (size_t)gid);
         const float mx = mp[0], my = mp[1], mz = mp[2];
-        cfloat_t cv = (cfloat_t)(uintptr_t)(a.cov3D + 6 * (size_t)g);
+        cfloat_t cv = (cfloat_t)(uintptr_t)(a.cov3D + 6 * (size_t)gid);
         const float c1x = cv[0], c1y = cv[1], c1z = cv[2], c2x = cv[3], c2y = cv[4], c2z = cv[5];
-        const float opa = ((cfloat_t)(uintptr_t)(a.opacity + g))[0];
-        cfloat_t sp = (cfloat_t)(uintptr_t)(a.semantics + (size_t)kC * g);
+        const float opa = ((cfloat_t)(uintptr_t)(a.opacity + gid))[0];
+        cfloat_t sp = (cfloat_t)(uintptr_t)(a.semantics + (size_t)kC * gid);
         float sem[kC];
 #pragma unroll
         for (int ch = 0; ch < kC; ++ch) sem[ch] = sp[ch];
@@ -443,18 +534,18 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? GF_BWD_OCC_BASE : G
             cg5 += 2 * dg * (c2x * c2y - c1y * c2z);
         }
         if (lane == 63) {
-            float *pm = a.means_grad + 3 * (size_t)g;
-            float *pc = a.cov_grad + 6 * (size_t)g;
-            float *ps = a.sem_grad + (size_t)kC * g;
+            float *pm = a.means_grad + 3 * (size_t)gid;
+            float *pc = a.cov_grad + 6 * (size_t)gid;
+            float *ps = a.sem_grad + (size_t)kC * gid;
             if (o0 == 0 && o1 == vol) {
                 pm[0] = mg0; pm[1] = mg1; pm[2] = mg2;
-                a.opa_grad[g] = og;
+                a.opa_grad[gid] = og;
                 pc[0] = cg0; pc[1] = cg1; pc[2] = cg2; pc[3] = cg3; pc[4] = cg4; pc[5] = cg5;
 #pragma unroll
                 for (int ch = 0; ch < kC; ++ch) ps[ch] = sg[ch];
             } else {
                 unsafeAtomicAdd(pm, mg0); unsafeAtomicAdd(pm + 1, mg1); unsafeAtomicAdd(pm + 2, mg2);
-                unsafeAtomicAdd(a.opa_grad + g, og);
+                unsafeAtomicAdd(a.opa_grad + gid, og);
                 unsafeAtomicAdd(pc, cg0); unsafeAtomicAdd(pc + 1, cg1); unsafeAtomicAdd(pc + 2, cg2);
                 unsafeAtomicAdd(pc + 3, cg3); unsafeAtomicAdd(pc + 4, cg4); unsafeAtomicAdd(pc + 5, cg5);
 #pragma unroll
@@ -512,16 +603,17 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     a.out_grad = logits_grad;
     a.means_grad = means3D_grad; a.opa_grad = opacity_grad; a.sem_grad = semantics_grad; a.cov_grad = cov3D_grad;
     a.state = (const uint32_t *)state; a.voxel2pts = ws.voxel2pts; a.vols = ws.vols; a.bsum = ws.bsum;
+    a.vols_in = ws.vols_in; a.order = ws.order; a.sort_hist = ws.sort_hist;
     a.P = P; a.N = N; a.H = H; a.W = W; a.D = D; a.per_axis = radii_per_axis ? 1 : 0; a.nblk = (P + 255) / 256;
     const long long V = (long long)H * W * D;
     a.force_general = ((long long)N != V || (flags & GF_PTS_GENERAL)) ? 1 : 0;
     a.assume_dense = (!a.force_general && (flags & GF_PTS_ASSUME_DENSE)) ? 1 : 0;
 
-    if (!a.assume_dense) {
-        hipLaunchKernelGGL(gf_v2p_fill_kernel, dim3(1024), dim3(256), 0, stream, a);
-        if (N > 0) hipLaunchKernelGGL(gf_v2p_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
-    }
+    const int v2p_blocks = a.assume_dense || N == 0 ? 0 : 2048;
     hipLaunchKernelGGL(gf_bwd_vol_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gf_bwd_sort_scan_kernel, dim3(kSortCells + v2p_blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gf_bwd_sort_scatter_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gf_bwd_bsum_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
     const int blocks = 1024;  // 4096 waves, 4 workgroups per CU (VGPR-limited)
     if (variant == GF_SPLAT_BASE)
         hipLaunchKernelGGL(gf_splat_bwd_kernel<GF_SPLAT_BASE>, dim3(blocks), dim3(256), 0, stream, a);
