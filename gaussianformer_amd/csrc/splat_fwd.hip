@@ -53,7 +53,7 @@ struct PrepArgs {
 };
 
 constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
-constexpr int kPrepSuperChunk = 2048;  // supertiles per LDS pass of the prep kernel (16 KB)
+constexpr int kPrepSuperChunk = 4096;  // bitmask words in LDS per pass of the prep kernel (32 KB)
 
 // Integer box of Gaussian g: model/head/localagg/src/auxiliary.h:8-20 (scalar radius) and
 // model/head/localagg_prob_fast/src/auxiliary.h:8-20 (per-axis radius).
@@ -72,17 +72,26 @@ __device__ __forceinline__ void gaussian_box(const int *__restrict__ means_int, 
     lo[2] = min(D, max(0, m2 - r2)); hi[2] = min(D, max(0, m2 + r2 + 1));
 }
 
-__global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
 {
-    // One wave per workgroup.  Gaussian role: 64 Gaussians -> one bitmask word per supertile.
-    // LDS is sized at launch to min(#supertiles, kPrepSuperChunk) words: with the static 16 KB
-    // only 10 of the 4497 single-wave workgroups fit a CU and the grid needed two dispatch rounds.
+    // Gaussian role: every wave turns 64 Gaussians into one bitmask word per supertile; a
+    // workgroup of WAVES waves owns WAVES consecutive words, so the bitmask rows are written
+    // in 8*WAVES-byte runs (WAVES = 1 for small P, where many small workgroups hide latency
+    // best; WAVES = 4 for large P, where the 8-byte scattered stores dominated: 39 us at P = 144 000).
+    // LDS is sized at launch: [min(#supertiles, chunk)][WAVES] words.
     extern __shared__ unsigned long long s_bits[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = kPrepSuperChunk / WAVES;  // supertiles per LDS pass
+    const int bits_words = min(chunk, a.nsx * a.nsy) * WAVES;  // bitmask words in LDS; record images follow
+    auto wg_sync = [&]() {
+        if (WAVES > 1) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // single wave: LDS ops stay ordered
+    };
     if ((int)blockIdx.x >= a.nprep_blocks) {
         // ---- verification role: is point n in voxel n for all n?  Each wave reports its own
         // slice unconditionally (no zero-initialised flag needed).
-        const int vb = (int)blockIdx.x - a.nprep_blocks;
+        const int vb = ((int)blockIdx.x - a.nprep_blocks) * WAVES + wave;
         bool bad = false;
         const long long stride = (long long)kVerifyBlocks * 64;
         for (long long n0 = (long long)vb * 64 + lane; n0 < a.N; n0 += 4 * stride) {
@@ -109,7 +118,8 @@ __global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
         if (lane == 0) a.verify_flags[vb] = any ? 1u : 0u;
         return;
     }
-    const int g = blockIdx.x * 64 + lane;
+    const int word = blockIdx.x * WAVES + wave;  // bitmask word of this wave
+    const int g = word * 64 + lane;
     const bool valid = g < a.P;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     if (valid) gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
@@ -120,51 +130,130 @@ __global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
     const int npairs = nonempty ? (sx_hi - sx_lo + 1) * (sy_hi - sy_lo + 1) : 0;
     const int nsuper = a.nsx * a.nsy;
     // zero the first LDS chunk while the parameter loads are in flight
-    for (int i = lane; i < min(kPrepSuperChunk, nsuper); i += 64) s_bits[i] = 0ull;
-    if (valid) {
-        const uint32_t plo = pack3(lo[0], lo[1], lo[2]);
-        const uint32_t phi = nonempty ? pack3(hi[0], hi[1], hi[2]) : plo;
-        a.boxes[g] = make_uint2(plo, phi);
-        const float *cv = a.cov3D + 6 * (size_t)g;
-        const float c0 = cv[0], c1 = cv[1], c2 = cv[2], c3 = cv[3], c4 = cv[4], c5 = cv[5];
-        float kdet = 0.f;
-        if (a.variant == GF_SPLAT_PROB) {
-            // model/head/localagg_prob/src/forward.cu:77-78
-            const float deter = c0 * c1 * c2 + 2 * c3 * c4 * c5 - c0 * c4 * c4 - c1 * c5 * c5 - c2 * c3 * c3;
-            kdet = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f);
+    for (int i = threadIdx.x; i < min(chunk, nsuper) * WAVES; i += 64 * WAVES) s_bits[i] = 0ull;
+    if (WAVES == 1) {
+        // ---- records, small P: each lane loads and stores its own Gaussian (strided, but one
+        // memory round trip; the staged variant below costs two more and measured 2 us slower
+        // at P = 25 601, where the kernel is latency-bound)
+        if (valid) {
+            const uint32_t plo = pack3(lo[0], lo[1], lo[2]);
+            const uint32_t phi = nonempty ? pack3(hi[0], hi[1], hi[2]) : plo;
+            a.boxes[g] = make_uint2(plo, phi);
+            const float *cv = a.cov3D + 6 * (size_t)g;
+            const float c0 = cv[0], c1 = cv[1], c2 = cv[2], c3 = cv[3], c4 = cv[4], c5 = cv[5];
+            float kdet = 0.f;
+            if (a.variant == GF_SPLAT_PROB) {
+                // model/head/localagg_prob/src/forward.cu:77-78
+                const float deter = c0 * c1 * c2 + 2 * c3 * c4 * c5 - c0 * c4 * c4 - c1 * c5 * c5 - c2 * c3 * c3;
+                kdet = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f);
+            }
+            const float *sm = a.semantics + (size_t)kC * g;
+            float4 *rec = reinterpret_cast<float4 *>(a.records + (size_t)g * kRecDwords);
+            rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opacity[g]);
+            if (a.prescale) {
+                // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
+                // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
+                //   p2 = dx(a dx + b dy + c dz) + dy(d dy + e dz) + f dz^2 = log2(e) * (-1/2 d^T S^-1 d)
+                const double L = 1.4426950408889634074;
+                rec[1] = make_float4((float)(-0.5 * L * c0), (float)(-0.5 * L * c1), (float)(-0.5 * L * c2), (float)(-L * c3));
+                rec[2] = make_float4((float)(-L * c4), (float)(-L * c5), __uint_as_float(plo), __uint_as_float(phi));
+            } else {
+                rec[1] = make_float4(c0, c1, c2, c3);
+                rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
+            }
+            rec[3] = make_float4(sm[0], sm[1], sm[2], sm[3]);
+            rec[4] = make_float4(sm[4], sm[5], sm[6], sm[7]);
+            rec[5] = make_float4(sm[8], sm[9], sm[10], sm[11]);
+            rec[6] = make_float4(sm[12], sm[13], sm[14], sm[15]);
+            rec[7] = make_float4(sm[16], sm[17], kdet, 0.f);
         }
-        const float *sm = a.semantics + (size_t)kC * g;
-        float4 *rec = reinterpret_cast<float4 *>(a.records + (size_t)g * kRecDwords);
-        rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opacity[g]);
-        if (a.prescale) {
-            // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
-            // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
-            //   p2 = dx(a dx + b dy + c dz) + dy(d dy + e dz) + f dz^2 = log2(e) * (-1/2 d^T S^-1 d)
-            const double L = 1.4426950408889634074;
-            rec[1] = make_float4((float)(-0.5 * L * c0), (float)(-0.5 * L * c1), (float)(-0.5 * L * c2), (float)(-L * c3));
-            rec[2] = make_float4((float)(-L * c4), (float)(-L * c5), __uint_as_float(plo), __uint_as_float(phi));
-        } else {
-            rec[1] = make_float4(c0, c1, c2, c3);
-            rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
+    } else {
+        // ---- records, large P.  The 64 Gaussians of a wave are contiguous in every input array, so the
+        // 72-B-strided semantics and 24-B-strided covariance rows are fetched as coalesced 16-byte
+        // pieces (lane L of load k reads piece L + 64k of the block), scattered into a wave-private
+        // LDS image of the 64 records, completed in place by each Gaussian's own lane, and written
+        // out as 8 fully coalesced 1-KB stores (the per-lane version touched 36-64 cache lines per
+        // load or store instruction).
+        float *R = reinterpret_cast<float *>(s_bits + bits_words) + wave * (64 * kRecDwords);
+        const int g0 = word * 64;
+        const int ng = max(0, min(64, a.P - g0));
+        auto stage = [&](const float *__restrict__ src, int per, int slot0) {  // src: [P][per] floats
+            const int nflt = ng * per;
+            const float *blk = src + (size_t)g0 * per;
+            const bool vec_ok = ((uintptr_t)src & 15) == 0;
+            for (int e0 = 4 * lane; e0 < nflt; e0 += 256) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (vec_ok && e0 + 3 < nflt) {
+                    const float4 t = *reinterpret_cast<const float4 *>(blk + e0);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (e0 + j < nflt) v[j] = blk[e0 + j];
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + j;
+                    if (e < nflt) {
+                        const int r = e / per;
+                        R[r * kRecDwords + slot0 + (e - r * per)] = v[j];
+                    }
+                }
+            }
+        };
+        stage(a.semantics, kC, 12);
+        stage(a.cov3D, 6, 4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const uint32_t plo = pack3(lo[0], lo[1], lo[2]);
+            const uint32_t phi = nonempty ? pack3(hi[0], hi[1], hi[2]) : plo;
+            a.boxes[g] = make_uint2(plo, phi);
+            float *row = R + lane * kRecDwords;
+            const float c0 = row[4], c1 = row[5], c2 = row[6], c3 = row[7], c4 = row[8], c5 = row[9];
+            float kdet = 0.f;
+            if (a.variant == GF_SPLAT_PROB) {
+                // model/head/localagg_prob/src/forward.cu:77-78
+                const float deter = c0 * c1 * c2 + 2 * c3 * c4 * c5 - c0 * c4 * c4 - c1 * c5 * c5 - c2 * c3 * c3;
+                kdet = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f);
+            }
+            float4 *rec = reinterpret_cast<float4 *>(row);
+            rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opacity[g]);
+            if (a.prescale) {
+                // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
+                // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
+                //   p2 = dx(a dx + b dy + c dz) + dy(d dy + e dz) + f dz^2 = log2(e) * (-1/2 d^T S^-1 d)
+                const double L = 1.4426950408889634074;
+                rec[1] = make_float4((float)(-0.5 * L * c0), (float)(-0.5 * L * c1), (float)(-0.5 * L * c2), (float)(-L * c3));
+                rec[2] = make_float4((float)(-L * c4), (float)(-L * c5), __uint_as_float(plo), __uint_as_float(phi));
+            } else {
+                rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
+            }
+            row[30] = kdet;
+            row[31] = 0.f;
         }
-        rec[3] = make_float4(sm[0], sm[1], sm[2], sm[3]);
-        rec[4] = make_float4(sm[4], sm[5], sm[6], sm[7]);
-        rec[5] = make_float4(sm[8], sm[9], sm[10], sm[11]);
-        rec[6] = make_float4(sm[12], sm[13], sm[14], sm[15]);
-        rec[7] = make_float4(sm[16], sm[17], kdet, 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        {
+            float4 *dst = reinterpret_cast<float4 *>(a.records + (size_t)g0 * kRecDwords);
+            const float4 *src4 = reinterpret_cast<const float4 *>(R);
+            for (int i = lane; i < ng * (kRecDwords / 4); i += 64) dst[i] = src4[i];
+        }
     }
     const unsigned long long mybit = 1ull << lane;
-    for (int s0 = 0; s0 < nsuper; s0 += kPrepSuperChunk) {
-        const int ns = min(kPrepSuperChunk, nsuper - s0);
-        if (s0 > 0)
-            for (int i = lane; i < ns; i += 64) s_bits[i] = 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // single wave: LDS ops stay ordered
+    for (int s0 = 0; s0 < nsuper; s0 += chunk) {
+        const int ns = min(chunk, nsuper - s0);
+        if (s0 > 0) {
+            wg_sync();  // previous flush done
+            for (int i = threadIdx.x; i < ns * WAVES; i += 64 * WAVES) s_bits[i] = 0ull;
+        }
+        wg_sync();
         // small footprints: each lane ORs its own bit (order-independent => deterministic)
         if (npairs > 0 && npairs <= 16) {
             for (int sx = sx_lo; sx <= sx_hi; ++sx)
                 for (int sy = sy_lo; sy <= sy_hi; ++sy) {
                     const int s = sx * a.nsy + sy - s0;
-                    if (s >= 0 && s < ns) atomicOr(&s_bits[s], mybit);
+                    if (s >= 0 && s < ns) atomicOr(&s_bits[s * WAVES + wave], mybit);
                 }
         }
         // large footprints (e.g. the whole-grid "empty" Gaussian): the wave cooperates
@@ -177,11 +266,14 @@ __global__ __launch_bounds__(64) void gf_splat_prep_kernel(PrepArgs a)
             const int ny = by_hi - by_lo + 1, tot = (bx_hi - bx_lo + 1) * ny;
             for (int i = lane; i < tot; i += 64) {
                 const int s = (bx_lo + i / ny) * a.nsy + by_lo + i % ny - s0;
-                if (s >= 0 && s < ns) atomicOr(&s_bits[s], 1ull << j);
+                if (s >= 0 && s < ns) atomicOr(&s_bits[s * WAVES + wave], 1ull << j);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        for (int i = lane; i < ns; i += 64) a.bitmask[(size_t)(s0 + i) * a.nwords + blockIdx.x] = s_bits[i];
+        wg_sync();
+        for (int i = threadIdx.x; i < ns * WAVES; i += 64 * WAVES) {
+            const int si = i / WAVES, w = i - si * WAVES;
+            if ((int)blockIdx.x * WAVES + w < a.nwords) a.bitmask[(size_t)(s0 + si) * a.nwords + blockIdx.x * WAVES + w] = s_bits[i];
+        }
     }
 }
 
@@ -829,12 +921,15 @@ extern "C" int gf_splat_forward(int variant, int radii_per_axis, int flags, int 
     pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.records = ws.records; pa.boxes = ws.boxes;
     pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
     pa.nwords = ws.nwords; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
-    pa.variant = variant; pa.nprep_blocks = (P + 63) / 64; pa.verify = verify ? 1 : 0;
+    const int prep_waves = P >= 65536 ? 4 : 1;
+    pa.variant = variant; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = verify ? 1 : 0;
     pa.prescale = (flags & (GF_LIBM_EXP | GF_COMP_EXP)) ? 0 : 1;
-    const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks : 0);
+    const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
-        const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy, kPrepSuperChunk);
-        hipLaunchKernelGGL(gf_splat_prep_kernel, dim3(prep_grid), dim3(64), prep_lds, stream, pa);
+        const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
+                                (prep_waves > 1 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
+        if (prep_waves == 1) hipLaunchKernelGGL(gf_splat_prep_kernel<1>, dim3(prep_grid), dim3(64), prep_lds, stream, pa);
+        else hipLaunchKernelGGL(gf_splat_prep_kernel<4>, dim3(prep_grid), dim3(256), prep_lds, stream, pa);
         GF_CHECK_LAUNCH();
     }
     if (N == 0) return GF_OK;
