@@ -158,11 +158,20 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
         for (int j = 0; j < VEC; ++j) go[j] = 0.f;
     }
     const int lane = lane_id();
+    // the three streams never alias; say so, or every gradient store fences the feature gathers
+    const float *__restrict__ feat = a.feat;
+    float *__restrict__ grad_weights = a.grad_weights;
+    float *__restrict__ grad_loc = a.grad_loc;
     for (int cam = 0; cam < a.cams; ++cam) {
         const float loc_w = loc[2 * cam], loc_h = loc[2 * cam + 1];
         if (!(loc_w > 0 && loc_w < 1 && loc_h > 0 && loc_h < 1)) continue;  // uniform per point
         const size_t cam_off = ((size_t)b * a.cams + cam) * a.num_feat * a.C + c0;
         float gl_w = 0.f, gl_h = 0.f;
+        // the grad_weights read-modify-writes are deferred until the camera's taps have been
+        // consumed: a store inside the level loop may alias the feature map as far as the
+        // compiler knows, which serialised the levels' gathers
+        constexpr int kDeferLevels = 8;
+        float gw_level[kDeferLevels];
         for (int s = 0; s < a.L; ++s) {
             const int h = a.spatial_shape[2 * s], w = a.spatial_shape[2 * s + 1];
             const float h_im = loc_h * h - 0.5f, w_im = loc_w * w - 0.5f;
@@ -172,10 +181,10 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
             float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v1[j] = v2[j] = v3[j] = v4[j] = 0.f;
-            if (t.ok1) vload<VEC>(a.feat + o1, v1);
-            if (t.ok2) vload<VEC>(a.feat + o2, v2);
-            if (t.ok3) vload<VEC>(a.feat + o3, v3);
-            if (t.ok4) vload<VEC>(a.feat + o4, v4);
+            if (t.ok1) vload<VEC>(feat + o1, v1);
+            if (t.ok2) vload<VEC>(feat + o2, v2);
+            if (t.ok3) vload<VEC>(feat + o3, v3);
+            if (t.ok4) vload<VEC>(feat + o4, v4);
             const long long wi = wbase + (long long)(cam * a.L + s) * a.G;
             const float wt = a.weights[wi];
             float gw = 0.f, gh_part = 0.f, gw_part = 0.f;
@@ -193,16 +202,28 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
                 gw_part += w * grad_w_weight * top;     // :120
                 gh_part += h * grad_h_weight * top;     // :121
             }
-            if (REDUCE) {
+            if (REDUCE && a.L <= kDeferLevels) {
+#pragma unroll
+                for (int q = 0; q < kDeferLevels; ++q)
+                    if (q == s) gw_level[q] = gw;
+            } else if (REDUCE) {
                 gw = group_sum(gw, lpg);
-                if ((lane & (lpg - 1)) == 0 && active) a.grad_weights[wi] += gw;
+                if ((lane & (lpg - 1)) == 0 && active) grad_weights[wi] += gw;
             } else {
-                unsafeAtomicAdd(a.grad_weights + wi, gw);
+                unsafeAtomicAdd(grad_weights + wi, gw);
             }
             gl_w += gw_part;
             gl_h += gh_part;
         }
-        float *gl = a.grad_loc + (bp * a.cams + cam) * 2;
+        if (REDUCE && a.L <= kDeferLevels) {
+#pragma unroll
+            for (int q = 0; q < kDeferLevels; ++q) {
+                if (q >= a.L) break;
+                const float gw = group_sum(gw_level[q], lpg);
+                if ((lane & (lpg - 1)) == 0 && active) grad_weights[wbase + (long long)(cam * a.L + q) * a.G] += gw;
+            }
+        }
+        float *gl = grad_loc + (bp * a.cams + cam) * 2;
         if (REDUCE) {
             gl_w = group_sum(gl_w, lpp);
             gl_h = group_sum(gl_h, lpp);
