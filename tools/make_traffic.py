@@ -1,0 +1,36 @@
+"""HBM bytes per render-kernel launch from the two TCC PMC passes (FETCH_SIZE, WRITE_SIZE; separate
+rocprofv3 --pmc runs), with the gfx950 correction MI355X_MICROARCH.md prescribes (FETCH_SIZE x2;
+both counters are in KiB).  usage: make_traffic.py <fetch_dir> <write_dir> <out.json> <tag>"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+fetch_dir, write_dir, out, tag = sys.argv[1:5]
+
+
+def mean_counter(d, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and "gf_splat_render_kernel" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    (name, vals), = acc.items()
+    return name, sum(vals) / len(vals), len(vals)
+
+
+name, fetch, n = mean_counter(fetch_dir, "FETCH_SIZE")
+_, write, _ = mean_counter(write_dir, "WRITE_SIZE")
+P, N = 25601, 640000
+json.dump({
+    "source": f"profiles/pmc_{tag}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, {n} launches each, nuscenes_gs25600_solid)",
+    "kernel": name[:60],
+    "FETCH_SIZE_KiB_raw": fetch,
+    "WRITE_SIZE_KiB_raw": write,
+    "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
+    "render_kernel_hbm_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
+    "render_kernel_hbm_bytes_per_launch_uncorrected": int(round((fetch + write) * 1024)),
+    "algorithmic_bytes_per_launch": 128 * P + 24 * N + 72 * N,
+}, open(out, "w"), indent=2)
+print(open(out).read())
