@@ -33,6 +33,8 @@ SIGNATURES = {
     "gf_daf_backward": (_i, [_i] * 7 + [_vp] * 10),
     "gf_daf_backward_workspace_bytes": (_sz, [_i] * 7),
     "gf_daf_backward_sorted": (_i, [_i] * 7 + [_vp] * 9 + [_vp, _sz, _vp]),
+    "gf_daf_prepare": (_i, [_i] * 6 + [_vp] * 7 + [_vp]),
+    "gf_daf_prepare_backward": (_i, [_i] * 6 + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare": (_i, [_i] * 4 + [_vp, _f, _f, _i, _i] + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare_backward": (_i, [_i] * 2 + [_vp] * 5 + [_vp]),
     "gf_profile_enable": (_i, [_i]),

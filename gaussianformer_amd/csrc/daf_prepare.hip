@@ -1,0 +1,247 @@
+// Fused caller-side preparation of the deformable aggregation: what
+// DeformableFeatureAggregation.forward does between the weights_fc GEMM and DAF.apply
+// (model/encoder/gaussian_encoder/deformable_module.py:174-214 and project_points :268-285):
+//   * project every key point into every camera, normalise by depth and image size, visibility mask;
+//   * permute the raw attention logits [cams, L, pts, G] -> [pts, cams, L, G], mask invisible
+//     (point, camera) pairs with -inf, softmax over (pts, cams, L) per group, zero anchors that
+//     no camera sees.
+// The reference runs ~15 elementwise / permute / softmax kernels over the 88-498 MB weights tensor;
+// here one wave per anchor reads the raw logits once and writes the DAF-layout weights once.
+#include "gf_common.hpp"
+
+namespace gf {
+
+constexpr int kPrepMaxPairs = 256;  // pts * cams per anchor held in LDS as visibility flags
+
+struct DafPrepArgs {
+    const float *key_points;     // [B, A, pts, 3]
+    const float *proj;           // [B, cams, 4, 4] row-major
+    const float *image_wh;       // [B, cams, 2] or null
+    const float *raw;            // [B, A, cams, L, pts, G]  (weights_fc output, deformable_module.py:243-253)
+    const unsigned char *wmask;  // same layout as raw (attention dropout keep-mask) or null
+    float *points_2d;            // [B, A*pts, cams, 2]
+    float *weights;              // [B, A*pts, cams, L, G]
+    const float *grad_weights;   // backward: [B, A*pts, cams, L, G]
+    const float *grad_points;    // backward: [B, A*pts, cams, 2]
+    float *grad_raw;             // backward: [B, A, cams, L, pts, G]
+    float *grad_key_points;      // backward: [B, A, pts, 3]
+    int B, A, pts, cams, L, G;
+};
+
+// reduce over the lanes that share (lane % G): xor-butterfly on the lane bits above log2(G)
+template <typename F>
+__device__ __forceinline__ float group_reduce(float v, int G, F op)
+{
+    for (int d = G; d < 64; d <<= 1) v = op(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+struct Proj {
+    float x, y, z;
+};
+__device__ __forceinline__ Proj project(const float *M, float X, float Y, float Z)
+{
+    Proj p;
+    p.x = M[0] * X + M[1] * Y + M[2] * Z + M[3];
+    p.y = M[4] * X + M[5] * Y + M[6] * Z + M[7];
+    p.z = M[8] * X + M[9] * Y + M[10] * Z + M[11];
+    return p;
+}
+
+// STAGE: the anchor's raw logits are copied to LDS with coalesced loads first (the permuted
+// reads of the three softmax passes then hit LDS instead of issuing 16-byte gathers).
+template <bool STAGE>
+__global__ __launch_bounds__(256) void gf_daf_prepare_kernel(DafPrepArgs a)
+{
+    __shared__ unsigned char s_valid[4][kPrepMaxPairs];
+    extern __shared__ float s_stage[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npair = a.pts * a.cams;
+    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_stage) + (STAGE ? 4 * npair * a.L * a.G : 0);
+    for (int i = threadIdx.x; i < npair * a.L * a.G; i += 256) {
+        const int g = i % a.G;
+        int r = i / a.G;
+        const int l = r % a.L;
+        r /= a.L;  // pt * cams + cam
+        const int pt = r / a.cams, cam = r - pt * a.cams;
+        s_tab[i] = (uint32_t)(((cam * a.L + l) * a.pts + pt) * a.G + g) | ((uint32_t)r << 20);
+    }
+    __syncthreads();
+    const long long anchor = (long long)blockIdx.x * 4 + wave;  // b * A + a
+    if (anchor >= (long long)a.B * a.A) return;
+    const int b = (int)(anchor / a.A);
+    // ---- projection (project_points, deformable_module.py:268-285)
+    for (int q = lane; q < npair; q += 64) {
+        const int pt = q / a.cams, cam = q - pt * a.cams;
+        const float *kp = a.key_points + (anchor * a.pts + pt) * 3;
+        const Proj p = project(a.proj + ((size_t)b * a.cams + cam) * 16, kp[0], kp[1], kp[2]);
+        const float zc = fmaxf(p.z, 1e-5f);  // torch.clamp(points_2d[..., 2:3], min=1e-5)
+        float u = p.x / zc, v = p.y / zc;
+        if (a.image_wh) {
+            u /= a.image_wh[((size_t)b * a.cams + cam) * 2];
+            v /= a.image_wh[((size_t)b * a.cams + cam) * 2 + 1];
+        }
+        s_valid[wave][q] = (p.z > 1e-5f) && (u > 0) && (u < 1) && (v > 0) && (v < 1);
+        *reinterpret_cast<float2 *>(a.points_2d + ((anchor * a.pts + pt) * a.cams + cam) * 2) = make_float2(u, v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- masked softmax over (pts, cams, L) per group; i runs in OUTPUT order [pt][cam][l][g]
+    const int E = npair * a.L * a.G;
+    const float *raw = a.raw + anchor * E;
+    float *mine = s_stage + (STAGE ? wave * E : 0);
+    if (STAGE) {
+        for (int i = lane; i < E; i += 64) mine[i] = raw[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const unsigned char *wm = a.wmask ? a.wmask + anchor * E : nullptr;
+    // s_tab[i] = input offset | (pt * cams + cam) << 20 of output element i, shared by the
+    // workgroup's four anchors: the five runtime integer divisions per element are paid once,
+    // not in each of the three softmax passes
+    auto entry = [&](int i, float &x, bool &ok) {
+        const uint32_t t = s_tab[i];
+        const int in = (int)(t & 0xfffffu), r = (int)(t >> 20);
+        x = STAGE ? mine[in] : raw[in];
+        ok = s_valid[wave][r] && (!wm || wm[in]);
+    };
+    float m = -INFINITY;
+    for (int i = lane; i < E; i += 64) {
+        float x; bool ok;
+        entry(i, x, ok);
+        if (ok) m = fmaxf(m, x);
+    }
+    m = group_reduce(m, a.G, [](float p, float q) { return fmaxf(p, q); });
+    const bool all_miss = m == -INFINITY;  // no visible, kept entry for this (anchor, group): weights = 0 (:196-213)
+    float s = 0.f;
+    for (int i = lane; i < E; i += 64) {
+        float x; bool ok;
+        entry(i, x, ok);
+        if (ok) s += expf(x - m);
+    }
+    s = group_reduce(s, a.G, [](float p, float q) { return p + q; });
+    float *out = a.weights + anchor * E;
+    for (int i = lane; i < E; i += 64) {
+        float x; bool ok;
+        entry(i, x, ok);
+        out[i] = (ok && !all_miss) ? expf(x - m) / s : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void gf_daf_prepare_bwd_kernel(DafPrepArgs a)
+{
+    extern __shared__ float s_stage[];
+    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_stage);  // output element -> input offset, as in the forward
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npair = a.pts * a.cams;
+    const int E = npair * a.L * a.G;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const int g = i % a.G;
+        int r = i / a.G;
+        const int l = r % a.L;
+        r /= a.L;
+        const int pt = r / a.cams, cam = r - pt * a.cams;
+        s_tab[i] = (uint32_t)(((cam * a.L + l) * a.pts + pt) * a.G + g);
+    }
+    __syncthreads();
+    const long long anchor = (long long)blockIdx.x * 4 + wave;
+    if (anchor >= (long long)a.B * a.A) return;
+    const int b = (int)(anchor / a.A);
+    // ---- softmax backward: d raw = y (dy - sum_group y dy); masked entries have y = 0
+    if (a.grad_raw) {
+        const float *y = a.weights + anchor * E, *dy = a.grad_weights + anchor * E;
+        float dot = 0.f;
+        for (int i = lane; i < E; i += 64) dot += y[i] * dy[i];
+        dot = group_reduce(dot, a.G, [](float p, float q) { return p + q; });
+        float *graw = a.grad_raw + anchor * E;
+        for (int i = lane; i < E; i += 64) graw[s_tab[i]] = y[i] * (dy[i] - dot);
+    }
+    // ---- projection backward: u = x / max(z, 1e-5) / w_img (the clamp has zero slope below 1e-5)
+    if (a.grad_key_points) {
+        for (int pt = lane; pt < a.pts; pt += 64) {
+            const float *kp = a.key_points + (anchor * a.pts + pt) * 3;
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+            for (int cam = 0; cam < a.cams; ++cam) {
+                const float *M = a.proj + ((size_t)b * a.cams + cam) * 16;
+                const Proj p = project(M, kp[0], kp[1], kp[2]);
+                const float zc = fmaxf(p.z, 1e-5f), iz = 1.f / zc;
+                float gu = a.grad_points[((anchor * a.pts + pt) * a.cams + cam) * 2];
+                float gv = a.grad_points[((anchor * a.pts + pt) * a.cams + cam) * 2 + 1];
+                if (a.image_wh) {
+                    gu /= a.image_wh[((size_t)b * a.cams + cam) * 2];
+                    gv /= a.image_wh[((size_t)b * a.cams + cam) * 2 + 1];
+                }
+                // d(x/zc) = dx/zc - x dz/zc^2 (second term only where z > 1e-5)
+                const float cz = p.z > 1e-5f ? -(gu * p.x + gv * p.y) * iz * iz : 0.f;
+                const float cx = gu * iz, cy = gv * iz;
+                gx += cx * M[0] + cy * M[4] + cz * M[8];
+                gy += cx * M[1] + cy * M[5] + cz * M[9];
+                gz += cx * M[2] + cy * M[6] + cz * M[10];
+            }
+            float *o = a.grad_key_points + (anchor * a.pts + pt) * 3;
+            o[0] = gx; o[1] = gy; o[2] = gz;
+        }
+    }
+}
+
+static int prep_check(int B, int A, int pts, int cams, int L, int G)
+{
+    GF_CHECK_ARG(B >= 0 && A >= 0 && pts > 0 && cams > 0 && L > 0 && G > 0, "bad size");
+    GF_CHECK_ARG((G & (G - 1)) == 0 && G <= 64, "num_groups must be a power of two <= 64");
+    GF_CHECK_ARG(pts * cams <= kPrepMaxPairs, "pts * cams exceeds the per-anchor capacity (256)");
+    GF_CHECK_ARG((long long)pts * cams * L * G < (1ll << 20), "anchor too large");
+    return GF_OK;
+}
+
+}  // namespace gf
+
+extern "C" int gf_daf_prepare(int B, int A, int pts, int cams, int L, int G, const float *key_points,
+                              const float *projection_mat, const float *image_wh, const float *raw_weights,
+                              const unsigned char *weight_mask, float *points_2d, float *weights, void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = prep_check(B, A, pts, cams, L, G)) return rc;
+    if ((long long)B * A == 0) return GF_OK;
+    GF_CHECK_ARG(key_points && projection_mat && raw_weights && points_2d && weights, "null pointer");
+    GF_CHECK_ARG(((uintptr_t)points_2d & 7) == 0, "points_2d must be 8-byte aligned");
+    DafPrepArgs a{};
+    a.key_points = key_points; a.proj = projection_mat; a.image_wh = image_wh; a.raw = raw_weights; a.wmask = weight_mask;
+    a.points_2d = points_2d; a.weights = weights; a.B = B; a.A = A; a.pts = pts; a.cams = cams; a.L = L; a.G = G;
+    const long long blocks = ((long long)B * A + 3) / 4;
+    GF_CHECK_ARG(blocks < (1ll << 31), "problem too large");
+    const size_t tab_bytes = (size_t)pts * cams * L * G * sizeof(uint32_t);
+    const size_t stage_bytes = 4 * tab_bytes;  // four anchors per workgroup
+    GF_CHECK_ARG(tab_bytes <= 60 * 1024 && pts * cams * L * G < (1 << 20), "anchor too large");
+    if (stage_bytes + tab_bytes <= 60 * 1024)
+        hipLaunchKernelGGL(gf_daf_prepare_kernel<true>, dim3((unsigned)blocks), dim3(256), stage_bytes + tab_bytes, stream, a);
+    else
+        hipLaunchKernelGGL(gf_daf_prepare_kernel<false>, dim3((unsigned)blocks), dim3(256), tab_bytes, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" int gf_daf_prepare_backward(int B, int A, int pts, int cams, int L, int G, const float *key_points,
+                                       const float *projection_mat, const float *image_wh, const float *weights,
+                                       const float *grad_weights, const float *grad_points_2d, float *grad_raw_weights,
+                                       float *grad_key_points, void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = prep_check(B, A, pts, cams, L, G)) return rc;
+    if ((long long)B * A == 0) return GF_OK;
+    GF_CHECK_ARG(!grad_raw_weights || (weights && grad_weights), "grad_raw_weights needs weights and grad_weights");
+    GF_CHECK_ARG(!grad_key_points || (key_points && projection_mat && grad_points_2d),
+                 "grad_key_points needs key_points, projection_mat and grad_points_2d");
+    DafPrepArgs a{};
+    a.key_points = key_points; a.proj = projection_mat; a.image_wh = image_wh; a.weights = const_cast<float *>(weights);
+    a.grad_weights = grad_weights; a.grad_points = grad_points_2d; a.grad_raw = grad_raw_weights;
+    a.grad_key_points = grad_key_points; a.B = B; a.A = A; a.pts = pts; a.cams = cams; a.L = L; a.G = G;
+    const long long blocks = ((long long)B * A + 3) / 4;
+    GF_CHECK_ARG(blocks < (1ll << 31), "problem too large");
+    const size_t tab_bytes = (size_t)pts * cams * L * G * sizeof(uint32_t);
+    GF_CHECK_ARG(tab_bytes <= 60 * 1024, "anchor too large");
+    hipLaunchKernelGGL(gf_daf_prepare_bwd_kernel, dim3((unsigned)blocks), dim3(256), tab_bytes, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

@@ -206,6 +206,31 @@ int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, int L, int 
  * gf_profile_enable(0) disables and frees.  Not part of the reference interface.
  */
 int gf_profile_enable(int max_records);
+/*
+ * Fused caller-side preparation of the deformable aggregation.
+ * Replaces, in DeformableFeatureAggregation.forward (model/encoder/gaussian_encoder/deformable_module.py):
+ *   project_points :268-285 (4x4 projection, depth clamp 1e-5, image_wh normalisation, visibility mask),
+ *   the weights / weight_mask permutes :174-193, the -inf masking, all_miss handling and softmax :199-214.
+ *   key_points f32 [B,A,pts,3]   projection_mat f32 [B,cams,4,4]   image_wh f32 [B,cams,2] or NULL
+ *   raw_weights f32 [B,A,cams,L,pts,G] (weights_fc output as reshaped at :243-253)
+ *   weight_mask u8 same layout (attention-dropout keep mask, :263) or NULL = keep all
+ * Outputs, in the layouts gf_daf_forward takes:
+ *   points_2d f32 [B,A*pts,cams,2]   weights f32 [B,A*pts,cams,L,G]
+ * G must be a power of two <= 64 and pts*cams <= 256.
+ */
+int gf_daf_prepare(int B, int A, int pts, int cams, int L, int G, const float *key_points,
+                   const float *projection_mat, const float *image_wh, const float *raw_weights,
+                   const unsigned char *weight_mask, float *points_2d, float *weights, void *stream);
+
+/*
+ * Its gradient: grad_raw_weights [B,A,cams,L,pts,G] from (weights, grad_weights) and
+ * grad_key_points [B,A,pts,3] from grad_points_2d; either output may be NULL.
+ */
+int gf_daf_prepare_backward(int B, int A, int pts, int cams, int L, int G, const float *key_points,
+                            const float *projection_mat, const float *image_wh, const float *weights,
+                            const float *grad_weights, const float *grad_points_2d, float *grad_raw_weights,
+                            float *grad_key_points, void *stream);
+
 /* Time only every `every`-th dominant-kernel launch (default 1): the two event records cost a few
  * microseconds of stream time each, so sampling keeps the timed region close to the un-instrumented one. */
 int gf_profile_stride(int every);

@@ -65,6 +65,26 @@ for P in (25601, 144000):
     sec = timed(lambda: gaussian_prepare(m, sc, q, [-40.0, -40.0, -1.0], 0.4, 3, 200, 200, 16))
     report("gaussian_prepare(module-level call)", f"P={P}", sec, 80 * P, {"P": P})
 
+from gaussianformer_amd.deformable_prepare import deformable_prepare  # noqa: E402
+from oracle import daf_prepare_ref  # noqa: E402  (torch-op restatement of the reference block, timed for comparison)
+for A in (25600, 144000):
+    pts_per, cams, L, G = 9, 6, 4, 4
+    kp = torch.rand(1, A, pts_per, 3, device=dev) * torch.tensor([80.0, 80.0, 6.4], device=dev) + torch.tensor([-40.0, -40.0, -1.0], device=dev)
+    pm = torch.eye(4, device=dev).repeat(1, cams, 1, 1)
+    for c in range(cams):
+        yaw = 2 * np.pi * c / cams
+        R = torch.tensor([[-np.sin(yaw), np.cos(yaw), 0.0], [0.0, 0.0, -1.0], [np.cos(yaw), np.sin(yaw), 0.0]], dtype=torch.float32)
+        K = torch.tensor([[1260.0, 0, 800.0], [0, 1260.0, 450.0], [0, 0, 1.0]])
+        pm[0, c, :3, :3] = (K @ R).to(dev)
+        pm[0, c, :3, 3] = (K @ torch.tensor([0.0, 1.5, 0.0])).to(dev)
+    wh = torch.tensor([[[1600.0, 900.0]] * cams], device=dev)
+    raw = torch.randn(1, A, cams, L, pts_per, G, device=dev)
+    nbytes = 2 * raw.numel() * 4 + kp.numel() * 4 + A * pts_per * cams * 8
+    sec = timed(lambda: deformable_prepare(kp, pm, wh, raw))
+    report("deformable_prepare (fused, module-level call)", f"A={A}", sec, nbytes, {"anchors": A})
+    sec = timed(lambda: daf_prepare_ref.prepare(kp, pm, wh, raw), iters=10)
+    report("deformable_prepare (reference torch-op sequence on the same GPU)", f"A={A}", sec, nbytes, {"anchors": A})
+
 DAF_CASES = () if "--splat-only" in sys.argv else ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000"))
 for pts, name in DAF_CASES:
     d = make_daf_inputs(num_pts=pts, seed=0)
