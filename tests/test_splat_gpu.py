@@ -366,3 +366,19 @@ def test_random_shapes_sweep(gpu):
                     assert e_hip <= max(3 * e_orc, 1e-3), f"{name}: HIP err {e_hip:.2e}, oracle err {e_orc:.2e} (vs fp64)"
         except AssertionError as e:
             raise AssertionError(f"trial {trial}: {config} P={P} grid {H}x{W}x{D} per_axis={per_axis} dense={dense}: {e}")
+
+
+def test_forward_pipeline_two_streams(gpu):
+    """Two frames in flight on two streams (SplatForwardPipeline) give the bits of a plain call."""
+    import torch
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import SplatForwardPipeline
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=31, P=5000, H=64, W=48, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    ref, t, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    pipe = SplatForwardPipeline(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D)
+    outs = [pipe.submit() for _ in range(6)]
+    for logits, ev in outs[-2:]:
+        ev.synchronize()
+        assert np.array_equal(logits.cpu().numpy(), ref["logits"])
+    torch.cuda.synchronize()
