@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GF_LIB") or os.path.join(_HERE, "csrc", "libgf_hip.so
 GF_ABI_VERSION = 1
 GF_SPLAT_BASE, GF_SPLAT_PROB = 0, 1
 GF_NUM_CHANNELS = 18
+GF_LABELS_ARGMAX, GF_LABELS_PROB_THRESHOLD, GF_LABELS_PROB_GEOSEM = 0, 1, 2
 GF_RADII_SCALAR, GF_RADII_SCALAR_CLAMPED, GF_RADII_PER_AXIS = 0, 1, 2
 GF_PREPARE_MEAN_OUT_OF_GRID, GF_PREPARE_RADIUS_BELOW_ONE = 1, 2
 GF_PTS_AUTO, GF_PTS_ASSUME_DENSE, GF_PTS_GENERAL, GF_FAST_EXP, GF_LIBM_EXP, GF_COMP_EXP = 0, 1, 2, 4, 8, 16
@@ -33,6 +34,7 @@ SIGNATURES = {
     "gf_daf_backward": (_i, [_i] * 7 + [_vp] * 10),
     "gf_daf_backward_workspace_bytes": (_sz, [_i] * 7),
     "gf_daf_backward_sorted": (_i, [_i] * 7 + [_vp] * 9 + [_vp, _sz, _vp]),
+    "gf_head_labels": (_i, [ctypes.c_longlong, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),
     "gf_daf_prepare": (_i, [_i] * 6 + [_vp] * 7 + [_vp]),
     "gf_daf_prepare_backward": (_i, [_i] * 6 + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare": (_i, [_i] * 4 + [_vp, _f, _f, _i, _i] + [_vp] * 8 + [_vp]),

@@ -206,6 +206,20 @@ int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, int L, int 
  * gf_profile_enable(0) disables and frees.  Not part of the reference interface.
  */
 int gf_profile_enable(int max_records);
+/* modes of gf_head_labels */
+#define GF_LABELS_ARGMAX 0          /* base head: argmax over the 18 logits (gaussian_head.py:185) */
+#define GF_LABELS_PROB_THRESHOLD 1  /* prob head: argmax where bin_logits > threshold, else empty_label (:178-183) */
+#define GF_LABELS_PROB_GEOSEM 2     /* prob head with combine_geosem: argmax of cat(logits[:,:-1]*bin, 1-bin) (:166-170,:185) */
+
+/*
+ * Occupancy labels straight from the splat outputs, replacing the transposes,
+ * argmax and mask kernels at the end of GaussianHead.forward (model/head/gaussian_head.py:164-185).
+ *   logits f32 [N,18]   bin_logits f32 [N] (prob modes, else NULL)   labels i64 [N] (torch.argmax's dtype)
+ * Ties resolve to the first maximal channel, like torch.argmax.
+ */
+int gf_head_labels(long long N, int C, int mode, const float *logits, const float *bin_logits,
+                   float threshold, int empty_label, long long *labels, void *stream);
+
 /*
  * Fused caller-side preparation of the deformable aggregation.
  * Replaces, in DeformableFeatureAggregation.forward (model/encoder/gaussian_encoder/deformable_module.py):

@@ -1,0 +1,106 @@
+"""Head epilogue: labels from the splat outputs, and the sharded labels path
+(2-rank gloo on the CPU with the per-rank ops stubbed, GPU kernel against the torch formulas
+of model/head/gaussian_head.py:164-185)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _reference_labels(logits, bin_logits=None, threshold=0.5, empty_label=17, combine_geosem=False):
+    """gaussian_head.py:164-185, op for op (semantics = (logits, bin_logits, ...))."""
+    if bin_logits is not None:
+        if combine_geosem:
+            sem = logits[:, :-1] * bin_logits.unsqueeze(-1)
+            geo = 1 - bin_logits.unsqueeze(-1)
+            geosem = torch.cat([sem, geo], dim=-1)
+        else:
+            geosem = logits
+        prediction = geosem[None].transpose(1, 2)
+        if not combine_geosem:
+            final_semantics = prediction.argmax(dim=1)
+            final_occupancy = bin_logits[None] > threshold
+            final_prediction = torch.ones_like(final_semantics) * empty_label
+            final_prediction[final_occupancy] = final_semantics[final_occupancy]
+            return final_prediction[0]
+        return prediction.argmax(dim=1)[0]
+    return logits[None].transpose(1, 2).argmax(dim=1)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 63, 64, 1000, 640000])
+def test_head_labels_match_torch(N):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gaussianformer_amd.head import occupancy_labels
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N)
+    logits = torch.randn(N, 18, generator=g).to(dev)
+    bins = torch.rand(N, generator=g).to(dev)
+    # ties: duplicate the maximum of some rows into a later channel -> the first one must win
+    if N >= 64:
+        rows = torch.arange(0, N, 7, device=dev)
+        m, am = logits[rows].max(dim=1)
+        later = torch.clamp(am + 3, max=17)
+        logits[rows, later] = m
+    for kw in (dict(), dict(bin_logits=bins, threshold=0.4, empty_label=17), dict(bin_logits=bins, combine_geosem=True)):
+        got = occupancy_labels(logits, **kw)
+        want = _reference_labels(logits, **kw)
+        assert got.dtype == torch.int64 and got.shape == (N,)
+        assert torch.equal(got, want), kw
+    # a non-16-byte-aligned view takes the scalar load path
+    if N >= 64:
+        flat = torch.zeros(N * 18 + 1, device=dev)
+        view = flat[1:].view(N, 18)
+        view.copy_(logits)
+        assert torch.equal(occupancy_labels(view), _reference_labels(logits))
+
+
+# ------------------------------------------------------------------ sharded labels, 2-rank gloo
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussianformer_amd.head import sharded_splat_labels
+    from test_sharded_cpu import _inputs, _local_splat_factory
+    si, args = _inputs()
+    labels = sharded_splat_labels(_local_splat_factory(si), *args, labels_fn=lambda lg: lg.argmax(dim=1))
+    q.put((rank, labels.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_labels_match_single_rank():
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gaussianformer_amd.head import sharded_splat_labels
+    from test_sharded_cpu import _inputs, _local_splat_factory
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    si, args = _inputs()
+    logits = _local_splat_factory(si)(*args)
+    want = logits.argmax(dim=1).numpy()
+    # N = 16*12*8 = 1536 points is even; summation order differs between 1 and 2 ranks, so allow
+    # a flip only where the top two logits are within rounding
+    top2 = torch.topk(logits, 2, dim=1).values
+    close = (top2[:, 0] - top2[:, 1]).abs().numpy() < 1e-5
+    for r in range(2):
+        assert got[r].shape == want.shape
+        assert np.all((got[r] == want) | close)
+    assert np.array_equal(got[0], got[1])
+    # world_size 1 path (no process group): plain labels
+    assert np.array_equal(sharded_splat_labels(_local_splat_factory(si), *args, labels_fn=lambda lg: lg.argmax(dim=1)).numpy(), want)

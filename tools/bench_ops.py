@@ -85,6 +85,13 @@ for A in (25600, 144000):
     sec = timed(lambda: daf_prepare_ref.prepare(kp, pm, wh, raw), iters=10)
     report("deformable_prepare (reference torch-op sequence on the same GPU)", f"A={A}", sec, nbytes, {"anchors": A})
 
+from gaussianformer_amd.head import occupancy_labels  # noqa: E402
+lg = torch.randn(640000, 18, device=dev)
+sec = timed(lambda: occupancy_labels(lg))
+report("head_labels (fused argmax, module-level call)", "N=640000", sec, 640000 * (72 + 8), {"N": 640000})
+sec = timed(lambda: lg[None].transpose(1, 2).argmax(dim=1))
+report("head_labels (reference: transposed-view torch argmax on the same GPU)", "N=640000", sec, 640000 * (72 + 8), {"N": 640000})
+
 DAF_CASES = () if "--splat-only" in sys.argv else ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000"))
 for pts, name in DAF_CASES:
     d = make_daf_inputs(num_pts=pts, seed=0)
