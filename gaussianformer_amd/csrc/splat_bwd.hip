@@ -22,22 +22,6 @@
 // Launches: [voxel->point map (arbitrary pts only)] -> volumes -> gradient kernel.
 #include "gf_common.hpp"
 
-#ifndef GF_BWD_OCC_BASE
-#define GF_BWD_OCC_BASE 4
-#endif
-#ifndef GF_BWD_OCC_PROB
-#define GF_BWD_OCC_PROB 2
-#endif
-#ifndef GF_BWD_XCD
-#define GF_BWD_XCD 1
-#endif
-#ifndef GF_BWD_PHASES
-#define GF_BWD_PHASES 1
-#endif
-#ifndef GF_BWD_LG_STAGE
-#define GF_BWD_LG_STAGE 1
-#endif
-
 namespace gf {
 
 struct BwdArgs {
@@ -291,7 +275,7 @@ __device__ __forceinline__ float wave_sum63(float v)
 }
 
 template <int VARIANT>
-__global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? GF_BWD_OCC_BASE : GF_BWD_OCC_PROB) void gf_splat_bwd_kernel(BwdArgs a)
+__global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_splat_bwd_kernel(BwdArgs a)
 {
     __shared__ unsigned long long s_pref[kBwdMaxBlk + 1];  // exclusive prefix of the block sums
     __shared__ __attribute__((aligned(16))) float s_rows_all[4 * 64 * kC];
@@ -328,19 +312,14 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? GF_BWD_OCC_BASE : G
     // Range schedule.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and every workgroup is
     // resident at once, so XCD k is given the k-th eighth of the concatenation (with the
     // Gaussians in spatial order that is one compact region of the grid whose dL rows stay in
-    // that XCD's 4 MB L2), walked in kBwdPhases successive sub-regions.
+    // that XCD's 4 MB L2).  Splitting an XCD's share into successive sub-regions measured slower.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const unsigned long long nranges = (unsigned long long)gridDim.x * 4ull * GF_BWD_PHASES;
+    const unsigned long long nranges = (unsigned long long)gridDim.x * 4ull;
     const unsigned long long per = (((R + nranges - 1) / nranges) + 63ull) & ~63ull;
-    for (int phase = 0; phase < GF_BWD_PHASES; ++phase) {
-#if GF_BWD_XCD
-    const int range_id = __builtin_amdgcn_readfirstlane(((xcd * GF_BWD_PHASES + phase) * per_xcd + slot) * 4 + (tid >> 6));
-#else
-    const int range_id = __builtin_amdgcn_readfirstlane((int)((phase * gridDim.x + blockIdx.x) * 4 + (tid >> 6)));
-#endif
+    const int range_id = __builtin_amdgcn_readfirstlane((xcd * per_xcd + slot) * 4 + (tid >> 6));
     unsigned long long r0 = (unsigned long long)range_id * per;
     const unsigned long long r1 = min(R, r0 + per);
-    if (r0 >= R) continue;
+    if (r0 >= R) return;
 
     // ---- locate the Gaussian containing voxel r0: binary search over blocks, then a wave scan
     int blo = 0, bhi = a.nblk;  // invariant: s_pref[blo] <= r0 < s_pref[bhi]
@@ -444,19 +423,9 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? GF_BWD_OCC_BASE : G
             stage_finish(raw, dL, s_rows, lane);
             float lg[kC];
             if (VARIANT == GF_SPLAT_PROB) {
-#if GF_BWD_LG_STAGE
                 float2 raw2[9];
                 stage_issue(a.logits, p, raw2, s_pidx, lane);
                 stage_finish(raw2, lg, s_rows, lane);
-#else
-                if (p >= 0) {
-#pragma unroll
-                    for (int j = 0; j < kC / 2; ++j) {
-                        const float2 t = *reinterpret_cast<const float2 *>(a.logits + (size_t)p * kC + 2 * j);
-                        lg[2 * j] = t.x; lg[2 * j + 1] = t.y;
-                    }
-                }
-#endif
             }
             advance();
             i += 64;
@@ -558,7 +527,6 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? GF_BWD_OCC_BASE : G
             ++g;
         }
     }
-    }  // phase
 }
 
 }  // namespace gf

@@ -514,33 +514,12 @@ __global__ __launch_bounds__(kBlock) void gf_splat_render_general_kernel(RenderA
     general_body<VARIANT, EXP>(a);
 }
 
-// Tuning switches (defaults = best measured; see profiles/README.md)
-#ifndef GF_DBUF
-#define GF_DBUF 0      // 1: software-pipeline the hit loop with two SGPR record sets
-#endif
-#ifndef GF_OCC
-#define GF_OCC 6       // waves per SIMD the render kernel is compiled for (two voxels per lane: 79 VGPRs)
-#endif
-#ifndef GF_DIAG
-#define GF_DIAG 0      // development diagnostics (tools/variants.py); 0 in the product
-#endif
-#ifndef GF_OUT_SC1
-#define GF_OUT_SC1 0   // 1: write logits with sc1 (write-through, do not keep the line in L2)
-#endif
+constexpr int kRenderWavesPerSimd = 6;  // two voxels per lane: 80 VGPRs
 
-__device__ __forceinline__ void store_row4(float *dst, float4 v)
-{
-#if GF_OUT_SC1
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const f32x4 vv = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
-#else
-    *reinterpret_cast<float4 *>(dst) = v;
-#endif
-}
+__device__ __forceinline__ void store_row4(float *dst, float4 v) { *reinterpret_cast<float4 *>(dst) = v; }
 
 template <int VARIANT, int EXP>
-__global__ __launch_bounds__(kBlock, GF_OCC) void gf_splat_render_kernel(RenderArgs a)
+__global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_kernel(RenderArgs a)
 {
     // Workgroup = tile of 8x4 voxel columns x 16 z (512 voxels); wave = 4x4x8 "double brick":
     // lane = (lx, ly, lz) owns the two voxels z = Zw + lz and Zw + 4 + lz.  With two voxels
@@ -836,18 +815,6 @@ __global__ __launch_bounds__(256) void gf_box_volumes_kernel(BoxVolArgs a)
     if (lane_id() == 0 && s) atomicAdd(a.num_rendered, s);
 }
 
-// Experiment hook: extra dynamic LDS per render workgroup caps how many workgroups a CU
-// holds at once (GF_RENDER_DYN_LDS bytes; 0 = no cap).
-static unsigned render_dyn_lds()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GF_RENDER_DYN_LDS");
-        v = e ? atoi(e) : 0;
-    }
-    return (unsigned)v;
-}
-
 template <int VARIANT, int EXP>
 static void launch_render(bool dense_candidate, const RenderArgs &r, hipStream_t stream)
 {
@@ -857,8 +824,7 @@ static void launch_render(bool dense_candidate, const RenderArgs &r, hipStream_t
         hipEvent_t ev0, ev1;
         const bool prof = profile_slot(&ev0, &ev1);
         if (prof) (void)hipEventRecord(ev0, stream);
-        hipLaunchKernelGGL((gf_splat_render_kernel<VARIANT, EXP>), dim3(per_xcd * 8), dim3(kBlock), render_dyn_lds(),
-                           stream, r);
+        hipLaunchKernelGGL((gf_splat_render_kernel<VARIANT, EXP>), dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
         if (prof) (void)hipEventRecord(ev1, stream);
     } else {
         const int blocks = (int)min((long long)4096, ((long long)r.N + kBlock - 1) / kBlock);
