@@ -28,6 +28,7 @@ SIGNATURES = {
     "gf_splat_workspace_bytes": (_sz, [_i] * 5),
     "gf_splat_state_bytes": (_sz, []),
     "gf_splat_forward": (_i, [_i] * 9 + [_vp] * 13 + [_vp, _sz, _vp]),
+    "gf_splat_forward_labels": (_i, [_i] * 9 + [_vp] * 12 + [_i, _f, _i, _vp] + [_vp, _vp, _sz, _vp]),
     "gf_splat_backward": (_i, [_i] * 9 + [_vp] * 20 + [_vp, _sz, _vp]),
     "gf_splat_box_volumes": (_i, [_i] * 5 + [_vp] * 5),
     "gf_daf_forward": (_i, [_i] * 7 + [_vp] * 7),

@@ -292,6 +292,10 @@ struct RenderArgs {
     uint32_t *state;
     unsigned long long *timeline;  // debug: 4 timestamps per workgroup (null = off)
     int P, N, nwords, H, W, D, nsx, nsy, ntiles_total, verify_dense;
+    // optional head epilogue (gf_splat_forward_labels): labels straight from the accumulators
+    long long *out_labels;  // null = off
+    int label_mode, empty_label;
+    float threshold;
 };
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
@@ -459,6 +463,27 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
     return v;
 }
 
+// Head epilogue on the accumulators (model/head/gaussian_head.py:164-185; same rules as
+// gf_head_labels in head_labels.hip): first maximal channel wins.
+template <int VARIANT>
+__device__ __forceinline__ long long label_of(const Acc &S, const RenderArgs &a)
+{
+    const float bin = VARIANT == GF_SPLAT_PROB ? 1 - S.bin : 0.f;
+    float best = 0.f;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < kC; ++c) {
+        float v = S.c[c];
+        if (a.label_mode == GF_LABELS_PROB_GEOSEM) v = c < kC - 1 ? v * bin : 1 - bin;
+        if (c == 0 || v > best) {
+            best = v;
+            arg = c;
+        }
+    }
+    if (a.label_mode == GF_LABELS_PROB_THRESHOLD && !(bin > a.threshold)) arg = a.empty_label;
+    return arg;
+}
+
 // Arbitrary query points: one lane per point, candidates straight from the supertile
 // bitmask in ascending Gaussian order (same per-voxel order as the dense body).
 template <int VARIANT, int EXP>
@@ -497,13 +522,18 @@ __device__ __forceinline__ void general_body(const RenderArgs &a)
         }
         if (VARIANT == GF_SPLAT_PROB) {
             prob_normalise(A);
-            a.out_bin[n] = 1 - A.bin;
-            a.out_density[n] = A.dens;
-            a.out_prob[n] = A.psum;
+            if (a.out_bin) {
+                a.out_bin[n] = 1 - A.bin;
+                a.out_density[n] = A.dens;
+                a.out_prob[n] = A.psum;
+            }
         }
-        float *o = a.out_logits + n * kC;
+        if (a.out_labels) a.out_labels[n] = label_of<VARIANT>(A, a);
+        if (a.out_logits) {
+            float *o = a.out_logits + n * kC;
 #pragma unroll
-        for (int ch = 0; ch < kC; ch += 2) *reinterpret_cast<float2 *>(o + ch) = make_float2(A.c[ch], A.c[ch + 1]);
+            for (int ch = 0; ch < kC; ch += 2) *reinterpret_cast<float2 *>(o + ch) = make_float2(A.c[ch], A.c[ch + 1]);
+        }
     }
 }
 
@@ -735,20 +765,25 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
         if (VARIANT == GF_SPLAT_PROB) {
             prob_normalise(A);
             prob_normalise(B);
-            if (okA) {
+            if (okA && a.out_bin) {
                 a.out_bin[vA] = 1 - A.bin;  // localagg_prob/src/forward.cu:99-101
                 a.out_density[vA] = A.dens;
                 a.out_prob[vA] = A.psum;
             }
-            if (okB) {
+            if (okB && a.out_bin) {
                 a.out_bin[vB] = 1 - B.bin;
                 a.out_density[vB] = B.dens;
                 a.out_prob[vB] = B.psum;
             }
         }
+        if (a.out_labels) {
+            if (okA) a.out_labels[vA] = label_of<VARIANT>(A, a);
+            if (okB) a.out_labels[vB] = label_of<VARIANT>(B, a);
+        }
         // rows -> LDS [voxel-in-brick][18] (wave-private region), then each brick's 16 runs of 4
         // consecutive rows (288 B) are written with 16-B stores; lower brick, then upper brick.
         float *stage = reinterpret_cast<float *>(s_mem) + wave * (64 * kC);
+        if (a.out_logits) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const Acc &S = half == 0 ? A : B;
@@ -781,6 +816,7 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
+        }
         }
         __syncthreads();  // staging is reused as list storage by the next zg
 #if GF_TIMELINE
@@ -854,25 +890,40 @@ extern "C" size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D)
 
 extern "C" size_t gf_splat_state_bytes(void) { return 256; }
 
-extern "C" int gf_splat_forward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
-                                int W, int D, const float *pts, const int *points_int,
-                                const float *means3D, const int *means3D_int, const float *opacity,
-                                const float *semantics, const int *radii, const float *cov3D,
-                                float *out_logits, float *out_bin_logits, float *out_density,
-                                float *out_probability, void *state, void *workspace,
-                                size_t workspace_bytes, void *stream_)
+namespace gf {
+struct LabelOpts {
+    long long *labels;  // null: plain forward
+    int mode, empty_label;
+    float threshold;
+};
+}  // namespace gf
+
+static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
+                              int W, int D, const float *pts, const int *points_int,
+                              const float *means3D, const int *means3D_int, const float *opacity,
+                              const float *semantics, const int *radii, const float *cov3D,
+                              float *out_logits, float *out_bin_logits, float *out_density,
+                              float *out_probability, const gf::LabelOpts &lab, void *state, void *workspace,
+                              size_t workspace_bytes, void *stream_)
 {
     using namespace gf;
+    (void)fn;
     hipStream_t stream = (hipStream_t)stream_;
     GF_CHECK_ARG(variant == GF_SPLAT_BASE || variant == GF_SPLAT_PROB, "unknown variant");
     GF_CHECK_ARG(C == kC, "only 18 semantic channels are supported (NUM_CHANNELS)");
     GF_CHECK_ARG(P >= 0 && N >= 0, "negative size");
     GF_CHECK_ARG(H > 0 && W > 0 && D > 0 && H <= 2047 && W <= 2047 && D <= 1023, "grid size out of range");
     GF_CHECK_ARG((long long)H * W * D < (1ll << 31), "grid too large");
-    GF_CHECK_ARG(N == 0 || (pts && points_int && out_logits), "null point/output pointer");
+    GF_CHECK_ARG(N == 0 || (pts && points_int && (out_logits || lab.labels)), "null point/output pointer");
     GF_CHECK_ARG(P == 0 || (means3D && means3D_int && opacity && semantics && radii && cov3D), "null Gaussian pointer");
-    GF_CHECK_ARG(variant == GF_SPLAT_BASE || N == 0 || (out_bin_logits && out_density && out_probability),
-                 "prob variant needs bin_logits/density/probability outputs");
+    GF_CHECK_ARG(variant == GF_SPLAT_BASE || N == 0 || (out_bin_logits && out_density && out_probability) ||
+                     (lab.labels && !out_logits && !out_bin_logits && !out_density && !out_probability),
+                 "prob variant needs bin_logits/density/probability outputs (all three, or none in labels-only mode)");
+    if (lab.labels) {
+        GF_CHECK_ARG(lab.mode == GF_LABELS_ARGMAX || lab.mode == GF_LABELS_PROB_THRESHOLD || lab.mode == GF_LABELS_PROB_GEOSEM,
+                     "unknown label mode");
+        GF_CHECK_ARG(lab.mode == GF_LABELS_ARGMAX || variant == GF_SPLAT_PROB, "the prob label modes need the prob variant");
+    }
     GF_CHECK_ARG(workspace != nullptr, "null workspace");
     SplatWorkspace ws = carve_workspace(workspace, P, N, H, W, D);
     if (workspace_bytes < ws.total_bytes) {
@@ -907,12 +958,42 @@ extern "C" int gf_splat_forward(int variant, int radii_per_axis, int flags, int 
     ra.H = H; ra.W = W; ra.D = D; ra.nsx = ws.nsx; ra.nsy = ws.nsy; ra.ntiles_total = ws.nsuper * kTilesPerSuper;
     ra.verify_dense = verify ? 1 : 0;
     ra.timeline = g_timeline;
+    ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     if (variant == GF_SPLAT_BASE)
         launch_render_exp<GF_SPLAT_BASE>(flags, dense_candidate, ra, stream);
     else
         launch_render_exp<GF_SPLAT_PROB>(flags, dense_candidate, ra, stream);
     GF_CHECK_LAUNCH();
     return GF_OK;
+}
+
+extern "C" int gf_splat_forward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
+                                int W, int D, const float *pts, const int *points_int,
+                                const float *means3D, const int *means3D_int, const float *opacity,
+                                const float *semantics, const int *radii, const float *cov3D,
+                                float *out_logits, float *out_bin_logits, float *out_density,
+                                float *out_probability, void *state, void *workspace,
+                                size_t workspace_bytes, void *stream)
+{
+    const gf::LabelOpts none{nullptr, 0, 0, 0.f};
+    return splat_forward_impl(__func__, variant, radii_per_axis, flags, P, N, C, H, W, D, pts, points_int, means3D,
+                              means3D_int, opacity, semantics, radii, cov3D, out_logits, out_bin_logits, out_density,
+                              out_probability, none, state, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gf_splat_forward_labels(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
+                                       int W, int D, const float *pts, const int *points_int,
+                                       const float *means3D, const int *means3D_int, const float *opacity,
+                                       const float *semantics, const int *radii, const float *cov3D,
+                                       float *out_logits, float *out_bin_logits, float *out_density,
+                                       float *out_probability, int label_mode, float threshold, int empty_label,
+                                       long long *out_labels, void *state, void *workspace, size_t workspace_bytes,
+                                       void *stream)
+{
+    const gf::LabelOpts lab{out_labels, label_mode, empty_label, threshold};  // out_labels NULL = plain forward
+    return splat_forward_impl(__func__, variant, radii_per_axis, flags, P, N, C, H, W, D, pts, points_int, means3D,
+                              means3D_int, opacity, semantics, radii, cov3D, out_logits, out_bin_logits, out_density,
+                              out_probability, lab, state, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gf_splat_box_volumes(int radii_per_axis, int P, int H, int W, int D,

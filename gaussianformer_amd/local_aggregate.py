@@ -74,6 +74,41 @@ def splat_forward(variant, pts, points_int, means3D, means3D_int, opacities, sem
     return logits, bin_logits, density, probability, state
 
 
+def splat_forward_labels(variant, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
+                         H, W, D, threshold=0.5, empty_label=17, combine_geosem=False, keep_logits=False,
+                         flags=_lib.GF_PTS_AUTO):
+    """Forward splat with the head epilogue folded in (``gf_splat_forward_labels``): returns
+    ``labels`` (int64 ``[N]``), or ``(labels, logits[, bin_logits, density, probability])`` with
+    ``keep_logits``.  Without ``keep_logits`` the 46 MB of logits are never written."""
+    lib = _lib.load()
+    _lib.require_gpu(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D)
+    f32, i32 = torch.float32, torch.int32
+    pts, means3D, opacities, semantics, cov3D = (_contig(t, f32) for t in (pts, means3D, opacities, semantics, cov3D))
+    points_int, means3D_int, radii = (_contig(t, i32) for t in (points_int, means3D_int, radii))
+    N, P, C = pts.shape[0], means3D.shape[0], semantics.shape[1]
+    dev = pts.device
+    prob = variant == _lib.GF_SPLAT_PROB
+    mode = _lib.GF_LABELS_ARGMAX if not prob else (
+        _lib.GF_LABELS_PROB_GEOSEM if combine_geosem else _lib.GF_LABELS_PROB_THRESHOLD)
+    labels = torch.empty(N, dtype=torch.int64, device=dev)
+    logits = torch.empty((N, C), dtype=f32, device=dev) if keep_logits else None
+    extra = [torch.empty(N, dtype=f32, device=dev) for _ in range(3)] if (prob and keep_logits) else [None] * 3
+    state = torch.empty(lib.gf_splat_state_bytes(), dtype=torch.uint8, device=dev)
+    nbytes = lib.gf_splat_workspace_bytes(P, N, H, W, D)
+    ws = _Workspace.get(dev, nbytes)
+    with torch.cuda.device(dev):
+        rc = lib.gf_splat_forward_labels(variant, int(radii.dim() == 2), flags, P, N, C, H, W, D,
+                                         _lib.ptr(pts), _lib.ptr(points_int), _lib.ptr(means3D), _lib.ptr(means3D_int),
+                                         _lib.ptr(opacities), _lib.ptr(semantics), _lib.ptr(radii), _lib.ptr(cov3D),
+                                         _lib.ptr(logits), *[_lib.ptr(e) for e in extra], mode, float(threshold),
+                                         int(empty_label), _lib.ptr(labels), _lib.ptr(state), _lib.ptr(ws), nbytes,
+                                         _lib.current_stream(dev))
+    _lib.check(rc, "gf_splat_forward_labels")
+    if not keep_logits:
+        return labels
+    return (labels, logits, *extra) if prob else (labels, logits)
+
+
 class SplatForwardPlan:
     """Pre-bound forward call for a fixed set of device tensors: outputs, state and workspace
     are allocated once and ``run()`` is a single C-ABI call (no Python-side allocation).

@@ -221,6 +221,18 @@ int gf_head_labels(long long N, int C, int mode, const float *logits, const floa
                    float threshold, int empty_label, long long *labels, void *stream);
 
 /*
+ * gf_splat_forward with the head epilogue folded into the render kernel: the labels are taken from
+ * the accumulators (same rules as gf_head_labels).  out_logits may be NULL (labels only: the
+ * 46 MB logits are never written); for the prob variant the three extra outputs must then be NULL too.
+ */
+int gf_splat_forward_labels(int variant, int radii_per_axis, int flags, int P, int N, int C, int H, int W, int D,
+                            const float *pts, const int *points_int, const float *means3D, const int *means3D_int,
+                            const float *opacity, const float *semantics, const int *radii, const float *cov3D,
+                            float *out_logits, float *out_bin_logits, float *out_density, float *out_probability,
+                            int label_mode, float threshold, int empty_label, long long *out_labels,
+                            void *state, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Fused caller-side preparation of the deformable aggregation.
  * Replaces, in DeformableFeatureAggregation.forward (model/encoder/gaussian_encoder/deformable_module.py):
  *   project_points :268-285 (4x4 projection, depth clamp 1e-5, image_wh normalisation, visibility mask),

@@ -104,3 +104,37 @@ def test_two_rank_sharded_labels_match_single_rank():
     assert np.array_equal(got[0], got[1])
     # world_size 1 path (no process group): plain labels
     assert np.array_equal(sharded_splat_labels(_local_splat_factory(si), *args, labels_fn=lambda lg: lg.argmax(dim=1)).numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,per_axis,dense", [("nuscenes_gs25600_solid", False, True), ("prob_gs6400", False, True),
+                                                   ("prob_gs6400", True, False), ("nuscenes_gs144000", False, False)])
+def test_fused_label_epilogue_matches_separate_kernels(config, per_axis, dense):
+    """gf_splat_forward_labels (labels from the render kernel's accumulators, with and without
+    writing the logits) == gf_splat_forward followed by gf_head_labels, for the dense grid and
+    for arbitrary points, base and prob heads."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.head import occupancy_labels
+    from gaussianformer_amd.local_aggregate import splat_forward, splat_forward_labels
+    from gaussianformer_amd.synthetic import make_splat_inputs
+    from util import prep, to_dev
+    dev = torch.device("cuda:0")
+    si = make_splat_inputs(config, seed=51, P=900, H=40, W=36, D=16, dense_pts=dense, N=None if dense else 5000)
+    pi, mi, radii, cov6 = prep(si, per_axis)
+    t = to_dev(dev, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
+    prob = si.variant == "prob"
+    variant = _lib.GF_SPLAT_PROB if prob else _lib.GF_SPLAT_BASE
+    logits, bl, de, pr, _ = splat_forward(variant, *t, si.H, si.W, si.D)
+    for kw in ([dict()] if not prob else [dict(threshold=0.3), dict(combine_geosem=True)]):
+        want = occupancy_labels(logits, bin_logits=bl, empty_label=17, **kw)
+        got = splat_forward_labels(variant, *t, si.H, si.W, si.D, **kw)
+        assert torch.equal(got, want), kw
+        outs = splat_forward_labels(variant, *t, si.H, si.W, si.D, keep_logits=True, **kw)
+        bits = lambda x: x.view(torch.int32)   # bitwise: the prob config can produce NaN (negative fp32 determinant)
+        assert torch.equal(outs[0], want) and torch.equal(bits(outs[1]), bits(logits))
+        if prob:
+            assert all(torch.equal(bits(a), bits(b)) for a, b in zip(outs[2:], (bl, de, pr)))
