@@ -24,6 +24,9 @@
 
 namespace gf {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+
 struct BwdArgs {
     const float *pts;
     const int *points_int;
@@ -436,20 +439,28 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
                 const float dx = mx - ptx, dy = my - pty, dz = mz - ptz;
                 float power = c1x * dx * dx + c1y * dy * dy + c1z * dz * dz;
                 power = -0.5f * power - (c2x * dx * dy + c2y * dy * dz + c2z * dx * dz);
-                const float e = expf(power);
+                // base: exp via v_exp_f32 (2^(x log2 e)); the argument's rounding adds ~|power| * 6e-8 relative
+                // error.  prob keeps ocml expf: its gradient divides by 1 - e + 1e-9 (backward.cu:93).
+                const float e = VARIANT == GF_SPLAT_PROB ? expf(power) : __builtin_amdgcn_exp2f(power * 1.44269504088896340736f);
                 const float sx = c1x * dx + c2x * dy + c2z * dz;  // (Sigma^-1 d)
                 const float sy = c2x * dx + c1y * dy + c2y * dz;
                 const float sz = c2z * dx + c2y * dy + c1z * dz;
                 if (VARIANT == GF_SPLAT_BASE) {
                     // model/head/localagg/src/backward.cu:72-87, with the channel sum factored
                     // out of the six covariance and three mean accumulators.
-                    float S = 0.f;
+                    // two channels per instruction (v_pk_fma_f32); S is summed pairwise, then across the pair
                     const float oe = opa * e;
+                    f32x2 S2 = {0.f, 0.f};
 #pragma unroll
-                    for (int ch = 0; ch < kC; ++ch) {
-                        S += sem[ch] * dL[ch];
-                        sg[ch] += oe * dL[ch];
+                    for (int ch = 0; ch < kC; ch += 2) {
+                        const f32x2 d2 = {dL[ch], dL[ch + 1]};
+                        const f32x2 s2 = {sem[ch], sem[ch + 1]};
+                        S2 = __builtin_elementwise_fma(s2, d2, S2);
+                        f32x2 g2 = {sg[ch], sg[ch + 1]};
+                        g2 = __builtin_elementwise_fma((f32x2){oe, oe}, d2, g2);
+                        sg[ch] = g2.x; sg[ch + 1] = g2.y;
                     }
+                    const float S = S2.x + S2.y;
                     const float T = e * S;
                     og += T;
                     const float K = opa * T;
