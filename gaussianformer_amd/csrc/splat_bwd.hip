@@ -69,13 +69,17 @@ __device__ __forceinline__ void stage_issue(const float *__restrict__ src, int p
     s_pidx[lane] = p;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // rows of lanes without a point (p = -1, tail of a segment) are fetched from row 0 and never
+    // used: unconditional loads keep the nine requests back to back instead of nine
+    // read-LDS / wait / branch / load sequences
+    int pr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pr[k] = s_pidx[(lane + 64 * k) / 9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int q = lane + 64 * k;
-        const int r = q / 9, part = q - 9 * r;
-        const int pr = s_pidx[r];
-        raw[k] = make_float2(0.f, 0.f);
-        if (pr >= 0) raw[k] = *reinterpret_cast<const float2 *>(src + (size_t)pr * kC + 2 * part);
+        const int part = q - 9 * (q / 9);
+        raw[k] = *reinterpret_cast<const float2 *>(src + (size_t)max(pr[k], 0) * kC + 2 * part);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
