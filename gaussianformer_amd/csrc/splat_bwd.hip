@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
         float ptx = 0.f, pty = 0.f, ptz = 0.f, ptx_n = 0.f, pty_n = 0.f, ptz_n = 0.f;
         int p = point_of(i, x, y, z), p_n = -1;
         stage_issue(a.out_grad, p, raw, s_pidx, lane);
-        if (p >= 0) { ptx = a.pts[3 * (size_t)p]; pty = a.pts[3 * (size_t)p + 1]; ptz = a.pts[3 * (size_t)p + 2]; }
+        { const size_t pc = (size_t)max(p, 0); ptx = a.pts[3 * pc]; pty = a.pts[3 * pc + 1]; ptz = a.pts[3 * pc + 2]; }  // unconditional, see stage_issue
         for (int base = o0; base < o1; base += 64) {  // wave-uniform trip count
             stage_finish(raw, dL, s_rows, lane);
             float lg[kC];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
             i += 64;
             p_n = point_of(i, x, y, z);
             stage_issue(a.out_grad, p_n, raw, s_pidx, lane);
-            if (p_n >= 0) { ptx_n = a.pts[3 * (size_t)p_n]; pty_n = a.pts[3 * (size_t)p_n + 1]; ptz_n = a.pts[3 * (size_t)p_n + 2]; }
+            { const size_t pc = (size_t)max(p_n, 0); ptx_n = a.pts[3 * pc]; pty_n = a.pts[3 * pc + 1]; ptz_n = a.pts[3 * pc + 2]; }
             if (p >= 0) {
                 const float dx = mx - ptx, dy = my - pty, dz = mz - ptz;
                 float power = c1x * dx * dx + c1y * dy * dy + c1z * dz * dz;
