@@ -465,21 +465,25 @@ __global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
             if (p0 == p1) continue;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (uint32_t pb = p0; pb < p1; pb += UNR) {
-                float4 go[UNR];
-                float wt[UNR], c[UNR];
+                // ids and coefficients first (LDS), then all loads back to back; slots past the end of
+                // the row re-read its last tap with a zero coefficient instead of branching
+                uint32_t q[UNR];
+                float c[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    go[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    wt[u] = 0.f; c[u] = 0.f;
-                    if (pb + u < p1) {
-                        const uint32_t q = s_id[pb + u] >> 2;
-                        const int s = (int)(q & lvl_mask);
-                        const uint32_t pc = q >> a.lvl_bits;
-                        const uint32_t cam = pc & cam_mask, pt = pc >> a.cam_bits;
-                        c[u] = s_cw[pb + u];
-                        wt[u] = a.weights[(((size_t)pt * a.cams + cam) * a.L + s) * a.G + group];
-                        go[u] = *reinterpret_cast<const float4 *>(a.grad_out + (size_t)pt * a.C + c0);
-                    }
+                    const uint32_t pi = min(pb + u, p1 - 1);
+                    q[u] = s_id[pi] >> 2;
+                    c[u] = pb + u < p1 ? s_cw[pi] : 0.f;
+                }
+                float4 go[UNR];
+                float wt[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int s = (int)(q[u] & lvl_mask);
+                    const uint32_t pc = q[u] >> a.lvl_bits;
+                    const uint32_t cam = pc & cam_mask, pt = pc >> a.cam_bits;
+                    wt[u] = a.weights[(((size_t)pt * a.cams + cam) * a.L + s) * a.G + group];
+                    go[u] = *reinterpret_cast<const float4 *>(a.grad_out + (size_t)pt * a.C + c0);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
