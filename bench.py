@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="nuscenes_gs25600_solid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-stream", action="store_true",
+                    help="skip the extra two-frames-in-flight measurement (used for the rocprofv3 kernel trace, whose "
+                         "per-kernel average would otherwise mix overlapped and sequential launches)")
     args = ap.parse_args()
 
     import torch
@@ -150,7 +153,7 @@ def main():
     # start and the tail of one step overlap the render kernel of the other.  Reported next to
     # `value` (which stays the strict one-step-at-a-time figure), never instead of it.
     two_stream = None
-    if world == 1:
+    if world == 1 and not args.no_two_stream:
         plans = [plan, SplatForwardPlan(variant, *t, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO)]
         streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
         for i in range(2 * max(2, args.warmup // 2)):

@@ -486,7 +486,7 @@ __device__ __forceinline__ long long label_of(const Acc &S, const RenderArgs &a)
 
 // Arbitrary query points: one lane per point, candidates straight from the supertile
 // bitmask in ascending Gaussian order (same per-voxel order as the dense body).
-template <int VARIANT, int EXP>
+template <int VARIANT, int EXP, bool LABELS>
 __device__ __forceinline__ void general_body(const RenderArgs &a)
 {
     for (long long n = (long long)blockIdx.x * kBlock + threadIdx.x; n < a.N; n += (long long)gridDim.x * kBlock) {
@@ -522,14 +522,14 @@ __device__ __forceinline__ void general_body(const RenderArgs &a)
         }
         if (VARIANT == GF_SPLAT_PROB) {
             prob_normalise(A);
-            if (a.out_bin) {
+            if (!LABELS || a.out_bin) {
                 a.out_bin[n] = 1 - A.bin;
                 a.out_density[n] = A.dens;
                 a.out_prob[n] = A.psum;
             }
         }
-        if (a.out_labels) a.out_labels[n] = label_of<VARIANT>(A, a);
-        if (a.out_logits) {
+        if (LABELS) a.out_labels[n] = label_of<VARIANT>(A, a);
+        if (!LABELS || a.out_logits) {
             float *o = a.out_logits + n * kC;
 #pragma unroll
             for (int ch = 0; ch < kC; ch += 2) *reinterpret_cast<float2 *>(o + ch) = make_float2(A.c[ch], A.c[ch + 1]);
@@ -537,18 +537,20 @@ __device__ __forceinline__ void general_body(const RenderArgs &a)
     }
 }
 
-template <int VARIANT, int EXP>
+template <int VARIANT, int EXP, bool LABELS>
 __global__ __launch_bounds__(kBlock) void gf_splat_render_general_kernel(RenderArgs a)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.state) a.state[0] = 1u;
-    general_body<VARIANT, EXP>(a);
+    general_body<VARIANT, EXP, LABELS>(a);
 }
 
 constexpr int kRenderWavesPerSimd = 6;  // two voxels per lane: 80 VGPRs
 
 __device__ __forceinline__ void store_row4(float *dst, float4 v) { *reinterpret_cast<float4 *>(dst) = v; }
 
-template <int VARIANT, int EXP>
+// LABELS: the head epilogue variant (gf_splat_forward_labels); a separate instantiation so that the
+// plain forward keeps its register allocation (the runtime-optional epilogue cost 16 B of scratch).
+template <int VARIANT, int EXP, bool LABELS>
 __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_kernel(RenderArgs a)
 {
     // Workgroup = tile of 8x4 voxel columns x 16 z (512 voxels); wave = 4x4x8 "double brick":
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
     if (a.verify_dense) nondense = __syncthreads_or((vf.x | vf.y | vf.z | vf.w) != 0u);
     if (blockIdx.x == 0 && tid == 0 && a.state) a.state[0] = nondense ? 1u : 0u;
     if (nondense) {
-        general_body<VARIANT, EXP>(a);
+        general_body<VARIANT, EXP, LABELS>(a);
         return;
     }
     if (!tile_ok) return;
@@ -765,25 +767,25 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
         if (VARIANT == GF_SPLAT_PROB) {
             prob_normalise(A);
             prob_normalise(B);
-            if (okA && a.out_bin) {
+            if (okA && (!LABELS || a.out_bin)) {
                 a.out_bin[vA] = 1 - A.bin;  // localagg_prob/src/forward.cu:99-101
                 a.out_density[vA] = A.dens;
                 a.out_prob[vA] = A.psum;
             }
-            if (okB && a.out_bin) {
+            if (okB && (!LABELS || a.out_bin)) {
                 a.out_bin[vB] = 1 - B.bin;
                 a.out_density[vB] = B.dens;
                 a.out_prob[vB] = B.psum;
             }
         }
-        if (a.out_labels) {
+        if (LABELS) {
             if (okA) a.out_labels[vA] = label_of<VARIANT>(A, a);
             if (okB) a.out_labels[vB] = label_of<VARIANT>(B, a);
         }
         // rows -> LDS [voxel-in-brick][18] (wave-private region), then each brick's 16 runs of 4
         // consecutive rows (288 B) are written with 16-B stores; lower brick, then upper brick.
         float *stage = reinterpret_cast<float *>(s_mem) + wave * (64 * kC);
-        if (a.out_logits) {
+        if (!LABELS || a.out_logits) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const Acc &S = half == 0 ? A : B;
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(256) void gf_box_volumes_kernel(BoxVolArgs a)
     if (lane_id() == 0 && s) atomicAdd(a.num_rendered, s);
 }
 
-template <int VARIANT, int EXP>
+template <int VARIANT, int EXP, bool LABELS>
 static void launch_render(bool dense_candidate, const RenderArgs &r, hipStream_t stream)
 {
     if (dense_candidate) {
@@ -860,20 +862,26 @@ static void launch_render(bool dense_candidate, const RenderArgs &r, hipStream_t
         hipEvent_t ev0, ev1;
         const bool prof = profile_slot(&ev0, &ev1);
         if (prof) (void)hipEventRecord(ev0, stream);
-        hipLaunchKernelGGL((gf_splat_render_kernel<VARIANT, EXP>), dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
+        hipLaunchKernelGGL((gf_splat_render_kernel<VARIANT, EXP, LABELS>), dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
         if (prof) (void)hipEventRecord(ev1, stream);
     } else {
         const int blocks = (int)min((long long)4096, ((long long)r.N + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL((gf_splat_render_general_kernel<VARIANT, EXP>), dim3(blocks), dim3(kBlock), 0, stream, r);
+        hipLaunchKernelGGL((gf_splat_render_general_kernel<VARIANT, EXP, LABELS>), dim3(blocks), dim3(kBlock), 0, stream, r);
     }
 }
 
 template <int VARIANT>
 static void launch_render_exp(int flags, bool dense_candidate, const RenderArgs &r, hipStream_t stream)
 {
-    if (flags & GF_LIBM_EXP) launch_render<VARIANT, kExpLibm>(dense_candidate, r, stream);
-    else if (flags & GF_COMP_EXP) launch_render<VARIANT, kExpComp>(dense_candidate, r, stream);
-    else launch_render<VARIANT, kExpFast>(dense_candidate, r, stream);
+    if (r.out_labels) {
+        if (flags & GF_LIBM_EXP) launch_render<VARIANT, kExpLibm, true>(dense_candidate, r, stream);
+        else if (flags & GF_COMP_EXP) launch_render<VARIANT, kExpComp, true>(dense_candidate, r, stream);
+        else launch_render<VARIANT, kExpFast, true>(dense_candidate, r, stream);
+        return;
+    }
+    if (flags & GF_LIBM_EXP) launch_render<VARIANT, kExpLibm, false>(dense_candidate, r, stream);
+    else if (flags & GF_COMP_EXP) launch_render<VARIANT, kExpComp, false>(dense_candidate, r, stream);
+    else launch_render<VARIANT, kExpFast, false>(dense_candidate, r, stream);
 }
 
 }  // namespace gf
