@@ -381,8 +381,11 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
         float deter = 1.f, kdet = 0.f;
         if (VARIANT == GF_SPLAT_PROB) {
             // model/head/localagg_prob/src/backward.cu:78-79
-            deter = c1x * c1y * c1z + 2 * c2x * c2y * c2z - c1x * c2y * c2y - c1y * c2z * c2z - c1z * c2x * c2x;
-            kdet = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f);
+            // in fp64, like the forward's prob_kdet (the fp32 sum cancels by orders of magnitude)
+            const double det64 = (double)c1x * c1y * c1z + 2.0 * c2x * c2y * c2z - (double)c1x * c2y * c2y -
+                                 (double)c1y * c2z * c2z - (double)c1z * c2x * c2x;
+            deter = (float)det64;
+            kdet = (float)(0.063493635934240969 * sqrt(det64));  // (2 pi)^-1.5 sqrt(det)
         }
 
         float mg0 = 0.f, mg1 = 0.f, mg2 = 0.f, og = 0.f, dg = 0.f;

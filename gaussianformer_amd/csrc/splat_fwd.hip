@@ -72,6 +72,18 @@ __device__ __forceinline__ void gaussian_box(const int *__restrict__ means_int, 
     lo[2] = min(D, max(0, m2 - r2)); hi[2] = min(D, max(0, m2 + r2 + 1));
 }
 
+// (2 pi)^-1.5 sqrt(det Sigma^-1), model/head/localagg_prob/src/forward.cu:77-78.  The determinant of
+// an ill-conditioned Sigma^-1 (scales down to 0.01 m) is a sum that cancels by many orders of
+// magnitude: in fp32 its value depends on the compiler's FMA contraction (nvcc, gcc and hipcc all
+// differ, and it can even come out negative -> NaN).  One fp64 evaluation per Gaussian costs
+// nothing and removes that noise; the result is the correctly rounded value the fp32 expression
+// approximates.
+__device__ __forceinline__ float prob_kdet(float c0, float c1, float c2, float c3, float c4, float c5)
+{
+    const double deter = (double)c0 * c1 * c2 + 2.0 * c3 * c4 * c5 - (double)c0 * c4 * c4 - (double)c1 * c5 * c5 - (double)c2 * c3 * c3;
+    return (float)(0.063493635934240969 * sqrt(deter));  // (2 pi)^-1.5
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
 {
@@ -144,8 +156,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             float kdet = 0.f;
             if (a.variant == GF_SPLAT_PROB) {
                 // model/head/localagg_prob/src/forward.cu:77-78
-                const float deter = c0 * c1 * c2 + 2 * c3 * c4 * c5 - c0 * c4 * c4 - c1 * c5 * c5 - c2 * c3 * c3;
-                kdet = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f);
+                kdet = prob_kdet(c0, c1, c2, c3, c4, c5);
             }
             const float *sm = a.semantics + (size_t)kC * g;
             float4 *rec = reinterpret_cast<float4 *>(a.records + (size_t)g * kRecDwords);
@@ -214,8 +225,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             float kdet = 0.f;
             if (a.variant == GF_SPLAT_PROB) {
                 // model/head/localagg_prob/src/forward.cu:77-78
-                const float deter = c0 * c1 * c2 + 2 * c3 * c4 * c5 - c0 * c4 * c4 - c1 * c5 * c5 - c2 * c3 * c3;
-                kdet = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f);
+                kdet = prob_kdet(c0, c1, c2, c3, c4, c5);
             }
             float4 *rec = reinterpret_cast<float4 *>(row);
             rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opacity[g]);
