@@ -117,3 +117,39 @@ def test_feature_maps_format_roundtrip(gpu):
     back = DAF.feature_maps_format([col, ss, st], inverse=True)
     for a, b in zip(maps, back):
         assert torch.equal(a, b)
+
+
+def test_daf_random_shapes_sweep(gpu):
+    """Randomised sweep over batch, cameras, channels/groups, pyramid shapes and point counts
+    (pixel-major and scatter backward paths, every lane layout) against the oracle."""
+    import os
+    import torch
+    from gaussianformer_amd.deformable_aggregation import DeformableAggregationFunction as DAF
+    rng = np.random.default_rng(int(os.environ.get("GF_SWEEP_SEED", "77")))
+    for trial in range(int(os.environ.get("GF_SWEEP_TRIALS", "12"))):
+        G = int(rng.choice([1, 2, 4, 8]))
+        C = G * int(rng.choice([1, 2, 3, 4, 8, 16, 32]))
+        if C > 256:
+            C = 256
+            G = int(rng.choice([4, 8]))
+        nl = int(rng.integers(1, 5))
+        levels = tuple((int(rng.integers(1, 30)), int(rng.integers(1, 40))) for _ in range(nl))
+        case = dict(num_pts=int(rng.integers(1, 1500)), B=int(rng.integers(1, 4)), cams=int(rng.integers(1, 7)), C=C, G=G,
+                    levels=levels)
+        d = make_daf_inputs(seed=500 + trial, **case)
+        try:
+            ref = oracle.daf_forward(**d)
+            feat, ss, st, loc, w = to_dev(gpu, d["mc_ms_feat"], d["spatial_shape"], d["scale_start_index"],
+                                          d["sampling_location"], d["weights"])
+            feat.requires_grad_(True); loc.requires_grad_(True); w.requires_grad_(True)
+            out = DAF.apply(feat, ss, st, loc, w)
+            assert_logits_close(out.detach().cpu().numpy(), ref, what="daf output")
+            g = rng.standard_normal(ref.shape).astype(np.float32)
+            out.backward(torch.from_numpy(g).to(gpu))
+            gf, gl, gw = oracle.daf_backward(d["mc_ms_feat"], d["spatial_shape"], d["scale_start_index"],
+                                             d["sampling_location"], d["weights"], g)
+            assert_grad_close(feat.grad.cpu().numpy(), gf, "grad_mc_ms_feat")
+            assert_grad_close(loc.grad.cpu().numpy(), gl, "grad_sampling_location")
+            assert_grad_close(w.grad.cpu().numpy(), gw, "grad_weights")
+        except AssertionError as e:
+            raise AssertionError(f"trial {trial}: {case}: {e}")
