@@ -1,43 +1,48 @@
 """TEST INFRASTRUCTURE ONLY -- torch restatement of the caller-side preparation of the
 deformable aggregation; never imported by the product.
 
-``project_points`` follows DeformableFeatureAggregation.project_points
-(model/encoder/gaussian_encoder/deformable_module.py:268-285); ``prepare`` follows the body of
-``forward`` between ``_get_weights`` and ``DAF.apply`` (:174-214), op for op, so autograd gives
-the reference gradients.  ``project_points`` is pinned against tests/golden/daf_prepare.npz,
-produced by executing the reference's own function (tools/make_golden_daf_prepare.py).
+``project_points`` states what DeformableFeatureAggregation.project_points computes
+(model/encoder/gaussian_encoder/deformable_module.py:268-285); ``prepare`` states what the body of
+``forward`` computes between ``_get_weights`` and ``DAF.apply`` (:174-214).  Everything is plain
+differentiable torch, so autograd supplies the reference gradients.  ``project_points`` is pinned
+bit for bit against tests/golden/daf_prepare.npz, which tools/make_golden_daf_prepare.py produced
+by executing the reference's own function.
 """
 import torch
 
+DEPTH_EPS = 1e-5  # :277, :281
+
 
 def project_points(key_points, projection_mat, image_wh=None):
-    """:268-285"""
-    pts_extend = torch.cat([key_points, torch.ones_like(key_points[..., :1])], dim=-1)
-    points_2d = torch.matmul(projection_mat[:, :, None, None], pts_extend[:, None, ..., None]).squeeze(-1)
-    depth = points_2d[..., 2]
-    points_2d = points_2d[..., :2] / torch.clamp(points_2d[..., 2:3], min=1e-5)
+    """key_points [b, A, p, 3], projection_mat [b, cams, 4, 4], image_wh [b, cams, 2] | None
+    -> (uv [b, cams, A, p, 2], visible [b, cams, A, p])."""
+    b, A, p, _ = key_points.shape
+    homogeneous = torch.cat([key_points, key_points.new_ones(b, A, p, 1)], dim=-1)
+    # every camera matrix applied to every point: [b, cams, 1, 1, 4, 4] @ [b, 1, A, p, 4, 1]
+    cam_space = torch.matmul(projection_mat[:, :, None, None], homogeneous[:, None, :, :, :, None])[..., 0]
+    depth = cam_space[..., 2]
+    uv = cam_space[..., 0:2] / cam_space[..., 2:3].clamp(min=DEPTH_EPS)
     if image_wh is not None:
-        points_2d = points_2d / image_wh[:, :, None, None]
-    mask = (depth > 1e-5) & (points_2d[..., 0] > 0) & (points_2d[..., 0] < 1) & \
-        (points_2d[..., 1] > 0) & (points_2d[..., 1] < 1)
-    return points_2d, mask
+        uv = uv / image_wh[:, :, None, None, :]
+    u, v = uv[..., 0], uv[..., 1]
+    visible = (depth > DEPTH_EPS) & (u > 0) & (u < 1) & (v > 0) & (v < 1)
+    return uv, visible
 
 
 def prepare(key_points, projection_mat, image_wh, weights, weight_mask=None):
-    """:174-214.  weights: [bs, A, cams, L, pts, G] as returned by _get_weights (:243-253)."""
-    bs, num_anchor, num_cams, num_levels, num_pts, num_groups = weights.shape
-    if weight_mask is None:
-        weight_mask = torch.ones_like(weights) > 0
-    weights = weights.permute(0, 1, 4, 2, 3, 5).contiguous().reshape(bs, num_anchor, num_pts, num_cams, num_levels, num_groups)
-    weight_mask = weight_mask.permute(0, 1, 4, 2, 3, 5).contiguous().reshape(weights.shape)
-    points_2d, mask = project_points(key_points, projection_mat, image_wh)
-    points_2d = points_2d.permute(0, 2, 3, 1, 4).reshape(bs, num_anchor * num_pts, num_cams, 2)
-    mask = mask.permute(0, 2, 3, 1)
-    mask = mask[..., None, None] & weight_mask
-    all_miss = mask.sum(dim=[2, 3, 4], keepdim=True) == 0
-    all_miss = all_miss.expand(-1, -1, num_pts, num_cams, num_levels, -1)
-    weights = weights.masked_fill(~mask, -torch.inf)      # weights[~mask] = -inf
-    weights = weights.masked_fill(all_miss, 0.0)          # weights[all_miss] = 0.
-    weights = weights.flatten(2, 4).softmax(dim=-2).reshape(bs, num_anchor * num_pts, num_cams, num_levels, num_groups)
-    weights = weights * (1 - all_miss.flatten(1, 2).float())
-    return points_2d, weights
+    """weights: raw attention logits [b, A, cams, L, p, G] (the layout `_get_weights` returns,
+    :243-253); weight_mask: bool keep-mask of the same shape or None.
+    -> (points_2d [b, A*p, cams, 2], weights [b, A*p, cams, L, G])."""
+    b, A, cams, L, p, G = weights.shape
+    # [b, A, cams, L, p, G] -> [b, A, p, cams, L, G]  (:176-193)
+    logits = weights.permute(0, 1, 4, 2, 3, 5)
+    keep = torch.ones_like(logits, dtype=torch.bool) if weight_mask is None else weight_mask.permute(0, 1, 4, 2, 3, 5)
+    uv, visible = project_points(key_points, projection_mat, image_wh)
+    points_2d = uv.permute(0, 2, 3, 1, 4).reshape(b, A * p, cams, 2)                     # :199-200
+    usable = visible.permute(0, 2, 3, 1)[..., None, None] & keep                          # [b, A, p, cams, L, G] (:201-202)
+    nothing = ~usable.flatten(2, 4).any(dim=2)                                            # [b, A, G]: no usable entry at all (:203)
+    nothing6 = nothing[:, :, None, None, None, :].expand_as(usable)
+    logits = logits.masked_fill(~usable, float("-inf")).masked_fill(nothing6, 0.0)        # :205-206
+    soft = logits.flatten(2, 4).softmax(dim=2)                                            # over (p, cams, L) per group (:207)
+    soft = soft * (~nothing)[:, :, None, :].to(soft.dtype)                                # :214
+    return points_2d, soft.reshape(b, A, p, cams, L, G).reshape(b, A * p, cams, L, G)
