@@ -11,4 +11,7 @@ timeout 300 python tools/timeline.py > gpurun_out/profiles_$R/timeline_render_$R
 ./tools/microbench/mfma > gpurun_out/profiles_$R/microbench_mfma_$R.txt 2>&1
 rm -rf gpurun_out/kt_daf; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_daf -- python tools/prof_daf.py > gpurun_out/kt_daf.log 2>&1; cp $(find gpurun_out/kt_daf -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_daf_$R.csv
 rm -rf gpurun_out/kt_q; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_q -- python tools/quick_time.py nuscenes_gs25600_solid > gpurun_out/profiles_$R/quick_time_gs25600_$R.log 2>&1; cp $(find gpurun_out/kt_q -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_ops_gs25600_$R.csv
+# BASELINE config [3]: nuscenes_gs144000 inference
+python bench.py --config nuscenes_gs144000 --no-cpu-baseline > gpurun_out/profiles_$R/bench_gs144000_$R.json 2> gpurun_out/bench_gs144000.err
+rm -rf gpurun_out/kt_144; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_144 -- python bench.py --config nuscenes_gs144000 --no-cpu-baseline --no-two-stream > gpurun_out/kt_144.log 2>&1; cp $(find gpurun_out/kt_144 -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_bench_gs144000_$R.csv
 cp gpurun_out/pytest_gpu_$R.log gpurun_out/smoke_$R.log gpurun_out/profiles_$R/
