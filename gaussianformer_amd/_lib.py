@@ -35,6 +35,7 @@ SIGNATURES = {
     "gf_daf_backward": (_i, [_i] * 7 + [_vp] * 10),
     "gf_daf_backward_workspace_bytes": (_sz, [_i] * 7),
     "gf_daf_backward_sorted": (_i, [_i] * 7 + [_vp] * 9 + [_vp, _sz, _vp]),
+    "gf_feature_maps_format": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "gf_head_labels": (_i, [ctypes.c_longlong, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),
     "gf_daf_prepare": (_i, [_i] * 6 + [_vp] * 7 + [_vp]),
     "gf_daf_prepare_backward": (_i, [_i] * 6 + [_vp] * 8 + [_vp]),

@@ -71,6 +71,41 @@ def deformable_aggregation_backward(mc_ms_feat, spatial_shape, scale_start_index
     _lib.check(rc, "gf_daf_backward")
 
 
+def _format_call(levels, table, inverse):
+    """gf_feature_maps_format on contiguous fp32 CUDA tensors: levels [bs,cams,C,h,w], table [bs,cams,num_feat,C]."""
+    import ctypes
+    lib = _lib.load()
+    bs, cams, C = levels[0].shape[:3]
+    L = len(levels)
+    hw = (ctypes.c_int * L)(*[int(f.shape[3] * f.shape[4]) for f in levels])
+    ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in levels])
+    with torch.cuda.device(table.device):
+        rc = lib.gf_feature_maps_format(bs * cams, C, L, ctypes.cast(hw, ctypes.c_void_p), ctypes.cast(ptrs, ctypes.c_void_p),
+                                        _lib.ptr(table), int(inverse), _lib.current_stream(table.device))
+    _lib.check(rc, "gf_feature_maps_format")
+
+
+class _FeatureMapsFormat(Function):
+    """levels -> channels-last table in one tiled-transpose launch; backward = the inverse launch."""
+
+    @staticmethod
+    def forward(ctx, *feature_maps):
+        levels = [f.contiguous().float() for f in feature_maps]
+        bs, cams, C = levels[0].shape[:3]
+        ctx.shapes = [tuple(f.shape) for f in levels]
+        num_feat = sum(s[3] * s[4] for s in ctx.shapes)
+        table = torch.empty(bs, cams, num_feat, C, dtype=torch.float32, device=levels[0].device)
+        _format_call(levels, table, inverse=False)
+        return table
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_table):
+        grads = [torch.empty(s, dtype=torch.float32, device=grad_table.device) for s in ctx.shapes]
+        _format_call(grads, grad_table.contiguous().float(), inverse=True)
+        return tuple(grads)
+
+
 class DeformableAggregationFunction(Function):
     """ops/deformable_aggregation.py:7-117."""
 
@@ -110,8 +145,12 @@ class DeformableAggregationFunction(Function):
             for h, w in shapes:
                 starts.append(run)
                 run += h * w
-            flat = [f.reshape(bs, num_cams, f.shape[2], -1) for f in feature_maps]
-            col_feats = torch.cat(flat, dim=-1).permute(0, 1, 3, 2)
+            if feature_maps[0].is_cuda and len(feature_maps) <= 8 and all(f.dtype == torch.float32 for f in feature_maps):
+                # one tiled-transpose launch (gf_feature_maps_format), already contiguous for DAF.apply
+                col_feats = _FeatureMapsFormat.apply(*feature_maps)
+            else:
+                flat = [f.reshape(bs, num_cams, f.shape[2], -1) for f in feature_maps]
+                col_feats = torch.cat(flat, dim=-1).permute(0, 1, 3, 2)
             dev = col_feats.device
             return [col_feats,
                     torch.tensor(shapes, dtype=torch.int64, device=dev),

@@ -206,6 +206,15 @@ int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, int L, int 
  * gf_profile_enable(0) disables and frees.  Not part of the reference interface.
  */
 int gf_profile_enable(int max_records);
+/*
+ * feature_maps_format (model/encoder/gaussian_encoder/ops/deformable_aggregation.py:77-117): L image-feature levels
+ * [planes, C, hw_l] (planes = bs * cams, contiguous) <-> one channels-last table [planes, sum_l hw_l, C], level l
+ * starting at row sum_{k<l} hw_k.  inverse = 0 fills the table from the levels, inverse = 1 the levels from the
+ * table (the backward of the former).  hw and levels are HOST arrays (L <= 8 ints / device pointers).
+ */
+int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const *levels, float *table,
+                           int inverse, void *stream);
+
 /* modes of gf_head_labels */
 #define GF_LABELS_ARGMAX 0          /* base head: argmax over the 18 logits (gaussian_head.py:185) */
 #define GF_LABELS_PROB_THRESHOLD 1  /* prob head: argmax where bin_logits > threshold, else empty_label (:178-183) */

@@ -117,6 +117,18 @@ def test_feature_maps_format_roundtrip(gpu):
     back = DAF.feature_maps_format([col, ss, st], inverse=True)
     for a, b in zip(maps, back):
         assert torch.equal(a, b)
+    # the tiled-transpose kernel against the reference's cat + permute (deformable_aggregation.py:77-100),
+    # odd sizes (partial 32x32 tiles), several batch elements, and its gradient (the inverse transpose)
+    maps = [torch.randn(2, 3, 37, h, w, device=gpu, requires_grad=True) for h, w in ((9, 13), (5, 7), (1, 1))]
+    col, ss, st = DAF.feature_maps_format(maps)
+    want = torch.cat([f.reshape(2, 3, 37, -1) for f in maps], dim=-1).permute(0, 1, 3, 2)
+    assert col.is_contiguous() and torch.equal(col, want)
+    assert ss.tolist() == [[9, 13], [5, 7], [1, 1]] and st.tolist() == [0, 117, 152]
+    g = torch.randn_like(col)
+    got = torch.autograd.grad(col, maps, g)
+    ref = torch.autograd.grad(want, maps, g)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
 
 
 def test_daf_random_shapes_sweep(gpu):

@@ -92,6 +92,13 @@ report("head_labels (fused argmax, module-level call)", "N=640000", sec, 640000 
 sec = timed(lambda: lg[None].transpose(1, 2).argmax(dim=1))
 report("head_labels (reference: transposed-view torch argmax on the same GPU)", "N=640000", sec, 640000 * (72 + 8), {"N": 640000})
 
+maps = [torch.randn(1, 6, 128, h, w, device=dev) for h, w in ((108, 200), (54, 100), (27, 50), (14, 25))]
+from gaussianformer_amd.deformable_aggregation import DeformableAggregationFunction as _DAF  # noqa: E402
+sec = timed(lambda: _DAF.feature_maps_format(maps)[0])
+report("feature_maps_format (tiled transpose, module-level call)", "nuScenes pyramid", sec, 2 * 4 * sum(m.numel() for m in maps), {})
+sec = timed(lambda: torch.cat([f.reshape(1, 6, 128, -1) for f in maps], dim=-1).permute(0, 1, 3, 2).contiguous())
+report("feature_maps_format (reference: cat + permute + contiguous on the same GPU)", "nuScenes pyramid", sec, 2 * 4 * sum(m.numel() for m in maps), {})
+
 DAF_CASES = () if "--splat-only" in sys.argv else ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000"))
 for pts, name in DAF_CASES:
     d = make_daf_inputs(num_pts=pts, seed=0)
