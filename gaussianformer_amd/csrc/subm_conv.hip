@@ -1,0 +1,556 @@
+// Submanifold sparse 3-D convolution over the Gaussian centres: the op behind
+// SparseConv3D (model/encoder/gaussian_encoder/spconv3d_module.py:10-83 -- spconv.SubMConv3d with
+// kernel 5, stride 1, padding 2, no bias, on a 0.5 m grid).  spconv is a third-party dependency that
+// is not in the reference tree and has no ROCm build, so this restates the published algorithm:
+//
+//     out[i] = sum_k  sum_{j : cell(j) = cell(i) + offset_k}  feat[j] . W[k]        (k over the K^3 offsets)
+//
+// i.e. a dense K^3 convolution evaluated only at the occupied cells.  Several points may share a
+// cell (25 600 centres in 409 600 cells: a few hundred do); they all contribute and each of them
+// receives the cell's output -- exactly what a dense convolution of the scattered-and-summed
+// features gives (that is the oracle in tests/test_subm_conv.py).
+//
+// Pipeline (all on the device; the pair count is the only value the host reads, like spconv):
+//   grid     : head[cell] / next[point] linked lists (atomicExch), cells in a dense int table
+//   count    : per offset k, how many (out i, in j) pairs; per (i, k) the count
+//   scan     : offsets of the K^3 pair segments and of their 32-pair tiles
+//   fill     : pair_in / pair_out arrays grouped by k; slot_first[i][k]
+//   gemm     : per tile of 32 pairs of one k: partial[slot] = feat[pair_in[slot]] . W[k]  (W[k] in LDS)
+//   reduce   : out[i] = sum over k (ascending) of its partial rows  -- deterministic, no float atomics
+// The gradient w.r.t. the features is the same operator with W'[k] = W[K^3-1-k]^T (the neighbour
+// relation is symmetric), the gradient w.r.t. W[k] is feat[pair_in]^T . grad_out[pair_out] per segment.
+#include "gf_common.hpp"
+
+namespace gf {
+
+constexpr int kPairTile = 128;   // pairs per workgroup tile of the gather-GEMM (32 per wave)
+constexpr int kWgradChunk = 512;  // pairs per workgroup of the weight gradient
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct SubmTables {
+    int *head;              // [cells]  first point of the cell's list, -1 = empty
+    int *next;              // [N]
+    int *slot_first;        // [N][K3]  first pair slot of (out point, offset), -1 = none
+    unsigned char *cnt;     // [N][K3]  pairs of (out point, offset)
+    unsigned int *kcount;   // [K3]
+    unsigned int *kstart;   // [K3+1]
+    unsigned int *tile_start;  // [K3+1]
+    unsigned int *kcursor;  // [K3]
+    unsigned int *chunk_start;  // [K3+1] weight-gradient chunks before segment k
+    unsigned long long *total;  // [1] total pairs
+};
+
+struct SubmArgs {
+    const int *indices;  // [N,4] (batch, x, y, z)
+    SubmTables t;
+    int *pair_in;
+    int *pair_out;
+    const float *feat;     // [N, Cin]
+    const float *weight;   // [K3, Cin, Cout]
+    const float *grad_out; // [N, Cout] (weight grad)
+    float *partial;        // [total, Cout]
+    float *out;            // [N, Cout]
+    float *grad_weight;    // [K3, Cin, Cout]
+    int N, batch, X, Y, Z, K, K3, Cin, Cout;
+    long long cells;
+};
+
+inline size_t subm_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static SubmTables subm_carve(void *base, int N, long long cells, int K3, size_t *bytes)
+{
+    char *p = (char *)base;
+    size_t off = 0;
+    SubmTables t;
+    t.head = (int *)(p + off); off += subm_align((size_t)cells * 4);
+    t.next = (int *)(p + off); off += subm_align((size_t)N * 4);
+    t.slot_first = (int *)(p + off); off += subm_align((size_t)N * K3 * 4);
+    t.cnt = (unsigned char *)(p + off); off += subm_align((size_t)N * K3);
+    t.kcount = (unsigned int *)(p + off); off += subm_align((size_t)K3 * 4);
+    t.kstart = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
+    t.tile_start = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
+    t.kcursor = (unsigned int *)(p + off); off += subm_align((size_t)K3 * 4);
+    t.chunk_start = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
+    t.total = (unsigned long long *)(p + off); off += 256;
+    *bytes = off;
+    return t;
+}
+
+__device__ __forceinline__ long long subm_cell(const SubmArgs &a, int b, int x, int y, int z)
+{
+    if (b < 0 || b >= a.batch || x < 0 || x >= a.X || y < 0 || y >= a.Y || z < 0 || z >= a.Z) return -1;
+    return (((long long)b * a.X + x) * a.Y + y) * a.Z + z;
+}
+
+__global__ __launch_bounds__(256) void gf_subm_grid_kernel(SubmArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const int4 c = *reinterpret_cast<const int4 *>(a.indices + 4 * (size_t)i);
+    const long long cell = subm_cell(a, c.x, c.y, c.z, c.w);
+    a.t.next[i] = cell >= 0 ? atomicExch(a.t.head + cell, i) : -1;
+}
+
+// grid: (ceil(N/256), K*K).  A thread owns one point and one (dx, dy) column of offsets and walks the
+// K offsets along z (k = kxy*K + kz, x-major / z fastest like a [K,K,K] kernel tensor): the index
+// row is read once and the K neighbour cells are consecutive ints of the table.
+// FILL = false counts, FILL = true writes the pairs.
+template <bool FILL>
+__global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
+{
+    __shared__ unsigned int s_w[4], s_base;
+    const int i = blockIdx.x * 256 + threadIdx.x, kxy = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = a.K / 2;
+    long long col = -1;  // cell of (x + dx, y + dy, z = 0); -1 = outside or inactive point
+    int z = 0;
+    if (i < a.N) {
+        const int4 c = *reinterpret_cast<const int4 *>(a.indices + 4 * (size_t)i);
+        if (subm_cell(a, c.x, c.y, c.z, c.w) >= 0) {
+            col = subm_cell(a, c.x, c.y + kxy / a.K - r, c.z + kxy % a.K - r, 0);
+            z = c.w;
+        }
+    }
+    for (int kz = 0; kz < a.K; ++kz) {
+        const int k = kxy * a.K + kz, zz = z + kz - r;
+        unsigned int c = 0;
+        int first = -1;
+        if (col >= 0 && zz >= 0 && zz < a.Z) {
+            first = a.t.head[col + zz];
+            for (int j = first; j >= 0; j = a.t.next[j]) ++c;
+        }
+        // block exclusive prefix of c
+        unsigned int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        __syncthreads();  // s_w / s_base of the previous kz consumed
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        unsigned int before = incl - c, total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) before += s_w[w];
+            total += s_w[w];
+        }
+        if (total == 0) continue;  // block-uniform
+        if (!FILL) {
+            if (threadIdx.x == 0) atomicAdd(a.t.kcount + k, total);
+            if (c) a.t.cnt[(size_t)i * a.K3 + k] = (unsigned char)min(c, 255u);
+            continue;
+        }
+        if (threadIdx.x == 0) s_base = a.t.kstart[k] + atomicAdd(a.t.kcursor + k, total);
+        __syncthreads();
+        if (c) {
+            unsigned int slot = s_base + before;
+            a.t.slot_first[(size_t)i * a.K3 + k] = (int)slot;
+            for (int j = first; j >= 0; j = a.t.next[j]) {
+                a.pair_in[slot] = j;
+                a.pair_out[slot] = i;
+                ++slot;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
+{
+    // K3 <= 343 entries: one wave, 64 per step, running totals carried in registers
+    const int lane = threadIdx.x;
+    unsigned int run = 0, tiles = 0, chunks = 0;
+    for (int k0 = 0; k0 < a.K3; k0 += 64) {
+        const int k = k0 + lane;
+        const unsigned int c = k < a.K3 ? a.t.kcount[k] : 0u;
+        const unsigned int tl = (c + kPairTile - 1) / kPairTile, ch = (c + kWgradChunk - 1) / kWgradChunk;
+        unsigned int ic = c, it = tl, ih = ch;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int uc = __shfl_up(ic, d, 64), ut = __shfl_up(it, d, 64), uh = __shfl_up(ih, d, 64);
+            if (lane >= d) { ic += uc; it += ut; ih += uh; }
+        }
+        if (k < a.K3) {
+            a.t.kstart[k] = run + ic - c;
+            a.t.tile_start[k] = tiles + it - tl;
+            a.t.chunk_start[k] = chunks + ih - ch;
+            a.t.kcursor[k] = 0;
+        }
+        run += __shfl(ic, 63, 64);
+        tiles += __shfl(it, 63, 64);
+        chunks += __shfl(ih, 63, 64);
+    }
+    if (lane == 0) {
+        a.t.kstart[a.K3] = run;
+        a.t.tile_start[a.K3] = tiles;
+        a.t.chunk_start[a.K3] = chunks;
+        a.t.total[0] = run;
+    }
+}
+
+// largest k with start[k] <= t (start is non-decreasing, start[0] = 0, t < start[K3]): the segment
+// that holds tile / chunk t.  Empty segments repeat their successor's value and are skipped.
+__device__ __forceinline__ int subm_segment_of(const unsigned int *start, int K3, unsigned int t)
+{
+    int lo = 0, hi = K3;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// partial[slot] = feat[pair_in[slot]] . W[k] on the matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32
+// accumulate, bitwise an fmaf chain).  A workgroup takes one tile of kPairTile pairs of one offset k and
+// one slice of SW output channels (blockIdx.y) and stages W[k][:, slice] (CIN x SW, 32 KB at 128 x 64 --
+// four workgroups per CU, so one workgroup's staging hides under the MFMAs of the others) in LDS; each
+// of its four waves owns 32 of the pairs.  A operand: lane (i = lane & 31, h = lane >> 5) keeps half h
+// of the gathered feature row of pair i in registers (CIN/2 contiguous floats, 16-byte loads, no LDS
+// round trip); MFMA step s multiplies input channels {s, CIN/2 + s} -- the k order of an MFMA is free
+// as long as A and B agree -- so the B operand is W[k][h CIN/2 + s][32 g + i], one conflict-free
+// ds_read_b32 per 64-cycle MFMA.
+template <int CIN, int COUT, int SW>
+__global__ __launch_bounds__(256, 4) void gf_subm_gemm_kernel(SubmArgs a)
+{
+    extern __shared__ float s_w[];  // [CIN][SW]
+    constexpr int HALF = CIN / 2, NG = SW / 32;
+    constexpr int WQ = CIN * SW / 4 / 256;  // float4 of the W slice per thread
+    static_assert(COUT % SW == 0 && SW % 32 == 0 && WQ >= 1, "unsupported slice");
+    const unsigned int t = blockIdx.x;
+    if (t >= a.t.tile_start[a.K3]) return;
+    const int k = subm_segment_of(a.t.tile_start, a.K3, t);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int c_lo = blockIdx.y * SW;
+    const unsigned int slot0 = a.t.kstart[k] + (t - a.t.tile_start[k]) * kPairTile + wave * 32;
+    const unsigned int seg_end = a.t.kstart[k + 1];
+    // gathered feature half-row and the W slice: every load is issued before the first use
+    const unsigned int myslot = slot0 + i;
+    const int row = myslot < seg_end ? a.pair_in[myslot] : 0;  // padding lanes compute on row 0; never stored
+    const float *wsrc = a.weight + (size_t)k * CIN * COUT + c_lo;
+    float4 wv[WQ];
+#pragma unroll
+    for (int u = 0; u < WQ; ++u) {
+        const int e = tid + 256 * u, ci = e / (SW / 4), c4 = e % (SW / 4);
+        wv[u] = reinterpret_cast<const float4 *>(wsrc + (size_t)ci * COUT)[c4];
+    }
+    const float4 *src = reinterpret_cast<const float4 *>(a.feat + (size_t)row * CIN + h * HALF);
+    float4 av[HALF / 4];
+#pragma unroll
+    for (int q = 0; q < HALF / 4; ++q) av[q] = src[q];
+#pragma unroll
+    for (int u = 0; u < WQ; ++u) reinterpret_cast<float4 *>(s_w)[tid + 256 * u] = wv[u];
+    __syncthreads();
+    if (slot0 >= seg_end) return;  // wave-uniform: this wave's 32 pairs lie past the segment
+    f32x16 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    const float *wb = s_w + (size_t)h * HALF * SW + i;
+#pragma unroll
+    for (int s = 0; s < HALF; ++s) {
+        const float4 a4 = av[s / 4];
+        const float aval = (s & 3) == 0 ? a4.x : (s & 3) == 1 ? a4.y : (s & 3) == 2 ? a4.z : a4.w;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, wb[s * SW + 32 * g], acc[g], 0, 0, 0);
+    }
+    // D layout: column = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h (pair)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned int slot = slot0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (slot < seg_end) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) a.partial[(size_t)slot * COUT + c_lo + 32 * g + i] = acc[g][r];
+        }
+    }
+}
+
+// out[i] = sum over k ascending of the partial rows of (i, k): COUT/4 lanes per point
+template <int COUT>
+__global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
+{
+    constexpr int CG = COUT / 4;
+    constexpr int ROWS = 256 / CG;
+    const int tc = threadIdx.x % CG;
+    const int i = blockIdx.x * ROWS + threadIdx.x / CG;
+    if (i >= a.N) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int *sf = a.t.slot_first + (size_t)i * a.K3;
+    const unsigned char *cn = a.t.cnt + (size_t)i * a.K3;
+    // the CG lanes of a point scan its K^3 counts together (most are zero), then walk the hits in
+    // ascending k -- the summation order is fixed by k, not by where the pairs were stored
+    for (int k0 = 0; k0 < a.K3; k0 += CG) {
+        const int kk = k0 + tc;
+        const int c_mine = kk < a.K3 ? cn[kk] : 0;
+        const int s_mine = c_mine ? sf[kk] : 0;
+        for (int l = 0; l < CG; ++l) {
+            const int c = __shfl(c_mine, l, CG);
+            if (!c) continue;
+            const int s0 = __shfl(s_mine, l, CG);
+            for (int sidx = 0; sidx < c; ++sidx) {
+                const float4 v = reinterpret_cast<const float4 *>(a.partial + (size_t)(s0 + sidx) * COUT)[tc];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    reinterpret_cast<float4 *>(a.out + (size_t)i * COUT)[tc] = acc;
+}
+
+// staging helpers of the weight gradient: thread tid owns float4 (tid + 256 u) of the 32 x C block, u < Q
+template <int C, int Q>
+__device__ __forceinline__ void wgrad_fetch_idx(int (&idx)[Q], const int *pairs, unsigned int pb, unsigned int p1)
+{
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+        const unsigned int p = pb + (threadIdx.x + 256 * u) / (C / 4);
+        idx[u] = p < p1 ? pairs[p] : 0;  // padding pairs read row 0 and are zeroed when staged
+    }
+}
+
+template <int C, int Q>
+__device__ __forceinline__ void wgrad_fetch_rows(float4 (&rows)[Q], const int (&idx)[Q], const float *src)
+{
+#pragma unroll
+    for (int u = 0; u < Q; ++u)
+        rows[u] = reinterpret_cast<const float4 *>(src + (size_t)idx[u] * C)[(threadIdx.x + 256 * u) % (C / 4)];
+}
+
+// grad_weight[k] += feat[pair_in]^T . grad_out[pair_out] over a chunk of <= kWgradChunk pairs of segment k
+// (the segments are very uneven: the centre offset holds every point, the far ones a few per cent), on
+// the matrix cores: the CIN x COUT block is (CIN/32) x (COUT/32) MFMA blocks shared out over the four
+// waves, the reduction dimension is the pair index.  32 pairs are staged per step -- gathered feature
+// and gradient rows, fetched into registers one step ahead -- and step s of the 16 MFMA steps takes
+// pairs {2s, 2s + 1}: A = s_f[2s + h][32 mi + i], B = s_g[2s + h][32 nj + i] (rows padded by 32 floats
+// so the two halves of the wave hit different banks).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 3) void gf_subm_wgrad_kernel(SubmArgs a)
+{
+    constexpr int kBatch = 32;
+    constexpr int NJ = COUT / 32, NB = (CIN / 32) * NJ;   // MFMA blocks of the product
+    constexpr int NBW = NB >= 4 ? NB / 4 : 1;              // blocks per wave
+    constexpr int FS = CIN + 32, GS = COUT + 32;           // LDS row strides
+    constexpr int FQ = kBatch * CIN / 4 / 256, GQ = kBatch * COUT / 4 / 256;  // float4 per thread and step
+    __shared__ __attribute__((aligned(16))) float s_f[kBatch * FS];
+    __shared__ __attribute__((aligned(16))) float s_g[kBatch * GS];
+    const unsigned int c = blockIdx.x;
+    if (c >= a.t.chunk_start[a.K3]) return;
+    const int k = subm_segment_of(a.t.chunk_start, a.K3, c);
+    const unsigned int p0 = a.t.kstart[k] + (c - a.t.chunk_start[k]) * kWgradChunk;
+    const unsigned int p1 = min(a.t.kstart[k + 1], p0 + kWgradChunk);
+    const bool shared_block = a.t.chunk_start[k + 1] - a.t.chunk_start[k] > 1;  // several workgroups add into grad_weight[k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    // pair indices are fetched two steps ahead and the rows one step ahead, so neither load chain is
+    // waited for in front of the MFMAs
+    int fi[FQ], gi[GQ];
+    float4 fr[FQ], gr[GQ];
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const bool active = wave * NBW < NB;  // fewer blocks than waves for the smallest channel counts
+    wgrad_fetch_idx<CIN, FQ>(fi, a.pair_in, p0, p1);
+    wgrad_fetch_idx<COUT, GQ>(gi, a.pair_out, p0, p1);
+    wgrad_fetch_rows<CIN, FQ>(fr, fi, a.feat);
+    wgrad_fetch_rows<COUT, GQ>(gr, gi, a.grad_out);
+    wgrad_fetch_idx<CIN, FQ>(fi, a.pair_in, p0 + kBatch, p1);
+    wgrad_fetch_idx<COUT, GQ>(gi, a.pair_out, p0 + kBatch, p1);
+    for (unsigned int pb = p0; pb < p1; pb += kBatch) {
+        __syncthreads();  // previous step's rows consumed
+#pragma unroll
+        for (int u = 0; u < FQ; ++u) {
+            const int e = tid + 256 * u, q = e / (CIN / 4), c4 = e % (CIN / 4);
+            const bool ok = pb + q < p1;
+            *reinterpret_cast<float4 *>(s_f + q * FS + 4 * c4) =
+                make_float4(ok ? fr[u].x : 0.f, ok ? fr[u].y : 0.f, ok ? fr[u].z : 0.f, ok ? fr[u].w : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < GQ; ++u) {
+            const int e = tid + 256 * u, q = e / (COUT / 4), c4 = e % (COUT / 4);
+            const bool ok = pb + q < p1;
+            *reinterpret_cast<float4 *>(s_g + q * GS + 4 * c4) =
+                make_float4(ok ? gr[u].x : 0.f, ok ? gr[u].y : 0.f, ok ? gr[u].z : 0.f, ok ? gr[u].w : 0.f);
+        }
+        __syncthreads();
+        if (pb + kBatch < p1) {
+            wgrad_fetch_rows<CIN, FQ>(fr, fi, a.feat);
+            wgrad_fetch_rows<COUT, GQ>(gr, gi, a.grad_out);
+            wgrad_fetch_idx<CIN, FQ>(fi, a.pair_in, pb + 2 * kBatch, p1);
+            wgrad_fetch_idx<COUT, GQ>(gi, a.pair_out, pb + 2 * kBatch, p1);
+        }
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < kBatch / 2; ++s) {
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) {
+                    const int blk = wave * NBW + b, mi = blk / NJ, nj = blk % NJ;
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_f[(2 * s + h) * FS + 32 * mi + i], s_g[(2 * s + h) * GS + 32 * nj + i],
+                                                                  acc[b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    float *dst = a.grad_weight + (size_t)k * CIN * COUT;
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int blk = wave * NBW + b, mi = blk / NJ, nj = blk % NJ;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float *d = dst + (size_t)(32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h) * COUT + 32 * nj + i;
+            if (!shared_block) *d = acc[b][r];
+            else unsafeAtomicAdd(d, acc[b][r]);
+        }
+    }
+}
+
+static int subm_check(int N, int batch, int X, int Y, int Z, int K)
+{
+    GF_CHECK_ARG(N >= 0 && batch > 0 && X > 0 && Y > 0 && Z > 0, "bad size");
+    GF_CHECK_ARG(K >= 1 && K <= 7 && (K & 1), "kernel size must be odd and <= 7");
+    GF_CHECK_ARG((long long)batch * X * Y * Z < (1ll << 31), "grid too large");
+    GF_CHECK_ARG((long long)N * K * K * K < (1ll << 31), "too many points");
+    return GF_OK;
+}
+
+static bool subm_channels_ok(int Cin, int Cout)
+{
+    return (Cout == 32 || Cout == 64 || Cout == 128) && (Cin == 32 || Cin == 64 || Cin == 128);
+}
+
+static SubmArgs subm_args(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables)
+{
+    SubmArgs a{};
+    a.N = N; a.batch = batch; a.X = X; a.Y = Y; a.Z = Z; a.K = K; a.K3 = K * K * K;
+    a.cells = (long long)batch * X * Y * Z;
+    a.indices = indices;
+    size_t bytes;
+    a.t = subm_carve(tables, N, a.cells, a.K3, &bytes);
+    return a;
+}
+
+}  // namespace gf
+
+extern "C" size_t gf_subm_tables_bytes(int N, int batch, int X, int Y, int Z, int K)
+{
+    using namespace gf;
+    if (N < 0 || batch <= 0 || X <= 0 || Y <= 0 || Z <= 0 || K < 1 || K > 7 || !(K & 1)) return 0;
+    size_t bytes = 0;
+    (void)subm_carve(nullptr, N, (long long)batch * X * Y * Z, K * K * K, &bytes);
+    return bytes;
+}
+
+extern "C" int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                                      size_t tables_bytes, void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = subm_check(N, batch, X, Y, Z, K)) return rc;
+    GF_CHECK_ARG(tables && tables_bytes >= gf_subm_tables_bytes(N, batch, X, Y, Z, K), "tables buffer too small (gf_subm_tables_bytes)");
+    GF_CHECK_ARG(N == 0 || indices, "null pointer");
+    GF_CHECK_ARG(((uintptr_t)indices & 15) == 0 && ((uintptr_t)tables & 255) == 0, "indices must be 16-byte and tables 256-byte aligned");
+    SubmArgs a = subm_args(N, batch, X, Y, Z, K, indices, tables);
+    if (hipMemsetAsync(a.t.head, 0xFF, (size_t)a.cells * 4, stream) != hipSuccess ||
+        hipMemsetAsync(a.t.slot_first, 0xFF, (size_t)N * a.K3 * 4, stream) != hipSuccess ||
+        hipMemsetAsync(a.t.cnt, 0, (size_t)N * a.K3, stream) != hipSuccess ||
+        hipMemsetAsync(a.t.kcount, 0, (size_t)a.K3 * 4, stream) != hipSuccess) {
+        set_error("%s: hipMemsetAsync failed", __func__);
+        return GF_ELAUNCH;
+    }
+    if (N > 0) {
+        hipLaunchKernelGGL(gf_subm_grid_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(gf_subm_pairs_kernel<false>, dim3((N + 255) / 256, K * K), dim3(256), 0, stream, a);
+    }
+    hipLaunchKernelGGL(gf_subm_scan_kernel, dim3(1), dim3(64), 0, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" int gf_subm_rulebook_fill(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                                     int *pair_in, int *pair_out, void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = subm_check(N, batch, X, Y, Z, K)) return rc;
+    GF_CHECK_ARG(tables && (N == 0 || (indices && pair_in && pair_out)), "null pointer");
+    if (N == 0) return GF_OK;
+    SubmArgs a = subm_args(N, batch, X, Y, Z, K, indices, tables);
+    a.pair_in = pair_in; a.pair_out = pair_out;
+    hipLaunchKernelGGL(gf_subm_pairs_kernel<true>, dim3((N + 255) / 256, K * K), dim3(256), 0, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+#define GF_SUBM_DISPATCH(CALL)                                         \
+    do {                                                              \
+        if (Cin == 128 && Cout == 128) CALL(128, 128);                \
+        else if (Cin == 128 && Cout == 64) CALL(128, 64);             \
+        else if (Cin == 128 && Cout == 32) CALL(128, 32);             \
+        else if (Cin == 64 && Cout == 128) CALL(64, 128);             \
+        else if (Cin == 64 && Cout == 64) CALL(64, 64);               \
+        else if (Cin == 64 && Cout == 32) CALL(64, 32);               \
+        else if (Cin == 32 && Cout == 128) CALL(32, 128);             \
+        else if (Cin == 32 && Cout == 64) CALL(32, 64);               \
+        else CALL(32, 32);                                            \
+    } while (0)
+
+extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
+                                  const float *features, const float *weight, const void *tables, const int *pair_in,
+                                  float *partial, float *out, void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = subm_check(N, batch, X, Y, Z, K)) return rc;
+    GF_CHECK_ARG(subm_channels_ok(Cin, Cout), "unsupported channels: Cin and Cout in {32, 64, 128}");
+    if (N == 0) return GF_OK;
+    GF_CHECK_ARG(features && weight && tables && pair_in && partial && out, "null pointer");
+    const int K3 = K * K * K;
+    GF_CHECK_ARG(total_pairs >= 0 && total_pairs / kPairTile + K3 < (1ll << 31), "bad pair count");
+    SubmArgs a = subm_args(N, batch, X, Y, Z, K, nullptr, const_cast<void *>(tables));
+    a.Cin = Cin; a.Cout = Cout; a.feat = features; a.weight = weight; a.pair_in = const_cast<int *>(pair_in);
+    a.partial = partial; a.out = out;
+    const int SW = Cout >= 64 ? 64 : 32;  // output-channel slice per workgroup
+    const size_t lds = (size_t)Cin * SW * sizeof(float);
+    const dim3 gemm_grid((unsigned)(total_pairs / kPairTile + K3), Cout / SW);  // x >= the number of tiles, whatever the split over the segments
+    const int rows = 256 / (Cout / 4);
+#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds, stream, a)
+    GF_SUBM_DISPATCH(GF_GEMM);
+#undef GF_GEMM
+    if (Cout == 128) hipLaunchKernelGGL(gf_subm_reduce_kernel<128>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
+    else if (Cout == 64) hipLaunchKernelGGL(gf_subm_reduce_kernel<64>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gf_subm_reduce_kernel<32>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" int gf_subm_conv_weight_grad(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout,
+                                        long long total_pairs, const float *features, const float *grad_out,
+                                        const void *tables, const int *pair_in, const int *pair_out,
+                                        float *grad_weight, void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = subm_check(N, batch, X, Y, Z, K)) return rc;
+    GF_CHECK_ARG(subm_channels_ok(Cin, Cout), "unsupported channels: Cin and Cout in {32, 64, 128}");
+    GF_CHECK_ARG(grad_weight != nullptr, "null pointer");
+    const int K3 = K * K * K;
+    if (hipMemsetAsync(grad_weight, 0, (size_t)K3 * Cin * Cout * sizeof(float), stream) != hipSuccess) {
+        set_error("%s: hipMemsetAsync failed", __func__);
+        return GF_ELAUNCH;
+    }
+    if (N == 0) return GF_OK;
+    GF_CHECK_ARG(features && grad_out && tables && pair_in && pair_out, "null pointer");
+    SubmArgs a = subm_args(N, batch, X, Y, Z, K, nullptr, const_cast<void *>(tables));
+    a.Cin = Cin; a.Cout = Cout; a.feat = features; a.grad_out = grad_out; a.pair_in = const_cast<int *>(pair_in);
+    a.pair_out = const_cast<int *>(pair_out); a.grad_weight = grad_weight;
+    GF_CHECK_ARG(total_pairs >= 0 && total_pairs / kWgradChunk + K3 < (1ll << 31), "bad pair count");
+    const dim3 grid((unsigned)(total_pairs / kWgradChunk + K3));  // >= the number of chunks, whatever the split over the segments
+#define GF_WGRAD(CI, CO) hipLaunchKernelGGL((gf_subm_wgrad_kernel<CI, CO>), grid, dim3(256), 0, stream, a)
+    GF_SUBM_DISPATCH(GF_WGRAD);
+#undef GF_WGRAD
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

@@ -1,0 +1,170 @@
+"""Submanifold sparse 3-D convolution over the Gaussian centres.
+
+Host mirror of ``SparseConv3D`` (model/encoder/gaussian_encoder/spconv3d_module.py:10-83), whose
+``spconv.SubMConv3d`` has no ROCm build: the rulebook and the gather-GEMM run in
+``gf_subm_rulebook_* / gf_subm_conv_apply / gf_subm_conv_weight_grad`` (include/gf_hip.h).
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd.function import Function, once_differentiable
+
+from . import _lib
+
+f32, i32 = torch.float32, torch.int32
+
+
+class Rulebook:
+    """Neighbour pairs of one point set (reusable across layers and by the backward pass)."""
+
+    def __init__(self, indices, batch_size, spatial_shape, kernel_size):
+        _lib.require_gpu(indices)
+        lib = _lib.load()
+        self.indices = indices.detach().to(i32).contiguous()
+        self.N = self.indices.shape[0]
+        self.dims = (self.N, int(batch_size), int(spatial_shape[0]), int(spatial_shape[1]), int(spatial_shape[2]),
+                     int(kernel_size))
+        dev = self.indices.device
+        nbytes = lib.gf_subm_tables_bytes(*self.dims)
+        if nbytes == 0:
+            raise RuntimeError(f"unsupported sparse-conv geometry {self.dims}")
+        self.tables = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gf_subm_rulebook_count(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes,
+                                            _lib.current_stream(dev))
+            _lib.check(rc, "gf_subm_rulebook_count")
+            # the one host read (spconv reads its pair counts the same way)
+            self.total = int(self.tables[nbytes - 256:nbytes - 248].view(torch.int64).item())
+            self.pair_in = torch.empty(max(self.total, 1), dtype=i32, device=dev)
+            self.pair_out = torch.empty(max(self.total, 1), dtype=i32, device=dev)
+            rc = lib.gf_subm_rulebook_fill(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables),
+                                           _lib.ptr(self.pair_in), _lib.ptr(self.pair_out), _lib.current_stream(dev))
+            _lib.check(rc, "gf_subm_rulebook_fill")
+
+    def apply(self, features, weight):
+        """``out[N, Cout]`` for ``features [N, Cin]`` and ``weight [K^3, Cin, Cout]`` (no autograd)."""
+        lib = _lib.load()
+        features, weight = features.detach().to(f32).contiguous(), weight.detach().to(f32).contiguous()
+        cin, cout = weight.shape[1], weight.shape[2]
+        dev = features.device
+        out = torch.empty(self.N, cout, dtype=f32, device=dev)
+        partial = torch.empty(max(self.total, 1), cout, dtype=f32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gf_subm_conv_apply(*self.dims, cin, cout, self.total, _lib.ptr(features), _lib.ptr(weight), _lib.ptr(self.tables),
+                                        _lib.ptr(self.pair_in), _lib.ptr(partial), _lib.ptr(out), _lib.current_stream(dev))
+        _lib.check(rc, "gf_subm_conv_apply")
+        return out
+
+    def weight_grad(self, features, grad_out):
+        lib = _lib.load()
+        features, grad_out = features.detach().to(f32).contiguous(), grad_out.detach().to(f32).contiguous()
+        cin, cout = features.shape[1], grad_out.shape[1]
+        k3 = self.dims[5] ** 3
+        gw = torch.empty(k3, cin, cout, dtype=f32, device=features.device)
+        with torch.cuda.device(features.device):
+            rc = lib.gf_subm_conv_weight_grad(*self.dims, cin, cout, self.total, _lib.ptr(features), _lib.ptr(grad_out),
+                                              _lib.ptr(self.tables), _lib.ptr(self.pair_in), _lib.ptr(self.pair_out),
+                                              _lib.ptr(gw), _lib.current_stream(features.device))
+        _lib.check(rc, "gf_subm_conv_weight_grad")
+        return gw
+
+
+class _SubMConv(Function):
+    @staticmethod
+    def forward(ctx, features, weight, rulebook):
+        ctx.rulebook = rulebook
+        ctx.save_for_backward(features, weight)
+        return rulebook.apply(features, weight)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        features, weight = ctx.saved_tensors
+        rb = ctx.rulebook
+        g_feat = g_w = None
+        if ctx.needs_input_grad[0]:
+            # the neighbour relation is symmetric: same rulebook, kernel mirrored and transposed
+            g_feat = rb.apply(grad_out, weight.flip(0).transpose(1, 2))
+        if ctx.needs_input_grad[1]:
+            g_w = rb.weight_grad(features, grad_out)
+        return g_feat, g_w, None
+
+
+def subm_conv3d(features, indices, weight, batch_size, spatial_shape, kernel_size, rulebook=None):
+    """Functional submanifold convolution; ``indices`` int ``[N,4]`` = (batch, x, y, z),
+    ``weight [K^3, Cin, Cout]`` (offsets in [K,K,K] order).  Returns ``[N, Cout]``."""
+    rb = rulebook if rulebook is not None else Rulebook(indices, batch_size, spatial_shape, kernel_size)
+    return _SubMConv.apply(features, weight, rb)
+
+
+class SubMConv3d(nn.Module):
+    """``spconv.SubMConv3d(in_channels, out_channels, kernel_size, stride=1, padding=k//2, bias=...)``
+    as used by the reference (spconv3d_module.py:28-44); weight ``[K^3, Cin, Cout]``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.weight = nn.Parameter(torch.empty(kernel_size ** 3, in_channels, out_channels))
+        nn.init.kaiming_uniform_(self.weight.view(-1, out_channels), a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(in_channels * kernel_size ** 3)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, features, indices, batch_size, spatial_shape, rulebook=None):
+        out = subm_conv3d(features, indices, self.weight, batch_size, spatial_shape, self.kernel_size, rulebook)
+        return out if self.bias is None else out + self.bias
+
+
+class SparseConv3D(nn.Module):
+    """Drop-in for the reference's ``SparseConv3D`` block (spconv3d_module.py:10-83): voxelise the
+    anchor centres, submanifold conv (one bias-free layer, or with ``use_multi_layer`` three
+    conv + LayerNorm + ReLU stages, :26-37), output projection.  The three stages share one
+    rulebook -- a submanifold convolution keeps the active set."""
+
+    def __init__(self, in_channels, embed_channels, pc_range, grid_size, xyz_activation="sigmoid", use_out_proj=False,
+                 kernel_size=5, use_multi_layer=False, **kwargs):
+        super().__init__()
+        if use_multi_layer:
+            self.layer = nn.ModuleList()
+            for i in range(3):
+                self.layer.append(SubMConv3d(in_channels if i == 0 else embed_channels, embed_channels, kernel_size))
+                self.layer.append(nn.LayerNorm(embed_channels))
+                self.layer.append(nn.ReLU(True))
+        else:
+            self.layer = SubMConv3d(in_channels, embed_channels, kernel_size, bias=False)
+        self.kernel_size = kernel_size
+        self.output_proj = nn.Linear(embed_channels, embed_channels) if use_out_proj else nn.Identity()
+        self.use_sigmoid = xyz_activation == "sigmoid"
+        self._range = [float(v) for v in pc_range]
+        self.register_buffer('pc_range', torch.tensor(pc_range, dtype=torch.float))
+        self.register_buffer('grid_size', torch.tensor(grid_size, dtype=torch.float))
+        # spatial_shape = ((pc_range[3:] - pc_range[:3]) / grid_size).to(int32), evaluated once in fp32 like the reference (:70-71)
+        self._spatial = ((self.pc_range[3:] - self.pc_range[:3]) / self.grid_size).to(torch.int32).tolist()
+
+    def voxel_indices(self, anchor):
+        """int32 ``[b*g, 4]`` (batch, x, y, z) of the anchor centres (spconv3d_module.py:56-66,
+        ``cartesian`` model/encoder/gaussian_encoder/utils.py:26-36, ``safe_sigmoid`` model/utils/safe_ops.py:7-9)."""
+        bs, g = anchor.shape[:2]
+        xyz = anchor[..., :3]
+        xyz = xyz.clamp(-9.21, 9.21).sigmoid() if self.use_sigmoid else xyz.clamp(min=1e-6, max=1 - 1e-6)
+        r = self._range
+        xyz = torch.stack([xyz[..., a] * (r[3 + a] - r[a]) + r[a] for a in range(3)], dim=-1).flatten(0, 1)
+        idx = ((xyz - self.pc_range[None, :3]) / self.grid_size[None, :]).to(torch.int32)
+        bidx = torch.arange(bs, device=idx.device, dtype=torch.int32).repeat_interleave(g)[:, None]
+        return torch.cat([bidx, idx], dim=-1)
+
+    def forward(self, instance_feature, anchor):
+        bs, g, _ = instance_feature.shape
+        indices = self.voxel_indices(anchor)
+        feats = instance_feature.flatten(0, 1)
+        if isinstance(self.layer, SubMConv3d):
+            out = self.layer(feats, indices, bs, self._spatial)
+        else:
+            rb = Rulebook(indices, bs, self._spatial, self.kernel_size)
+            out = feats
+            for m in self.layer:
+                out = m(out, indices, bs, self._spatial, rulebook=rb) if isinstance(m, SubMConv3d) else m(out)
+        return self.output_proj(out.unflatten(0, (bs, g)))

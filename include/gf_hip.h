@@ -215,6 +215,35 @@ int gf_profile_enable(int max_records);
 int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const *levels, float *table,
                            int inverse, void *stream);
 
+/*
+ * Submanifold sparse 3-D convolution over point cells: the operator of
+ * SparseConv3D (model/encoder/gaussian_encoder/spconv3d_module.py:10-83; spconv.SubMConv3d, kernel K, stride 1,
+ * padding K/2, no bias).  spconv is not in the reference tree; the published algorithm is restated:
+ *     out[i] = sum_k sum_{j : cell(j) = cell(i) + offset_k} features[j] . weight[k]
+ * with offsets in [K,K,K] order (x major, z fastest) and weight f32 [K^3, Cin, Cout].  Points sharing a cell all
+ * contribute and all receive that cell's output (= a dense convolution of the scattered-and-summed features,
+ * read back at the points).  indices i32 [N,4] = (batch, x, y, z); points outside the grid are inactive (output 0).
+ *
+ * Call order: gf_subm_rulebook_count (device tables; the total pair count is the i64 at byte
+ * gf_subm_tables_bytes(..) - 256 of `tables`) -> allocate pair_in / pair_out (i32 [total]) and partial
+ * (f32 [total, Cout]) -> gf_subm_rulebook_fill -> gf_subm_conv_apply (any number of times; the gradient w.r.t.
+ * the features is the same call with weight'[k] = weight[K^3-1-k]^T) / gf_subm_conv_weight_grad.
+ * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  Both products run on the f32 matrix
+ * cores (v_mfma_f32_32x32x2_f32: exact f32, an fmaf chain); results are deterministic except the weight gradient of
+ * segments longer than 512 pairs (float atomics between their chunks).
+ */
+size_t gf_subm_tables_bytes(int N, int batch, int X, int Y, int Z, int K);
+int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                           size_t tables_bytes, void *stream);
+int gf_subm_rulebook_fill(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                          int *pair_in, int *pair_out, void *stream);
+int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
+                       const float *features, const float *weight, const void *tables, const int *pair_in,
+                       float *partial, float *out, void *stream);
+int gf_subm_conv_weight_grad(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
+                             const float *features, const float *grad_out, const void *tables, const int *pair_in,
+                             const int *pair_out, float *grad_weight, void *stream);
+
 /* modes of gf_head_labels */
 #define GF_LABELS_ARGMAX 0          /* base head: argmax over the 18 logits (gaussian_head.py:185) */
 #define GF_LABELS_PROB_THRESHOLD 1  /* prob head: argmax where bin_logits > threshold, else empty_label (:178-183) */

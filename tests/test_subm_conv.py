@@ -1,0 +1,149 @@
+"""Submanifold sparse convolution against its definition: a dense K^3
+convolution of the scattered-and-summed features, read back at the points (fp64 torch, autograd
+for the gradients).  spconv itself is not available (no ROCm build, not in the reference tree)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_reference(feat, idx, weight, batch, shape, K):
+    """feat [N,Cin] f64, idx [N,4] (b,x,y,z), weight [K^3,Cin,Cout] f64 -> out [N,Cout] (differentiable)."""
+    X, Y, Z = shape
+    N, cin = feat.shape
+    cout = weight.shape[2]
+    inside = (idx[:, 0] >= 0) & (idx[:, 0] < batch) & (idx[:, 1] >= 0) & (idx[:, 1] < X) & (idx[:, 2] >= 0) & \
+        (idx[:, 2] < Y) & (idx[:, 3] >= 0) & (idx[:, 3] < Z)
+    lin = ((idx[:, 0] * X + idx[:, 1]) * Y + idx[:, 2]) * Z + idx[:, 3]
+    lin = torch.where(inside, lin, torch.zeros_like(lin)).long()
+    dense = torch.zeros(batch * X * Y * Z, cin, dtype=feat.dtype).index_add(0, lin, feat * inside[:, None].to(feat.dtype))
+    dense = dense.view(batch, X, Y, Z, cin).permute(0, 4, 1, 2, 3)
+    w = weight.view(K, K, K, cin, cout).permute(4, 3, 0, 1, 2)
+    y = torch.nn.functional.conv3d(dense, w, padding=K // 2)            # cross-correlation: out[x] = sum_d in[x+d] w[d]
+    y = y.permute(0, 2, 3, 4, 1).reshape(batch * X * Y * Z, cout)
+    return y[lin] * inside[:, None].to(feat.dtype)
+
+
+def _points(rng, N, batch, shape, dup=0.1, outside=2):
+    X, Y, Z = shape
+    idx = np.stack([rng.integers(0, batch, N), rng.integers(0, X, N), rng.integers(0, Y, N), rng.integers(0, Z, N)], 1)
+    ndup = int(N * dup)
+    if ndup and N > 1:
+        src = rng.integers(0, N, ndup)
+        dst = rng.integers(0, N, ndup)
+        idx[dst] = idx[src]                      # points sharing a cell
+    if outside and N > outside:
+        idx[:outside, 1] = X + 3                 # inactive points (outside the grid)
+    return torch.from_numpy(idx.astype(np.int32))
+
+
+@pytest.mark.parametrize("N,batch,shape,K,cin,cout", [
+    (600, 1, (12, 10, 6), 5, 128, 128),      # the reference's layer: 5^3, 128 -> 128
+    (900, 2, (9, 14, 4), 3, 32, 64),
+    (300, 1, (6, 6, 6), 5, 64, 32),
+    (1, 1, (4, 4, 4), 3, 32, 32),
+    (2000, 1, (8, 8, 3), 5, 128, 128),       # crowded: ~10 points per cell, many duplicates
+])
+def test_subm_conv_forward_backward(N, batch, shape, K, cin, cout):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gaussianformer_amd.sparse_conv import Rulebook, subm_conv3d
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N + K)
+    idx = _points(rng, N, batch, shape)
+    g = torch.Generator().manual_seed(N)
+    feat = torch.randn(N, cin, generator=g)
+    weight = torch.randn(K ** 3, cin, cout, generator=g) * 0.1
+    gout = torch.randn(N, cout, generator=g)
+    f64, w64 = feat.double().requires_grad_(True), weight.double().requires_grad_(True)
+    ref = _dense_reference(f64, idx.long(), w64, batch, shape, K)
+    (ref * gout.double()).sum().backward()
+
+    fd, wd = feat.to(dev).requires_grad_(True), weight.to(dev).requires_grad_(True)
+    rb = Rulebook(idx.to(dev), batch, shape, K)
+    out = subm_conv3d(fd, idx.to(dev), wd, batch, shape, K, rulebook=rb)
+    scale = float(ref.detach().abs().max()) + 1e-6
+    assert (out.detach().cpu().double() - ref.detach()).abs().max() <= 2e-5 * scale
+    out.backward(gout.to(dev))
+    assert (fd.grad.cpu().double() - f64.grad).abs().max() <= 2e-5 * (float(f64.grad.abs().max()) + 1e-6)
+    assert (wd.grad.cpu().double() - w64.grad).abs().max() <= 5e-5 * (float(w64.grad.abs().max()) + 1e-6)
+    # the pair count is the number of (out, in, offset) incidences of the definition
+    cells = {}
+    for n, c in enumerate(idx.tolist()):
+        if 0 <= c[1] < shape[0]:
+            cells.setdefault(tuple(c), []).append(n)
+    r = K // 2
+    want = 0
+    for c, members in cells.items():
+        for dx in range(-r, r + 1):
+            for dy in range(-r, r + 1):
+                for dz in range(-r, r + 1):
+                    want += len(members) * len(cells.get((c[0], c[1] + dx, c[2] + dy, c[3] + dz), ()))
+    assert rb.total == want
+    # deterministic: a second rulebook + apply gives the same bits
+    out2 = Rulebook(idx.to(dev), batch, shape, K).apply(fd.detach(), wd.detach())
+    if len(cells) == sum(len(m) for m in cells.values()):      # no shared cells: summation order is fixed
+        assert torch.equal(out2, out.detach())
+    else:
+        assert torch.allclose(out2, out.detach(), rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_sparse_conv3d_module():
+    """SparseConv3D block at the nuScenes geometry (pc_range +-40 m, 0.5 m cells -> 160x160x16 grid,
+    spconv3d_module.py:47-83): shapes, gradient flow, agreement with the functional op."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gaussianformer_amd.sparse_conv import SparseConv3D, subm_conv3d
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = SparseConv3D(128, 128, pc_range=[-40.0, -40.0, -1.0, 40.0, 40.0, 7.0], grid_size=[0.5, 0.5, 0.5], use_out_proj=True).to(dev)
+    anchor = torch.randn(2, 3000, 11, device=dev)
+    feat = torch.randn(2, 3000, 128, device=dev, requires_grad=True)
+    out = m(feat, anchor)
+    assert out.shape == (2, 3000, 128) and torch.isfinite(out).all()
+    out.square().mean().backward()
+    assert torch.isfinite(feat.grad).all() and float(feat.grad.abs().max()) > 0
+    assert torch.isfinite(m.layer.weight.grad).all() and float(m.layer.weight.grad.abs().max()) > 0
+    # same indices -> same result through the functional op
+    xyz = anchor[..., :3].clamp(-9.21, 9.21).sigmoid() * torch.tensor([80.0, 80.0, 8.0], device=dev) + torch.tensor([-40.0, -40.0, -1.0], device=dev)
+    idx = ((xyz.flatten(0, 1) - torch.tensor([-40.0, -40.0, -1.0], device=dev)) / 0.5).to(torch.int32)
+    indices = torch.cat([torch.arange(2, device=dev, dtype=torch.int32).repeat_interleave(3000)[:, None], idx], -1)
+    y = subm_conv3d(feat.detach().flatten(0, 1), indices, m.layer.weight.detach(), 2, (160, 160, 16), 5)
+    assert torch.allclose(m.output_proj(y.unflatten(0, (2, 3000))), out.detach(), rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_conv3d_multi_layer():
+    """``use_multi_layer`` (spconv3d_module.py:26-37): three conv(+bias) + LayerNorm + ReLU stages over
+    one shared rulebook, against the same chain built from the dense fp64 definition."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gaussianformer_amd.sparse_conv import SparseConv3D, SubMConv3d
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    pc_range, cell = [-4.0, -4.0, -1.0, 4.0, 4.0, 1.0], [0.5, 0.5, 0.5]
+    m = SparseConv3D(32, 64, pc_range=pc_range, grid_size=cell, use_multi_layer=True, kernel_size=3).to(dev)
+    anchor = torch.randn(2, 500, 11, device=dev)
+    feat = torch.randn(2, 500, 32, device=dev, requires_grad=True)
+    out = m(feat, anchor)
+    out.square().mean().backward()
+    assert out.shape == (2, 500, 64)
+
+    idx = m.voxel_indices(anchor).cpu()
+    assert m._spatial == [16, 16, 4]
+    f64 = feat.detach().cpu().double().flatten(0, 1).requires_grad_(True)
+    x, params = f64, []
+    for layer in m.layer:
+        if isinstance(layer, SubMConv3d):
+            w = layer.weight.detach().cpu().double().requires_grad_(True)
+            params.append((layer.weight, w))
+            x = _dense_reference(x, idx.long(), w, 2, (16, 16, 4), 3) + layer.bias.detach().cpu().double()
+        elif isinstance(layer, torch.nn.LayerNorm):
+            x = torch.nn.functional.layer_norm(x, (64,), layer.weight.detach().cpu().double(), layer.bias.detach().cpu().double(), layer.eps)
+        else:
+            x = torch.relu(x)
+    x.square().mean().backward()
+    assert torch.allclose(out.detach().cpu().double().flatten(0, 1), x.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(feat.grad.cpu().double().flatten(0, 1), f64.grad, rtol=1e-3, atol=1e-4 * float(f64.grad.abs().max()))
+    for p, w in params:
+        assert torch.allclose(p.grad.cpu().double(), w.grad, rtol=1e-3, atol=1e-4 * float(w.grad.abs().max()))

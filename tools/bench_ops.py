@@ -99,6 +99,23 @@ report("feature_maps_format (tiled transpose, module-level call)", "nuScenes pyr
 sec = timed(lambda: torch.cat([f.reshape(1, 6, 128, -1) for f in maps], dim=-1).permute(0, 1, 3, 2).contiguous())
 report("feature_maps_format (reference: cat + permute + contiguous on the same GPU)", "nuScenes pyramid", sec, 2 * 4 * sum(m.numel() for m in maps), {})
 
+from gaussianformer_amd.sparse_conv import Rulebook  # noqa: E402
+for A in (25600, 144000):
+    xyz = torch.rand(A, 3, device=dev) * torch.tensor([160.0, 160.0, 16.0], device=dev)
+    idx = torch.cat([torch.zeros(A, 1, dtype=torch.int32, device=dev), xyz.to(torch.int32)], dim=1)
+    feat_sc = torch.randn(A, 128, device=dev)
+    w_sc = torch.randn(125, 128, 128, device=dev) * 0.05
+    sec = timed(lambda: Rulebook(idx, 1, (160, 160, 16), 5), iters=10)
+    rb = Rulebook(idx, 1, (160, 160, 16), 5)
+    flops = 2.0 * rb.total * 128 * 128
+    report("subm_conv rulebook (count + host read + fill)", f"A={A}", sec, 16 * A + 8 * rb.total, {"pairs": rb.total})
+    sec = timed(lambda: rb.apply(feat_sc, w_sc), iters=10)
+    report("subm_conv apply 5^3 128->128 (gather-GEMM + reduce)", f"A={A}", sec, 4 * (2 * rb.total * 128 + 125 * 128 * 128 + 2 * A * 128),
+           {"pairs": rb.total, "TFLOPs": flops / sec / 1e12})
+    go_sc = torch.randn(A, 128, device=dev)
+    sec = timed(lambda: rb.weight_grad(feat_sc, go_sc), iters=10)
+    report("subm_conv weight gradient", f"A={A}", sec, 4 * (2 * rb.total * 128 + 125 * 128 * 128), {"pairs": rb.total, "TFLOPs": flops / sec / 1e12})
+
 DAF_CASES = () if "--splat-only" in sys.argv else ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000"))
 for pts, name in DAF_CASES:
     d = make_daf_inputs(num_pts=pts, seed=0)
