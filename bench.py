@@ -10,7 +10,8 @@ detection, inputs and outputs resident in HBM) over one frame: P = 25 601 Gaussi
 200x200x16 grid with 18 semantic channels.  With N > 1 ranks every rank splats its own shard of
 P Gaussians into a full partial grid and the partial logits are summed with one RCCL
 all-reduce (weak scaling: per-GPU work is fixed); ``value`` counts the Gaussians
-of all ranks.  Rank 0 prints one JSON line.
+of all ranks.  Rank 0 prints one JSON line.  Extras next to `value`, never instead of it: `two_stream` (N = 1, two
+frames in flight) and `reduce_scatter_labels` (N > 1, the label-producing variant with half the xGMI traffic).
 """
 import argparse
 import ctypes
@@ -95,8 +96,13 @@ def main():
         raise RuntimeError("bench.py needs an MI355X; there is no CPU path for the product")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # GF_BENCH_FORCE_DIST=1 takes the RCCL path with a single rank too (a 1-GPU check of the plumbing)
+    use_dist = world > 1 or os.environ.get("GF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
 
@@ -114,7 +120,7 @@ def main():
 
     def step():
         plan.run(stream)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(plan.logits, op=dist.ReduceOp.SUM)
 
     for _ in range(args.warmup):
@@ -125,17 +131,17 @@ def main():
     # region (an event pair costs ~3 us of stream time; sampling keeps the region representative)
     _lib.check(lib.gf_profile_stride(PROFILE_STRIDE), "gf_profile_stride")
     _lib.check(lib.gf_profile_enable(args.steps), "gf_profile_enable")
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -167,6 +173,40 @@ def main():
         two_stream = {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
                       "note": "same K steps, two frames in flight on two HIP streams (double-buffered outputs and workspace)"}
 
+    # Extra, N > 1 only: the same K steps ending in occupancy labels instead of replicated logits --
+    # reduce-scatter of the partial grids (each rank receives the summed logits of its 1/N of the
+    # voxels), labels on the owned slab (gf_head_labels), all-gather of the labels: half the xGMI
+    # traffic of the all-reduce (gaussianformer_amd.head.sharded_splat_labels).  Never `value`.
+    rs_labels = None
+    if use_dist and si.variant != "prob" and N % world == 0:
+        try:
+            from gaussianformer_amd.head import occupancy_labels
+            mine = torch.empty(N // world, 18, dtype=torch.float32, device=dev)
+            labels = torch.empty(N, dtype=torch.int64, device=dev)
+
+            def label_step():
+                plan.run(stream)
+                dist.reduce_scatter_tensor(mine, plan.logits, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(labels, occupancy_labels(mine))
+
+            for _ in range(max(2, args.warmup // 2)):
+                label_step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                label_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            rs_labels = {"value": world * P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
+                         "note": "same K steps ending in labels: reduce-scatter of the partial logits, labels on the owned "
+                                 "slab, all-gather of the labels"}
+        except Exception as exc:  # an extra must never cost the headline line
+            rs_labels = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * P / (elapsed / args.steps)
@@ -193,10 +233,12 @@ def main():
         }
         if two_stream:
             out["two_stream"] = two_stream
+        if rs_labels:
+            out["reduce_scatter_labels"] = rs_labels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(si, pi, mi, radii, cov6)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
