@@ -269,16 +269,56 @@ __global__ __launch_bounds__(256) void gf_bwd_bsum_kernel(BwdArgs a)
     if (threadIdx.x == 0) a.bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// DPP add-reduce whose total is valid in lane 63 only (no broadcast)
-__device__ __forceinline__ float wave_sum63(float v)
+// Transposed wave reduction: 32 values per lane in, each summed over the 64 lanes, and the total of
+// value reduce_slot(lane) left in that lane (lanes 2m and 2m + 1 hold the same one).  Every step halves
+// both the number of live values and the width they are spread over: the two 32-lane halves trade
+// registers (v_permlane32_swap), then the odd and even 16-lane rows (v_permlane16_swap), then DPP
+// inside a row with a select deciding which value a lane keeps.  70 instructions for 32 values where
+// 32 six-step butterflies take 192 -- and the 28 gradients of a Gaussian leave in one vector store.
+// The swaps are issued as inline asm, four register pairs per block: hipcc 7.2 mis-tracks the second
+// result of __builtin_amdgcn_permlane{16,32}_swap (it adds r.x to itself or to a neighbouring pair's
+// register -- tools/microbench/lanes.hip reproduces it).  The s_nop pads cover the VALU-write ->
+// permlane-swap and permlane-swap -> VALU-read wait states, which the compiler cannot see inside asm.
+// After v_permlane32_swap a, b: a = [a_lo, b_lo], b = [a_hi, b_hi] (halves of 32 lanes);
+// after v_permlane16_swap a, b: a = [a_r0, b_r0, a_r2, b_r2], b = [a_r1, b_r1, a_r3, b_r3] (rows of 16).
+#define GF_SWAP4(OP, a0, b0, a1, b1, a2, b2, a3, b3)                                                           \
+    asm volatile("s_nop 1\n\t" OP " %0, %1\n\t" OP " %2, %3\n\t" OP " %4, %5\n\t" OP " %6, %7\n\ts_nop 1"     \
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3))
+
+template <int DPP_CTRL, int BIT>
+__device__ __forceinline__ float fold_add(float a, float b, int lane)  // lanes with BIT clear keep a, the others b
 {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true));
-    return v;
+    const bool hi = lane & BIT;
+    const float keep = hi ? b : a, give = hi ? a : b;
+    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), DPP_CTRL, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float wave_reduce32(float (&v)[32], int lane)
+{
+    float w[16], x[8], y[4], z[2];
+    // halves: lanes < 32 end up with v[2j] summed over {l, l + 32}, lanes >= 32 with v[2j + 1]
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) GF_SWAP4("v_permlane32_swap_b32", v[j], v[j + 1], v[j + 2], v[j + 3], v[j + 4], v[j + 5], v[j + 6], v[j + 7]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = v[2 * j] + v[2 * j + 1];
+    // rows: even rows keep w[2j], odd rows w[2j + 1]
+#pragma unroll
+    for (int j = 0; j < 16; j += 8) GF_SWAP4("v_permlane16_swap_b32", w[j], w[j + 1], w[j + 2], w[j + 3], w[j + 4], w[j + 5], w[j + 6], w[j + 7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = w[2 * j] + w[2 * j + 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = fold_add<0x128, 8>(x[2 * j], x[2 * j + 1], lane);  // row_ror:8 = lane ^ 8
+#pragma unroll
+    for (int j = 0; j < 2; ++j) z[j] = fold_add<0x141, 4>(y[2 * j], y[2 * j + 1], lane);  // row_half_mirror: l -> 7 - l
+    float t = fold_add<0x4e, 2>(z[0], z[1], lane);                                         // quad_perm [2,3,0,1] = lane ^ 2
+    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xb1, 0xf, 0xf, true));  // lane ^ 1
+    return t;
+}
+
+// index of the value a lane ends up with: value bit k is decided by the (k+1)-th step
+__device__ __forceinline__ int reduce_slot(int lane)
+{
+    return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
 }
 
 template <int VARIANT>
@@ -503,41 +543,34 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
             p = p_n; ptx = ptx_n; pty = pty_n; ptz = ptz_n;
         }
 
-        // reduce across the wave (totals valid in lane 63)
-        mg0 = wave_sum63(mg0); mg1 = wave_sum63(mg1); mg2 = wave_sum63(mg2);
-        og = wave_sum63(og);
-        cg0 = wave_sum63(cg0); cg1 = wave_sum63(cg1); cg2 = wave_sum63(cg2);
-        cg3 = wave_sum63(cg3); cg4 = wave_sum63(cg4); cg5 = wave_sum63(cg5);
+        // Reduce across the wave and store: slots 0-17 semantics, 18-23 covariance, 24-26 mean,
+        // 27 opacity, 28 the determinant gradient of the prob variant (lane 14 holds slot 28).
+        float total;
+        {
+            float v[32];
 #pragma unroll
-        for (int ch = 0; ch < kC; ++ch) sg[ch] = wave_sum63(sg[ch]);
-        if (VARIANT == GF_SPLAT_PROB) {
-            dg = wave_sum63(dg);
-            // deter_grad terms, model/head/localagg_prob/src/backward.cu:102-107
-            cg0 += dg * (c1y * c1z - c2y * c2y);
-            cg1 += dg * (c1x * c1z - c2z * c2z);
-            cg2 += dg * (c1x * c1y - c2x * c2x);
-            cg3 += 2 * dg * (c2y * c2z - c1z * c2x);
-            cg4 += 2 * dg * (c2x * c2z - c1x * c2y);
-            cg5 += 2 * dg * (c2x * c2y - c1y * c2z);
+            for (int ch = 0; ch < kC; ++ch) v[ch] = sg[ch];
+            v[18] = cg0; v[19] = cg1; v[20] = cg2; v[21] = cg3; v[22] = cg4; v[23] = cg5;
+            v[24] = mg0; v[25] = mg1; v[26] = mg2; v[27] = og;
+            v[28] = dg; v[29] = 0.f; v[30] = 0.f; v[31] = 0.f;
+            total = wave_reduce32(v, lane);
         }
-        if (lane == 63) {
-            float *pm = a.means_grad + 3 * (size_t)gid;
-            float *pc = a.cov_grad + 6 * (size_t)gid;
-            float *ps = a.sem_grad + (size_t)kC * gid;
-            if (o0 == 0 && o1 == vol) {
-                pm[0] = mg0; pm[1] = mg1; pm[2] = mg2;
-                a.opa_grad[gid] = og;
-                pc[0] = cg0; pc[1] = cg1; pc[2] = cg2; pc[3] = cg3; pc[4] = cg4; pc[5] = cg5;
-#pragma unroll
-                for (int ch = 0; ch < kC; ++ch) ps[ch] = sg[ch];
-            } else {
-                unsafeAtomicAdd(pm, mg0); unsafeAtomicAdd(pm + 1, mg1); unsafeAtomicAdd(pm + 2, mg2);
-                unsafeAtomicAdd(a.opa_grad + gid, og);
-                unsafeAtomicAdd(pc, cg0); unsafeAtomicAdd(pc + 1, cg1); unsafeAtomicAdd(pc + 2, cg2);
-                unsafeAtomicAdd(pc + 3, cg3); unsafeAtomicAdd(pc + 4, cg4); unsafeAtomicAdd(pc + 5, cg5);
-#pragma unroll
-                for (int ch = 0; ch < kC; ++ch) unsafeAtomicAdd(ps + ch, sg[ch]);
-            }
+        const int slot = reduce_slot(lane);
+        if (VARIANT == GF_SPLAT_PROB) {
+            // deter_grad terms, model/head/localagg_prob/src/backward.cu:102-107
+            const float dgt = __shfl(total, 14, 64);
+            const float k0 = c1y * c1z - c2y * c2y, k1 = c1x * c1z - c2z * c2z, k2 = c1x * c1y - c2x * c2x;
+            const float k3 = 2 * (c2y * c2z - c1z * c2x), k4 = 2 * (c2x * c2z - c1x * c2y), k5 = 2 * (c2x * c2y - c1y * c2z);
+            const float kk = slot == 18 ? k0 : slot == 19 ? k1 : slot == 20 ? k2 : slot == 21 ? k3 : slot == 22 ? k4 : k5;
+            if (slot >= 18 && slot < 24) total += dgt * kk;
+        }
+        if (slot < 28 && !(lane & 1)) {
+            float *dst = slot < 18 ? a.sem_grad + (size_t)kC * gid + slot
+                       : slot < 24 ? a.cov_grad + 6 * (size_t)gid + (slot - 18)
+                       : slot < 27 ? a.means_grad + 3 * (size_t)gid + (slot - 24)
+                                   : a.opa_grad + gid;
+            if (o0 == 0 && o1 == vol) *dst = total;
+            else unsafeAtomicAdd(dst, total);
         }
         r0 = gstart + (unsigned long long)o1;
         if (o1 == vol) {

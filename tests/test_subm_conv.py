@@ -147,3 +147,31 @@ def test_sparse_conv3d_multi_layer():
     assert torch.allclose(feat.grad.cpu().double().flatten(0, 1), f64.grad, rtol=1e-3, atol=1e-4 * float(f64.grad.abs().max()))
     for p, w in params:
         assert torch.allclose(p.grad.cpu().double(), w.grad, rtol=1e-3, atol=1e-4 * float(w.grad.abs().max()))
+
+
+def test_subm_conv_degenerate_inputs():
+    """No points, every point outside the grid, and an isolated point (only the centre offset pairs with itself)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gaussianformer_amd.sparse_conv import subm_conv3d, Rulebook
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    w = torch.randn(27, 32, 64, device=dev)
+    # empty
+    out = subm_conv3d(torch.zeros(0, 32, device=dev), torch.zeros(0, 4, dtype=torch.int32, device=dev), w, 1, (4, 4, 4), 3)
+    assert out.shape == (0, 64)
+    # all outside -> no pairs, zero output, zero gradients
+    idx = torch.tensor([[0, 9, 0, 0], [0, -1, 2, 2], [3, 1, 1, 1]], dtype=torch.int32, device=dev)
+    f = torch.randn(3, 32, device=dev, requires_grad=True)
+    wp = w.clone().requires_grad_(True)
+    rb = Rulebook(idx, 1, (4, 4, 4), 3)
+    assert rb.total == 0
+    out = subm_conv3d(f, idx, wp, 1, (4, 4, 4), 3, rulebook=rb)
+    assert float(out.abs().max()) == 0.0
+    out.sum().backward()
+    assert float(f.grad.abs().max()) == 0.0 and float(wp.grad.abs().max()) == 0.0
+    # one isolated point: out = feat . W[centre]
+    idx = torch.tensor([[0, 2, 2, 2]], dtype=torch.int32, device=dev)
+    f = torch.randn(1, 32, device=dev)
+    out = subm_conv3d(f, idx, w, 1, (5, 5, 5), 3)
+    assert torch.allclose(out, f @ w[13], rtol=1e-5, atol=1e-5)
