@@ -7,8 +7,11 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$R.log 2>&
 bash tools/collect_profiles.sh $R > gpurun_out/collect_$R.log 2>&1; head -3 gpurun_out/collect_$R.log | cut -c1-600
 timeout 600 python tools/bench_ops.py > gpurun_out/profiles_$R/bench_ops_$R.jsonl 2> gpurun_out/bench_ops.err; cat gpurun_out/profiles_$R/bench_ops_$R.jsonl
 timeout 300 python tools/timeline.py > gpurun_out/profiles_$R/timeline_render_$R.txt 2>&1; tail -20 gpurun_out/profiles_$R/timeline_render_$R.txt
+for m in valu mfma lanes; do [ -x tools/microbench/$m ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/microbench/$m tools/microbench/$m.hip 2>/dev/null; done
 ./tools/microbench/valu > gpurun_out/profiles_$R/microbench_valu_$R.txt 2>&1
 ./tools/microbench/mfma > gpurun_out/profiles_$R/microbench_mfma_$R.txt 2>&1
+./tools/microbench/lanes > gpurun_out/profiles_$R/microbench_lanes_$R.txt 2>&1
+rm -rf gpurun_out/kt_subm; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_subm -- python tools/prof_subm.py > gpurun_out/kt_subm.log 2>&1; cp $(find gpurun_out/kt_subm -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_subm_$R.csv
 rm -rf gpurun_out/kt_daf; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_daf -- python tools/prof_daf.py > gpurun_out/kt_daf.log 2>&1; cp $(find gpurun_out/kt_daf -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_daf_$R.csv
 rm -rf gpurun_out/kt_q; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_q -- python tools/quick_time.py nuscenes_gs25600_solid > gpurun_out/profiles_$R/quick_time_gs25600_$R.log 2>&1; cp $(find gpurun_out/kt_q -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_ops_gs25600_$R.csv
 # BASELINE config [3]: nuscenes_gs144000 inference
