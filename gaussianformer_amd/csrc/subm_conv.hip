@@ -190,12 +190,18 @@ __global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
 
 // largest k with start[k] <= t (start is non-decreasing, start[0] = 0, t < start[K3]): the segment
 // that holds tile / chunk t.  Empty segments repeat their successor's value and are skipped.
-__device__ __forceinline__ int subm_segment_of(const unsigned int *start, int K3, unsigned int t)
+// The table (<= 344 entries) is copied to LDS with one load per thread first: searched in global
+// memory the seven dependent loads cost 3-5 us per workgroup, as long as the workgroup's MFMAs.
+constexpr int kSubmMaxK3 = 343;
+
+__device__ __forceinline__ int subm_segment_of(const unsigned int *start, int K3, unsigned int t, unsigned int *s_start)
 {
+    for (int e = threadIdx.x; e <= K3; e += blockDim.x) s_start[e] = start[e];
+    __syncthreads();
     int lo = 0, hi = K3;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (start[mid] <= t) lo = mid; else hi = mid;
+        if (s_start[mid] <= t) lo = mid; else hi = mid;
     }
     return lo;
 }
@@ -216,13 +222,14 @@ __global__ __launch_bounds__(256, 4) void gf_subm_gemm_kernel(SubmArgs a)
     constexpr int HALF = CIN / 2, NG = SW / 32;
     constexpr int WQ = CIN * SW / 4 / 256;  // float4 of the W slice per thread
     static_assert(COUT % SW == 0 && SW % 32 == 0 && WQ >= 1, "unsupported slice");
+    __shared__ unsigned int s_start[kSubmMaxK3 + 1];
     const unsigned int t = blockIdx.x;
-    if (t >= a.t.tile_start[a.K3]) return;
-    const int k = subm_segment_of(a.t.tile_start, a.K3, t);
+    const int k = subm_segment_of(a.t.tile_start, a.K3, t, s_start);
+    if (t >= s_start[a.K3]) return;  // workgroup-uniform
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int c_lo = blockIdx.y * SW;
-    const unsigned int slot0 = a.t.kstart[k] + (t - a.t.tile_start[k]) * kPairTile + wave * 32;
+    const unsigned int slot0 = a.t.kstart[k] + (t - s_start[k]) * kPairTile + wave * 32;
     const unsigned int seg_end = a.t.kstart[k + 1];
     // gathered feature half-row and the W slice: every load is issued before the first use
     const unsigned int myslot = slot0 + i;
@@ -273,29 +280,46 @@ __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
 {
     constexpr int CG = COUT / 4;
     constexpr int ROWS = 256 / CG;
+    constexpr int UNR = 4;
     const int tc = threadIdx.x % CG;
     const int i = blockIdx.x * ROWS + threadIdx.x / CG;
-    if (i >= a.N) return;
+    const int lane = threadIdx.x & 63;
+    const int gshift = lane & ~(CG - 1);  // first lane of this point's group inside the wave
+    const bool live = i < a.N;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int *sf = a.t.slot_first + (size_t)i * a.K3;
-    const unsigned char *cn = a.t.cnt + (size_t)i * a.K3;
+    const int *sf = a.t.slot_first + (size_t)(live ? i : 0) * a.K3;
+    const unsigned char *cn = a.t.cnt + (size_t)(live ? i : 0) * a.K3;
     // the CG lanes of a point scan its K^3 counts together (most are zero), then walk the hits in
-    // ascending k -- the summation order is fixed by k, not by where the pairs were stored
+    // ascending k -- the summation order is fixed by k, not by where the pairs were stored.  The first
+    // rows of up to UNR hits are requested together: one at a time the walk is a chain of ~1 us loads.
     for (int k0 = 0; k0 < a.K3; k0 += CG) {
         const int kk = k0 + tc;
-        const int c_mine = kk < a.K3 ? cn[kk] : 0;
+        const int c_mine = live && kk < a.K3 ? cn[kk] : 0;
         const int s_mine = c_mine ? sf[kk] : 0;
-        for (int l = 0; l < CG; ++l) {
-            const int c = __shfl(c_mine, l, CG);
-            if (!c) continue;
-            const int s0 = __shfl(s_mine, l, CG);
-            for (int sidx = 0; sidx < c; ++sidx) {
-                const float4 v = reinterpret_cast<const float4 *>(a.partial + (size_t)(s0 + sidx) * COUT)[tc];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        unsigned long long hits = (__ballot(c_mine != 0) >> gshift) & (CG == 64 ? ~0ull : ((1ull << CG) - 1ull));
+        while (hits) {  // uniform within the group; other groups of the wave idle through it
+            int l[UNR], c[UNR], s0[UNR];
+            float4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                l[u] = hits ? __builtin_ctzll(hits) : -1;
+                if (hits) hits &= hits - 1;
+                c[u] = l[u] >= 0 ? __shfl(c_mine, max(l[u], 0), CG) : 0;
+                s0[u] = __shfl(s_mine, max(l[u], 0), CG);
+                v[u] = c[u] ? reinterpret_cast<const float4 *>(a.partial + (size_t)s0[u] * COUT)[tc] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (!c[u]) continue;
+                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                for (int sidx = 1; sidx < c[u]; ++sidx) {  // several points in the neighbour cell
+                    const float4 e = reinterpret_cast<const float4 *>(a.partial + (size_t)(s0[u] + sidx) * COUT)[tc];
+                    acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+                }
             }
         }
     }
-    reinterpret_cast<float4 *>(a.out + (size_t)i * COUT)[tc] = acc;
+    if (live) reinterpret_cast<float4 *>(a.out + (size_t)i * COUT)[tc] = acc;
 }
 
 // staging helpers of the weight gradient: thread tid owns float4 (tid + 256 u) of the 32 x C block, u < Q
@@ -334,12 +358,13 @@ __global__ __launch_bounds__(256, 3) void gf_subm_wgrad_kernel(SubmArgs a)
     constexpr int FQ = kBatch * CIN / 4 / 256, GQ = kBatch * COUT / 4 / 256;  // float4 per thread and step
     __shared__ __attribute__((aligned(16))) float s_f[kBatch * FS];
     __shared__ __attribute__((aligned(16))) float s_g[kBatch * GS];
+    __shared__ unsigned int s_start[kSubmMaxK3 + 1];
     const unsigned int c = blockIdx.x;
-    if (c >= a.t.chunk_start[a.K3]) return;
-    const int k = subm_segment_of(a.t.chunk_start, a.K3, c);
-    const unsigned int p0 = a.t.kstart[k] + (c - a.t.chunk_start[k]) * kWgradChunk;
+    const int k = subm_segment_of(a.t.chunk_start, a.K3, c, s_start);
+    if (c >= s_start[a.K3]) return;  // workgroup-uniform
+    const unsigned int p0 = a.t.kstart[k] + (c - s_start[k]) * kWgradChunk;
     const unsigned int p1 = min(a.t.kstart[k + 1], p0 + kWgradChunk);
-    const bool shared_block = a.t.chunk_start[k + 1] - a.t.chunk_start[k] > 1;  // several workgroups add into grad_weight[k]
+    const bool shared_block = s_start[k + 1] - s_start[k] > 1;  // several workgroups add into grad_weight[k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     // pair indices are fetched two steps ahead and the rows one step ahead, so neither load chain is

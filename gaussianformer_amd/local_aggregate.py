@@ -249,8 +249,10 @@ class _LocalAggregate(torch.autograd.Function):
         state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii = ctx.saved_tensors
         mg, og, sg, cg = splat_backward(_lib.GF_SPLAT_BASE, pts, points_int, means3D, means3D_int, opacities,
                                         semantics, radii, cov3D, H, W, D, out_grad, state=state)
-        # grads for (means3D, opacities, semantics, cov3D) only -- :91-104
-        return None, None, mg, None, og, sg, None, cg, None, None, None
+        # grads for (means3D, opacities, semantics, cov3D) only -- :91-104.  The reference returns the opacity
+        # gradient as [P] whatever the input's shape; a [P,1] opacity that requires grad would be rejected by
+        # autograd there, so it is reshaped here.
+        return None, None, mg, None, og.view_as(opacities), sg, None, cg, None, None, None
 
 
 class _LocalAggregateProb(torch.autograd.Function):
@@ -274,7 +276,7 @@ class _LocalAggregateProb(torch.autograd.Function):
                                         radii, cov3D, H, W, D, logits_grad,
                                         fwd_outputs=(logits, bin_logits, density, probability),
                                         bin_logits_grad=bin_logits_grad, density_grad=density_grad, state=state)
-        return None, None, mg, None, og, sg, None, cg, None, None, None
+        return None, None, mg, None, og.view_as(opas), sg, None, cg, None, None, None
 
 
 class _AggregatorBase(nn.Module):

@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""One training step of the hot path, chained through torch autograd (BASELINE.json configs[2] without
+the parts that stay torch / mmcv in the reference: image backbone, FFNs, norms, refinement, losses).
+
+    image pyramid -> feature_maps_format
+    4 encoder blocks: SparseConv3D (rulebook + gather-GEMM) -> weights_fc (torch GEMM) ->
+                      deformable_prepare (projection + masked softmax) -> DAF.apply -> sum over key points
+    head:             LocalAggregator.forward_from_rotations (fused Gaussian pre-processing + splat)
+    loss = <logits, fixed target>; backward through everything.
+
+Every native op of the step runs from libgf_hip.so; what torch contributes is the glue named above.
+Prints one JSON line: forward and forward+backward milliseconds per step, and that every leaf received a
+finite, non-zero gradient.  Needs an MI355X.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gaussianformer_amd.deformable_aggregation import DeformableAggregationFunction as DAF  # noqa: E402
+from gaussianformer_amd.deformable_prepare import deformable_prepare  # noqa: E402
+from gaussianformer_amd.local_aggregate import LocalAggregator  # noqa: E402
+from gaussianformer_amd.sparse_conv import SparseConv3D  # noqa: E402
+from gaussianformer_amd.synthetic import DAF_LEVELS, voxel_centres  # noqa: E402
+
+PC_RANGE = [-40.0, -40.0, -1.0, 40.0, 40.0, 5.4]
+CAMS, LEVELS, GROUPS, KEY_PTS, EMBED = 6, 4, 4, 9, 128
+
+
+def cameras(dev):
+    """Six pinhole cameras 60 degrees apart, 1600x900, nuScenes-like intrinsics (a point is seen by one or two)."""
+    pm = torch.eye(4).repeat(1, CAMS, 1, 1)
+    K = torch.tensor([[1260.0, 0, 800.0], [0, 1260.0, 450.0], [0, 0, 1.0]])
+    for c in range(CAMS):
+        yaw = 2 * np.pi * c / CAMS
+        R = torch.tensor([[-np.sin(yaw), np.cos(yaw), 0.0], [0.0, 0.0, -1.0], [np.cos(yaw), np.sin(yaw), 0.0]], dtype=torch.float32)
+        pm[0, c, :3, :3] = K @ R
+        pm[0, c, :3, 3] = K @ torch.tensor([0.0, 1.5, 0.0])
+    return pm.to(dev), torch.tensor([[[1600.0, 900.0]] * CAMS], device=dev)
+
+
+class Block(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.spconv = SparseConv3D(EMBED, EMBED, PC_RANGE, [0.5, 0.5, 0.5], use_out_proj=False, kernel_size=5)
+        self.weights_fc = torch.nn.Linear(EMBED, CAMS * LEVELS * KEY_PTS * GROUPS)
+        self.key_offsets = torch.nn.Parameter(torch.randn(KEY_PTS, 3) * 0.5)
+
+    def forward(self, feat, anchor, means, scales, table, ss, st, pm, wh):
+        bs, A, _ = feat.shape
+        feat = feat + self.spconv(feat, anchor)
+        key_points = means.unsqueeze(2) + self.key_offsets * scales.unsqueeze(2)
+        raw = self.weights_fc(feat).reshape(bs, A, CAMS, LEVELS, KEY_PTS, GROUPS)
+        points_2d, weights = deformable_prepare(key_points, pm, wh, raw)
+        sampled = DAF.apply(table, ss, st, points_2d, weights)          # [bs, A * KEY_PTS, EMBED]
+        return feat + sampled.view(bs, A, KEY_PTS, EMBED).sum(2)
+
+
+def run(anchors=25600, steps=10, warmup=3):
+    """Runs the chained step and returns the result record (raises if a leaf got no usable gradient)."""
+    args = argparse.Namespace(anchors=anchors, steps=steps, warmup=warmup)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench_step.py needs an MI355X")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    A = args.anchors
+    H, W, D, cell = 200, 200, 16, 0.4
+    pc_min = PC_RANGE[:3]
+
+    blocks = torch.nn.ModuleList([Block() for _ in range(4)]).to(dev)
+    for b in blocks:
+        torch.nn.init.normal_(b.spconv.layer.weight, std=0.01)
+    anchor = torch.randn(1, A, 11, device=dev).requires_grad_(True)
+    sem_raw = torch.randn(1, A, 18, device=dev).requires_grad_(True)
+    feat0 = torch.randn(1, A, EMBED, device=dev).requires_grad_(True)
+    maps = [torch.randn(1, CAMS, EMBED, h, w, device=dev).requires_grad_(True) for h, w in DAF_LEVELS]
+    pm, wh = cameras(dev)
+    pts = torch.from_numpy(voxel_centres(H, W, D, cell, np.asarray(pc_min, dtype=np.float32))).to(dev)[None]
+    target = torch.randn(H * W * D, 18, device=dev)
+    agg = LocalAggregator(3, H, W, D, pc_min, cell).to(dev)
+    lo = torch.tensor(PC_RANGE[:3], device=dev)
+    span = torch.tensor(PC_RANGE[3:], device=dev) - lo
+
+    def forward():
+        means = anchor[..., :3].clamp(-9.21, 9.21).sigmoid() * span + lo
+        scales = anchor[..., 3:6].sigmoid() * (0.64 - 0.08) + 0.08
+        rots = torch.nn.functional.normalize(anchor[..., 6:10], dim=-1)
+        opa = anchor[..., 10:11].sigmoid()
+        sem = torch.nn.functional.softplus(sem_raw)
+        table, ss, st = DAF.feature_maps_format(maps)
+        feat = feat0
+        for b in blocks:
+            feat = b(feat, anchor, means, scales, table, ss, st, pm, wh)
+        # the refinement layer of the reference would turn feat into anchor updates; here feat gates the opacity
+        opa = opa * feat.mean(-1, keepdim=True).sigmoid()
+        logits = agg.forward_from_rotations(pts, means, opa, sem, scales, rots)
+        if isinstance(logits, (tuple, list)):
+            logits = logits[0]
+        return (logits.reshape(-1, 18) * target).mean()
+
+    leaves = [anchor, sem_raw, feat0] + maps + list(blocks.parameters())
+
+    def step(backward=True):
+        for t in leaves:
+            t.grad = None
+        loss = forward()
+        if backward:
+            loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(backward=False)
+    torch.cuda.synchronize()
+    fwd = (time.perf_counter() - t0) / args.steps
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    full = (time.perf_counter() - t0) / args.steps
+
+    bad = [i for i, t in enumerate(leaves) if t.grad is None or not torch.isfinite(t.grad).all() or float(t.grad.abs().max()) == 0.0]
+    out = {"op": "hot-path training step (4 x [sparse conv + DAF prepare + DAF] + fused prepare + splat, fwd + bwd)",
+           "anchors": A, "sample_points": A * KEY_PTS, "forward_ms": fwd * 1e3, "forward_backward_ms": full * 1e3,
+           "loss": float(loss.detach()), "leaves": len(leaves), "leaves_without_finite_nonzero_grad": bad}
+    if bad:
+        raise RuntimeError(f"gradient check failed for leaves {bad}: {out}")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--anchors", type=int, default=25600)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    print(json.dumps(run(args.anchors, args.steps, args.warmup)))
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,9 @@ for m in valu mfma lanes; do [ -x tools/microbench/$m ] || /opt/rocm/bin/hipcc -
 rm -rf gpurun_out/kt_subm; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_subm -- python tools/prof_subm.py > gpurun_out/kt_subm.log 2>&1; cp $(find gpurun_out/kt_subm -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_subm_$R.csv
 rm -rf gpurun_out/kt_daf; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_daf -- python tools/prof_daf.py > gpurun_out/kt_daf.log 2>&1; cp $(find gpurun_out/kt_daf -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_daf_$R.csv
 rm -rf gpurun_out/kt_q; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_q -- python tools/quick_time.py nuscenes_gs25600_solid > gpurun_out/profiles_$R/quick_time_gs25600_$R.log 2>&1; cp $(find gpurun_out/kt_q -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_ops_gs25600_$R.csv
+# BASELINE config [2]: the native ops of one training step, chained
+timeout 300 python tools/bench_step.py > gpurun_out/profiles_$R/bench_step_$R.json 2> gpurun_out/bench_step.err
+rm -rf gpurun_out/kt_step; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_step -- python tools/bench_step.py --steps 5 --warmup 2 > gpurun_out/kt_step.log 2>&1; cp $(find gpurun_out/kt_step -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_step_$R.csv
 # BASELINE config [3]: nuscenes_gs144000 inference
 python bench.py --config nuscenes_gs144000 --no-cpu-baseline > gpurun_out/profiles_$R/bench_gs144000_$R.json 2> gpurun_out/bench_gs144000.err
 rm -rf gpurun_out/kt_144; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_144 -- python bench.py --config nuscenes_gs144000 --no-cpu-baseline --no-two-stream > gpurun_out/kt_144.log 2>&1; cp $(find gpurun_out/kt_144 -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_bench_gs144000_$R.csv
