@@ -32,6 +32,8 @@ ids = ids[valid]
 T = T[T[:, 0] > 0]
 t0 = T[:, 0].min()
 T = (T - t0) / 100.0  # 100 MHz -> us
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez("gpurun_out/timeline_blocks_%s.npz" % config, block=np.nonzero(valid)[0], ids=ids, T=T)
 print("blocks", len(T), "kernel span us", T[:, 3].max())
 for name, col in (("start", 0), ("list built", 1), ("consumed", 2), ("end", 3)):
     v = T[:, col]; print(f"{name:12s} min {v.min():7.2f} p50 {np.median(v):7.2f} p90 {np.percentile(v,90):7.2f} max {v.max():7.2f}")
