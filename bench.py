@@ -35,11 +35,14 @@ def algorithmic_bytes(P, N, C=18):
     return 128 * P + 24 * N + 4 * C * N
 
 
-def measured_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+def measured_traffic_bytes(config):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload
     (profiles/traffic_*.json, FETCH_SIZE x2 correction applied there); None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
+    pattern = {"nuscenes_gs25600_solid": "traffic_r*.json", "nuscenes_gs144000": "traffic_gs144000_r*.json"}.get(config)
+    if pattern is None:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
         return None
     try:
@@ -216,7 +219,7 @@ def main():
             achieved = abytes / (kernel_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": measured_traffic_bytes() if args.config == "nuscenes_gs25600_solid" else None,
+                        "traffic": measured_traffic_bytes(args.config),
                         "kernel": "gf_splat_render_kernel", "kernel_us": kernel_ms * 1e3,
                         "kernel_launches_timed": n_ev,
                         "algorithmic_bytes": abytes}

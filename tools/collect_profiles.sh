@@ -14,6 +14,14 @@ for pass in "A:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACT
 done
 python tools/make_traffic.py gpurun_out/pmc_${R}_C gpurun_out/pmc_${R}_D $OUT/traffic_$R.json $R
 cp $OUT/traffic_$R.json profiles/traffic_$R.json   # bench.py reports the newest profiles/traffic_r*.json
+# the same two TCC passes for BASELINE config [3] (P = 144 000)
+for pass in "C:FETCH_SIZE" "D:WRITE_SIZE"; do
+  name=${pass%%:*}; ctrs=${pass#*:}
+  rm -rf gpurun_out/pmc144_${R}_$name
+  rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/pmc144_${R}_$name -- python tools/prof_fwd.py nuscenes_gs144000 8 0 > gpurun_out/pmc144_${R}_$name.log 2>&1
+done
+python tools/make_traffic.py gpurun_out/pmc144_${R}_C gpurun_out/pmc144_${R}_D $OUT/traffic_gs144000_$R.json $R nuscenes_gs144000 144000
+cp $OUT/traffic_gs144000_$R.json profiles/traffic_gs144000_$R.json
 python bench.py --steps 200 --warmup 20 > $OUT/bench_$R.json 2> $OUT/bench_$R.err
 cat $OUT/bench_$R.json
 rm -rf gpurun_out/kt_$R

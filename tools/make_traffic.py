@@ -1,6 +1,6 @@
 """HBM bytes per render-kernel launch from the two TCC PMC passes (FETCH_SIZE, WRITE_SIZE; separate
 rocprofv3 --pmc runs), with the gfx950 correction MI355X_MICROARCH.md prescribes (FETCH_SIZE x2;
-both counters are in KiB).  usage: make_traffic.py <fetch_dir> <write_dir> <out.json> <tag>"""
+both counters are in KiB).  usage: make_traffic.py <fetch_dir> <write_dir> <out.json> <tag> [config P]"""
 import collections
 import csv
 import glob
@@ -8,6 +8,8 @@ import json
 import sys
 
 fetch_dir, write_dir, out, tag = sys.argv[1:5]
+config = sys.argv[5] if len(sys.argv) > 5 else "nuscenes_gs25600_solid"
+P = int(sys.argv[6]) if len(sys.argv) > 6 else 25601
 
 
 def mean_counter(d, counter):
@@ -22,9 +24,10 @@ def mean_counter(d, counter):
 
 name, fetch, n = mean_counter(fetch_dir, "FETCH_SIZE")
 _, write, _ = mean_counter(write_dir, "WRITE_SIZE")
-P, N = 25601, 640000
+N = 640000
 json.dump({
-    "source": f"profiles/pmc_{tag}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, {n} launches each, nuscenes_gs25600_solid)",
+    "source": f"profiles/pmc_{tag}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, {n} launches each, {config})",
+    "config": config,
     "kernel": name[:60],
     "FETCH_SIZE_KiB_raw": fetch,
     "WRITE_SIZE_KiB_raw": write,
