@@ -306,6 +306,7 @@ struct RenderArgs {
     long long *out_labels;  // null = off
     int label_mode, empty_label;
     float threshold;
+    int raw_numerator;  // prob variant: logits = sum sem * prob, not divided by prob_sum (GF_PROB_NUMERATOR)
 };
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
@@ -531,7 +532,7 @@ __device__ __forceinline__ void general_body(const RenderArgs &a)
             }
         }
         if (VARIANT == GF_SPLAT_PROB) {
-            prob_normalise(A);
+            if (!a.raw_numerator) prob_normalise(A);
             if (!LABELS || a.out_bin) {
                 a.out_bin[n] = 1 - A.bin;
                 a.out_density[n] = A.dens;
@@ -775,8 +776,8 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
 #endif
 
         if (VARIANT == GF_SPLAT_PROB) {
-            prob_normalise(A);
-            prob_normalise(B);
+            if (!a.raw_numerator) prob_normalise(A);
+            if (!a.raw_numerator) prob_normalise(B);
             if (okA && (!LABELS || a.out_bin)) {
                 a.out_bin[vA] = 1 - A.bin;  // localagg_prob/src/forward.cu:99-101
                 a.out_density[vA] = A.dens;
@@ -942,6 +943,8 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
                      "unknown label mode");
         GF_CHECK_ARG(lab.mode == GF_LABELS_ARGMAX || variant == GF_SPLAT_PROB, "the prob label modes need the prob variant");
     }
+    GF_CHECK_ARG(!(flags & GF_PROB_NUMERATOR) || (variant == GF_SPLAT_PROB && !lab.labels),
+                 "GF_PROB_NUMERATOR is a prob-variant flag and excludes the label epilogue");
     GF_CHECK_ARG(workspace != nullptr, "null workspace");
     SplatWorkspace ws = carve_workspace(workspace, P, N, H, W, D);
     if (workspace_bytes < ws.total_bytes) {
@@ -977,6 +980,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.verify_dense = verify ? 1 : 0;
     ra.timeline = g_timeline;
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
+    ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
     if (variant == GF_SPLAT_BASE)
         launch_render_exp<GF_SPLAT_BASE>(flags, dense_candidate, ra, stream);
     else

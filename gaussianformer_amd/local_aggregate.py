@@ -403,6 +403,24 @@ class LocalAggregatorProb(_AggregatorBase):
             pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D, self.H, self.W, self.D)
         return logits, bin_logits, density  # n, c; n; n
 
+    @torch.no_grad()
+    def forward_pieces(self, pts, means3D, opas, semantics, scales, cov3D):
+        """Inference-only: ``(numerator [n,18], bin_logits [n], density [n], probability [n])`` with the
+        un-normalised numerator (``GF_PROB_NUMERATOR``) -- what the shards of
+        ``sharded.sharded_splat_forward_prob`` exchange before normalising."""
+        pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D = self._prepare(
+            pts, means3D, opas, semantics, scales, cov3D)
+        if self.per_axis_radii:
+            radii = torch.ceil(scales * self.scale_multiplier / self.grid_size).to(torch.int)
+        else:
+            radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
+        radii = radii.clamp(min=self.radii_min)
+        cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
+        numerator, bin_logits, density, probability, _ = splat_forward(
+            _lib.GF_SPLAT_PROB, pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D,
+            self.H, self.W, self.D, flags=_lib.GF_PTS_AUTO | _lib.GF_PROB_NUMERATOR)
+        return numerator, bin_logits, density, probability
+
 
 class LocalAggregatorProbFast(LocalAggregatorProb):
     """Drop-in for ``local_aggregate_prob_fast.LocalAggregator``."""

@@ -47,6 +47,10 @@ extern "C" {
 #define GF_FAST_EXP 4          /* (default behaviour; kept for ABI compatibility) */
 #define GF_LIBM_EXP 8          /* natural-log form + ocml expf (13 VALU per exp) */
 #define GF_COMP_EXP 16         /* natural-log form + v_exp_f32 with a compensated argument (<= 3 ulp) */
+/* prob variant, forward only: `logits` receives the un-normalised numerator sum_g semantics_g * prob_g instead of
+ * numerator / probability (localagg_prob/src/forward.cu:92-98 is left to the caller).  For Gaussian-sharded inference:
+ * numerators, probability and density add up over shards, 1 - bin_logits multiplies. */
+#define GF_PROB_NUMERATOR 32
 
 int gf_abi_version(void);
 const char *gf_last_error(void);
