@@ -1,5 +1,5 @@
-"""Submanifold sparse convolution against its definition: a dense K^3
-convolution of the scattered-and-summed features, read back at the points (fp64 torch, autograd
+"""Submanifold sparse convolution against its definition (oracle/subm_ref.py): a dense
+K^3 convolution of the scattered-and-summed features, read back at the points (fp64 torch, autograd
 for the gradients).  spconv itself is not available (no ROCm build, not in the reference tree)."""
 import numpy as np
 import pytest
@@ -8,21 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _dense_reference(feat, idx, weight, batch, shape, K):
-    """feat [N,Cin] f64, idx [N,4] (b,x,y,z), weight [K^3,Cin,Cout] f64 -> out [N,Cout] (differentiable)."""
-    X, Y, Z = shape
-    N, cin = feat.shape
-    cout = weight.shape[2]
-    inside = (idx[:, 0] >= 0) & (idx[:, 0] < batch) & (idx[:, 1] >= 0) & (idx[:, 1] < X) & (idx[:, 2] >= 0) & \
-        (idx[:, 2] < Y) & (idx[:, 3] >= 0) & (idx[:, 3] < Z)
-    lin = ((idx[:, 0] * X + idx[:, 1]) * Y + idx[:, 2]) * Z + idx[:, 3]
-    lin = torch.where(inside, lin, torch.zeros_like(lin)).long()
-    dense = torch.zeros(batch * X * Y * Z, cin, dtype=feat.dtype).index_add(0, lin, feat * inside[:, None].to(feat.dtype))
-    dense = dense.view(batch, X, Y, Z, cin).permute(0, 4, 1, 2, 3)
-    w = weight.view(K, K, K, cin, cout).permute(4, 3, 0, 1, 2)
-    y = torch.nn.functional.conv3d(dense, w, padding=K // 2)            # cross-correlation: out[x] = sum_d in[x+d] w[d]
-    y = y.permute(0, 2, 3, 4, 1).reshape(batch * X * Y * Z, cout)
-    return y[lin] * inside[:, None].to(feat.dtype)
+from oracle.subm_ref import subm_conv3d_dense as _dense_reference  # noqa: E402  (the checker)
 
 
 def _points(rng, N, batch, shape, dup=0.1, outside=2):
