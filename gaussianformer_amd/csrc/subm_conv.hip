@@ -32,13 +32,13 @@ struct SubmTables {
     int *head;              // [cells]  first point of the cell's list, -1 = empty
     int *next;              // [N]
     int *slot_first;        // [N][K3]  first pair slot of (out point, offset), -1 = none
-    unsigned char *cnt;     // [N][K3]  pairs of (out point, offset)
-    unsigned int *kcount;   // [K3]
+    unsigned short *cnt;    // [N][K3]  pairs of (out point, offset); a cell with more than 65535 points raises total[1]
+    unsigned long long *kcount;  // [K3] pairs per offset (64-bit: crowded cells square their population)
     unsigned int *kstart;   // [K3+1]
     unsigned int *tile_start;  // [K3+1]
     unsigned int *kcursor;  // [K3]
     unsigned int *chunk_start;  // [K3+1] weight-gradient chunks before segment k
-    unsigned long long *total;  // [1] total pairs
+    unsigned long long *total;  // [0] total pairs, [1] non-zero if a cell is too crowded for the 16-bit counts
 };
 
 struct SubmArgs {
@@ -66,8 +66,8 @@ static SubmTables subm_carve(void *base, int N, long long cells, int K3, size_t 
     t.head = (int *)(p + off); off += subm_align((size_t)cells * 4);
     t.next = (int *)(p + off); off += subm_align((size_t)N * 4);
     t.slot_first = (int *)(p + off); off += subm_align((size_t)N * K3 * 4);
-    t.cnt = (unsigned char *)(p + off); off += subm_align((size_t)N * K3);
-    t.kcount = (unsigned int *)(p + off); off += subm_align((size_t)K3 * 4);
+    t.cnt = (unsigned short *)(p + off); off += subm_align((size_t)N * K3 * 2);
+    t.kcount = (unsigned long long *)(p + off); off += subm_align((size_t)K3 * 8);
     t.kstart = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
     t.tile_start = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
     t.kcursor = (unsigned int *)(p + off); off += subm_align((size_t)K3 * 4);
@@ -137,8 +137,9 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
         }
         if (total == 0) continue;  // block-uniform
         if (!FILL) {
-            if (threadIdx.x == 0) atomicAdd(a.t.kcount + k, total);
-            if (c) a.t.cnt[(size_t)i * a.K3 + k] = (unsigned char)min(c, 255u);
+            if (threadIdx.x == 0) atomicAdd(a.t.kcount + k, (unsigned long long)total);
+            if (c) a.t.cnt[(size_t)i * a.K3 + k] = (unsigned short)min(c, 65535u);
+            if (c > 65535u) atomicOr(a.t.total + 1, 1ull);  // reported next to the pair count; the caller must refuse
             continue;
         }
         if (threadIdx.x == 0) s_base = a.t.kstart[k] + atomicAdd(a.t.kcursor + k, total);
@@ -160,9 +161,12 @@ __global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
     // K3 <= 343 entries: one wave, 64 per step, running totals carried in registers
     const int lane = threadIdx.x;
     unsigned int run = 0, tiles = 0, chunks = 0;
+    unsigned long long total64 = 0;
     for (int k0 = 0; k0 < a.K3; k0 += 64) {
         const int k = k0 + lane;
-        const unsigned int c = k < a.K3 ? a.t.kcount[k] : 0u;
+        const unsigned long long c64 = k < a.K3 ? a.t.kcount[k] : 0ull;
+        total64 += c64;  // per lane; summed over the wave at the end
+        const unsigned int c = (unsigned int)c64;
         const unsigned int tl = (c + kPairTile - 1) / kPairTile, ch = (c + kWgradChunk - 1) / kWgradChunk;
         unsigned int ic = c, it = tl, ih = ch;
 #pragma unroll
@@ -180,11 +184,14 @@ __global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
         tiles += __shfl(it, 63, 64);
         chunks += __shfl(ih, 63, 64);
     }
+    // pair slots are 32-bit ints: more than 2^31 - 1 pairs is reported like a crowded cell (the prefixes above wrapped)
+    for (int d = 32; d >= 1; d >>= 1) total64 += __shfl_xor(total64, d, 64);
+    if (lane == 0 && total64 >= (1ull << 31)) atomicOr(a.t.total + 1, 2ull);
     if (lane == 0) {
         a.t.kstart[a.K3] = run;
         a.t.tile_start[a.K3] = tiles;
         a.t.chunk_start[a.K3] = chunks;
-        a.t.total[0] = run;
+        a.t.total[0] = total64;
     }
 }
 
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
     const bool live = i < a.N;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int *sf = a.t.slot_first + (size_t)(live ? i : 0) * a.K3;
-    const unsigned char *cn = a.t.cnt + (size_t)(live ? i : 0) * a.K3;
+    const unsigned short *cn = a.t.cnt + (size_t)(live ? i : 0) * a.K3;
     // the CG lanes of a point scan its K^3 counts together (most are zero), then walk the hits in
     // ascending k -- the summation order is fixed by k, not by where the pairs were stored.  The first
     // rows of up to UNR hits are requested together: one at a time the walk is a chain of ~1 us loads.
@@ -480,8 +487,9 @@ extern "C" int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int
     SubmArgs a = subm_args(N, batch, X, Y, Z, K, indices, tables);
     if (hipMemsetAsync(a.t.head, 0xFF, (size_t)a.cells * 4, stream) != hipSuccess ||
         hipMemsetAsync(a.t.slot_first, 0xFF, (size_t)N * a.K3 * 4, stream) != hipSuccess ||
-        hipMemsetAsync(a.t.cnt, 0, (size_t)N * a.K3, stream) != hipSuccess ||
-        hipMemsetAsync(a.t.kcount, 0, (size_t)a.K3 * 4, stream) != hipSuccess) {
+        hipMemsetAsync(a.t.cnt, 0, (size_t)N * a.K3 * 2, stream) != hipSuccess ||
+        hipMemsetAsync(a.t.total, 0, 16, stream) != hipSuccess ||
+        hipMemsetAsync(a.t.kcount, 0, (size_t)a.K3 * 8, stream) != hipSuccess) {
         set_error("%s: hipMemsetAsync failed", __func__);
         return GF_ELAUNCH;
     }

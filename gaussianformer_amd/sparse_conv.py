@@ -35,7 +35,11 @@ class Rulebook:
                                             _lib.current_stream(dev))
             _lib.check(rc, "gf_subm_rulebook_count")
             # the one host read (spconv reads its pair counts the same way)
-            self.total = int(self.tables[nbytes - 256:nbytes - 248].view(torch.int64).item())
+            total, refused = self.tables[nbytes - 256:nbytes - 240].view(torch.int64).tolist()
+            if refused:
+                raise RuntimeError("sparse-conv rulebook refused: " +
+                                   ("a cell holds more than 65535 points" if refused & 1 else "more than 2^31 - 1 neighbour pairs"))
+            self.total = int(total)
             self.pair_in = torch.empty(max(self.total, 1), dtype=i32, device=dev)
             self.pair_out = torch.empty(max(self.total, 1), dtype=i32, device=dev)
             rc = lib.gf_subm_rulebook_fill(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables),

@@ -229,7 +229,8 @@ int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const
  * read back at the points).  indices i32 [N,4] = (batch, x, y, z); points outside the grid are inactive (output 0).
  *
  * Call order: gf_subm_rulebook_count (device tables; the total pair count is the i64 at byte
- * gf_subm_tables_bytes(..) - 256 of `tables`) -> allocate pair_in / pair_out (i32 [total]) and partial
+ * gf_subm_tables_bytes(..) - 256 of `tables`, and the i64 after it is non-zero when the point set is refused:
+ * bit 0 a cell with more than 65535 points, bit 1 more than 2^31 - 1 pairs -- the caller must not go on) -> allocate pair_in / pair_out (i32 [total]) and partial
  * (f32 [total, Cout]) -> gf_subm_rulebook_fill -> gf_subm_conv_apply (any number of times; the gradient w.r.t.
  * the features is the same call with weight'[k] = weight[K^3-1-k]^T) / gf_subm_conv_weight_grad.
  * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  Both products run on the f32 matrix

@@ -161,3 +161,56 @@ def test_subm_conv_degenerate_inputs():
     f = torch.randn(1, 32, device=dev)
     out = subm_conv3d(f, idx, w, 1, (5, 5, 5), 3)
     assert torch.allclose(out, f @ w[13], rtol=1e-5, atol=1e-5)
+
+
+def test_subm_conv_random_sweep():
+    """Random point counts, grids, kernel sizes and channel pairs (GF_SWEEP_SEED / GF_SWEEP_TRIALS select others),
+    forward and both gradients against the dense definition."""
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gaussianformer_amd.sparse_conv import subm_conv3d
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(int(os.environ.get("GF_SWEEP_SEED", "11")))
+    for trial in range(int(os.environ.get("GF_SWEEP_TRIALS", "10"))):
+        K = int(rng.choice([1, 3, 5, 7]))
+        batch = int(rng.integers(1, 4))
+        shape = tuple(int(v) for v in rng.integers(1, 12, 3))
+        N = int(rng.integers(1, 1500))
+        cin, cout = (int(v) for v in rng.choice([32, 64, 128], 2))
+        idx = _points(rng, N, batch, shape, dup=float(rng.random()) * 0.5, outside=int(rng.integers(0, 4)))
+        g = torch.Generator().manual_seed(1000 + trial)
+        feat = torch.randn(N, cin, generator=g)
+        weight = torch.randn(K ** 3, cin, cout, generator=g) * 0.1
+        gout = torch.randn(N, cout, generator=g)
+        f64, w64 = feat.double().requires_grad_(True), weight.double().requires_grad_(True)
+        ref = _dense_reference(f64, idx.long(), w64, batch, shape, K)
+        (ref * gout.double()).sum().backward()
+        fd, wd = feat.to(dev).requires_grad_(True), weight.to(dev).requires_grad_(True)
+        out = subm_conv3d(fd, idx.to(dev), wd, batch, shape, K)
+        out.backward(gout.to(dev))
+        what = f"trial {trial}: N={N} batch={batch} shape={shape} K={K} {cin}->{cout}"
+        scale = float(ref.detach().abs().max()) + 1e-6
+        assert (out.detach().cpu().double() - ref.detach()).abs().max() <= 3e-5 * scale, what
+        assert (fd.grad.cpu().double() - f64.grad).abs().max() <= 3e-5 * (float(f64.grad.abs().max()) + 1e-6), what
+        assert (wd.grad.cpu().double() - w64.grad).abs().max() <= 1e-4 * (float(w64.grad.abs().max()) + 1e-6), what
+
+
+def test_subm_conv_crowded_cells():
+    """Hundreds of points per cell (a sweep once caught 8-bit per-offset counts saturating at 255), and the loud
+    refusal of a cell beyond the 16-bit limit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gaussianformer_amd.sparse_conv import Rulebook, subm_conv3d
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    N, batch, shape, K = 1400, 1, (1, 2, 2), 1
+    idx = _points(rng, N, batch, shape, dup=0.0, outside=0)
+    g = torch.Generator().manual_seed(9)
+    feat, weight = torch.randn(N, 64, generator=g), torch.randn(1, 64, 128, generator=g) * 0.1
+    ref = _dense_reference(feat.double(), idx.long(), weight.double(), batch, shape, K)
+    out = subm_conv3d(feat.to(dev), idx.to(dev), weight.to(dev), batch, shape, K)
+    assert (out.cpu().double() - ref).abs().max() <= 3e-5 * float(ref.abs().max())
+    crowd = torch.zeros(66000, 4, dtype=torch.int32, device=dev)          # 66 000 points in one cell
+    with pytest.raises(RuntimeError, match="65535"):
+        Rulebook(crowd, 1, (2, 2, 2), 1)
