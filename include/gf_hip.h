@@ -228,11 +228,14 @@ int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const
  * contribute and all receive that cell's output (= a dense convolution of the scattered-and-summed features,
  * read back at the points).  indices i32 [N,4] = (batch, x, y, z); points outside the grid are inactive (output 0).
  *
- * Call order: gf_subm_rulebook_count (device tables; the total pair count is the i64 at byte
- * gf_subm_tables_bytes(..) - 256 of `tables`, and the i64 after it is non-zero when the point set is refused:
- * bit 0 a cell with more than 65535 points, bit 1 more than 2^31 - 1 pairs -- the caller must not go on) -> allocate pair_in / pair_out (i32 [total]) and partial
- * (f32 [total, Cout]) -> gf_subm_rulebook_fill -> gf_subm_conv_apply (any number of times; the gradient w.r.t.
- * the features is the same call with weight'[k] = weight[K^3-1-k]^T) / gf_subm_conv_weight_grad.
+ * Call order:
+ *   1. gf_subm_rulebook_count builds the device tables.  The total pair count is the i64 at byte
+ *      gf_subm_tables_bytes(..) - 256 of `tables`; the i64 after it is non-zero when the point set is refused
+ *      (bit 0: a cell with more than 65535 points, bit 1: more than 2^31 - 1 pairs) -- the caller must stop there.
+ *   2. the caller allocates pair_in / pair_out (i32 [total]) and partial (f32 [total, Cout]);
+ *   3. gf_subm_rulebook_fill;
+ *   4. gf_subm_conv_apply, any number of times (the gradient w.r.t. the features is the same call with
+ *      weight'[k] = weight[K^3-1-k]^T), and gf_subm_conv_weight_grad.
  * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  Both products run on the f32 matrix
  * cores (v_mfma_f32_32x32x2_f32: exact f32, an fmaf chain); results are deterministic except the weight gradient of
  * segments longer than 512 pairs (float atomics between their chunks).
