@@ -301,6 +301,7 @@ struct RenderArgs {
     const uint32_t *verify_flags;
     uint32_t *state;
     unsigned long long *timeline;  // debug: 4 timestamps per workgroup (null = off)
+    const int *tile_perm;          // debug (GF_TIMELINE builds): workgroup -> logical tile, for scheduling experiments
     int P, N, nwords, H, W, D, nsx, nsy, ntiles_total, verify_dense;
     // optional head epilogue (gf_splat_forward_labels): labels straight from the accumulators
     long long *out_labels;  // null = off
@@ -585,7 +586,10 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
     // tile of this workgroup.  XCD-aware order: consecutive logical tiles (supertile-major)
     // stay on one XCD so its L2 keeps that supertile's bitmask, boxes and records.
     const int per_xcd = (int)(gridDim.x >> 3);
-    const int logical = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    int logical = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+#if GF_TIMELINE
+    if (a.tile_perm) logical = a.tile_perm[blockIdx.x];
+#endif
     const int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
     const int X0 = (s / a.nsy) * kSuper;
     const int Y0 = (s % a.nsy) * kSuper + t * kTileY;
@@ -897,9 +901,10 @@ static void launch_render_exp(int flags, bool dense_candidate, const RenderArgs 
 
 }  // namespace gf
 
-namespace gf { static unsigned long long *g_timeline = nullptr; }
+namespace gf { static unsigned long long *g_timeline = nullptr; static const int *g_tile_perm = nullptr; }
 // debug hook (not in the public header): per-workgroup timestamps of the render kernel
 extern "C" void gf_debug_set_timeline(void *dev_ptr) { gf::g_timeline = (unsigned long long *)dev_ptr; }
+extern "C" void gf_debug_set_tile_perm(const void *dev_ptr) { gf::g_tile_perm = (const int *)dev_ptr; }
 
 extern "C" size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D)
 {
@@ -979,6 +984,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.H = H; ra.W = W; ra.D = D; ra.nsx = ws.nsx; ra.nsy = ws.nsy; ra.ntiles_total = ws.nsuper * kTilesPerSuper;
     ra.verify_dense = verify ? 1 : 0;
     ra.timeline = g_timeline;
+    ra.tile_perm = g_tile_perm;
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
     if (variant == GF_SPLAT_BASE)
