@@ -132,6 +132,27 @@ __device__ __forceinline__ float group_sum(float v, int width)
     return v;
 }
 
+// DPP forms for the nuScenes layout (C = 128, 4 channels per lane, 4 groups: 8 lanes per group, 32 per point):
+// running sums inside a row of 16 lanes, the total lands in the LAST lane of every 8 / 32.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+
+__device__ __forceinline__ float sum8_last(float v)  // valid in lanes with (lane & 7) == 7
+{
+    v = dpp_add<0x111>(v);  // row_shr:1
+    v = dpp_add<0x112>(v);  // row_shr:2
+    return dpp_add<0x114>(v);  // row_shr:4
+}
+
+__device__ __forceinline__ float sum32_last(float v)  // valid in lanes 31 and 63
+{
+    v = dpp_add<0x118>(sum8_last(v));  // row_shr:8 -> lane 15 of each row holds the row
+    return dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+}
+
 // LPG = lanes per channel group, LPP = lanes per point (both powers of two <= 64 on the
 // fast path).  REDUCE = false falls back to the reference's per-lane atomics.
 // FEAT = false leaves grad_mc_ms_feat to the pixel-major kernels below (gf_daf_backward_sorted).
@@ -158,6 +179,7 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
         for (int j = 0; j < VEC; ++j) go[j] = 0.f;
     }
     const int lane = lane_id();
+    const bool dpp = REDUCE && lpg == 8 && lpp == 32;  // kernel-uniform
     // the three streams never alias; say so, or every gradient store fences the feature gathers
     const float *__restrict__ feat = a.feat;
     float *__restrict__ grad_weights = a.grad_weights;
@@ -219,15 +241,17 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
 #pragma unroll
             for (int q = 0; q < kDeferLevels; ++q) {
                 if (q >= a.L) break;
-                const float gw = group_sum(gw_level[q], lpg);
-                if ((lane & (lpg - 1)) == 0 && active) grad_weights[wbase + (long long)(cam * a.L + q) * a.G] += gw;
+                const float gw = dpp ? sum8_last(gw_level[q]) : group_sum(gw_level[q], lpg);
+                const bool writer = dpp ? (lane & 7) == 7 : (lane & (lpg - 1)) == 0;
+                if (writer && active) grad_weights[wbase + (long long)(cam * a.L + q) * a.G] = gw;
             }
         }
         float *gl = grad_loc + (bp * a.cams + cam) * 2;
         if (REDUCE) {
-            gl_w = group_sum(gl_w, lpp);
-            gl_h = group_sum(gl_h, lpp);
-            if ((lane & (lpp - 1)) == 0 && active) { gl[0] += gl_w; gl[1] += gl_h; }
+            gl_w = dpp ? sum32_last(gl_w) : group_sum(gl_w, lpp);
+            gl_h = dpp ? sum32_last(gl_h) : group_sum(gl_h, lpp);
+            const bool writer = dpp ? (lane & 31) == 31 : (lane & (lpp - 1)) == 0;
+            if (writer && active) { gl[0] = gl_w; gl[1] = gl_h; }
         } else {
             unsafeAtomicAdd(gl, gl_w);
             unsafeAtomicAdd(gl + 1, gl_h);

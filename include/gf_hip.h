@@ -171,8 +171,10 @@ int gf_daf_forward(int B, int num_cams, int num_feat, int C, int L, int num_pts,
                    const float *weights, float *output, void *stream);
 
 /*
- * Deformable aggregation, backward.  Accumulates into the three caller-zeroed gradient
- * buffers exactly like the reference (ops/deformable_aggregation.py:55-67).
+ * Deformable aggregation, backward.  The three gradient buffers must be zero on entry, as the reference's
+ * Python side makes them (ops/deformable_aggregation.py:55-67): grad_mc_ms_feat is accumulated; an entry of
+ * grad_weights / grad_sampling_location has exactly one producer and is stored, not added (entries of cameras
+ * that do not see the point keep their zero).
  * Replaces  deformable_aggregation_backward  .../ops/src/deformable_aggregation.cpp:73-110
  *           deformable_aggregation_grad_kernel .../ops/src/deformable_aggregation_cuda.cu:190-259
  */
@@ -184,7 +186,7 @@ int gf_daf_backward(int B, int num_cams, int num_feat, int C, int L, int num_pts
 
 /*
  * Deformable aggregation backward, pixel-major gradient of the feature maps.  Same arguments,
- * results and accumulate-into-zeroed-buffers contract as gf_daf_backward, plus a device
+ * results and zero-on-entry contract as gf_daf_backward, plus a device
  * workspace.  grad_weights / grad_sampling_location come from the same point-major kernel;
  * grad_mc_ms_feat is produced without the reference's per-channel atomic scatter
  * (deformable_aggregation_cuda.cu:92-110): taps are bucketed by destination pixel row with a
