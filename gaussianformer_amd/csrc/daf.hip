@@ -75,6 +75,18 @@ __device__ __forceinline__ Taps make_taps(float h_im, float w_im, int height, in
     return t;
 }
 
+// pixel rows (h * width + w) of the four taps with out-of-image coordinates clamped to the nearest
+// valid pixel; such taps carry a zero coefficient (ok1..ok4 false), their value is never used
+struct Corners {
+    int r1, r2, r3, r4;
+};
+__device__ __forceinline__ Corners clamp_corners(const Taps &t, int height, int width)
+{
+    const int h0 = max(t.h_low, 0), h1 = min(t.h_low + 1, height - 1);
+    const int w0 = max(t.w_low, 0), w1 = min(t.w_low + 1, width - 1);
+    return {h0 * width + w0, h0 * width + w1, h1 * width + w0, h1 * width + w1};
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void gf_daf_fwd_kernel(DafArgs a)
 {
@@ -95,24 +107,27 @@ __global__ __launch_bounds__(256) void gf_daf_fwd_kernel(DafArgs a)
         const float loc_w = loc[2 * cam], loc_h = loc[2 * cam + 1];
         if (!(loc_w > 0 && loc_w < 1 && loc_h > 0 && loc_h < 1)) continue;  // :166
         const float *fcam = a.feat + ((size_t)b * a.cams + cam) * a.num_feat * a.C + c0;
+#pragma unroll 2
         for (int s = 0; s < a.L; ++s) {
             const int h = a.spatial_shape[2 * s], w = a.spatial_shape[2 * s + 1];
             const float h_im = loc_h * h - 0.5f, w_im = loc_w * w - 0.5f;  // :174-175
             const Taps t = make_taps(h_im, w_im, h, w);
             const float *base = fcam + (size_t)a.scale_start[s] * a.C;
-            const float *p1 = base + ((long long)t.h_low * w + t.w_low) * a.C;
+            // All four taps are loaded unconditionally from clamped (always valid) pixels and the
+            // out-of-image ones get a zero coefficient: a load under `if (ok)` is followed by its own
+            // s_waitcnt inside the branch, which made the sixteen taps of a camera a serial chain.
+            const Corners c = clamp_corners(t, h, w);
             float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) v1[j] = v2[j] = v3[j] = v4[j] = 0.f;
-            if (t.ok1) vload<VEC>(p1, v1);
-            if (t.ok2) vload<VEC>(p1 + a.C, v2);
-            if (t.ok3) vload<VEC>(p1 + (size_t)w * a.C, v3);
-            if (t.ok4) vload<VEC>(p1 + (size_t)w * a.C + a.C, v4);
+            vload<VEC>(base + (size_t)c.r1 * a.C, v1);
+            vload<VEC>(base + (size_t)c.r2 * a.C, v2);
+            vload<VEC>(base + (size_t)c.r3 * a.C, v3);
+            vload<VEC>(base + (size_t)c.r4 * a.C, v4);
             const float wt = wts[(cam * a.L + s) * a.G];
+            const float w1 = t.ok1 ? t.w1 : 0.f, w2 = t.ok2 ? t.w2 : 0.f, w3 = t.ok3 ? t.w3 : 0.f, w4 = t.ok4 ? t.w4 : 0.f;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float val = (t.w1 * v1[j] + t.w2 * v2[j] + t.w3 * v3[j] + t.w4 * v4[j]);  // :51-53
-                acc[j] += val * wt;                                                                // :182
+                const float val = (w1 * v1[j] + w2 * v2[j] + w3 * v3[j] + w4 * v4[j]);  // :51-53
+                acc[j] += val * wt;                                                        // :182
             }
         }
     }
@@ -200,13 +215,20 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
             const Taps t = make_taps(h_im, w_im, h, w);
             const size_t o1 = cam_off + (size_t)a.scale_start[s] * a.C + ((long long)t.h_low * w + t.w_low) * a.C;
             const size_t o2 = o1 + a.C, o3 = o1 + (size_t)w * a.C, o4 = o3 + a.C;
+            // unconditional loads from clamped pixels, then zeroed where the tap is outside the image
+            // (see gf_daf_fwd_kernel: a load under `if (ok)` waits for itself inside the branch)
+            const Corners cc = clamp_corners(t, h, w);
+            const size_t lvl_off = cam_off + (size_t)a.scale_start[s] * a.C;
             float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+            vload<VEC>(feat + lvl_off + (size_t)cc.r1 * a.C, v1);
+            vload<VEC>(feat + lvl_off + (size_t)cc.r2 * a.C, v2);
+            vload<VEC>(feat + lvl_off + (size_t)cc.r3 * a.C, v3);
+            vload<VEC>(feat + lvl_off + (size_t)cc.r4 * a.C, v4);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) v1[j] = v2[j] = v3[j] = v4[j] = 0.f;
-            if (t.ok1) vload<VEC>(feat + o1, v1);
-            if (t.ok2) vload<VEC>(feat + o2, v2);
-            if (t.ok3) vload<VEC>(feat + o3, v3);
-            if (t.ok4) vload<VEC>(feat + o4, v4);
+            for (int j = 0; j < VEC; ++j) {
+                v1[j] = t.ok1 ? v1[j] : 0.f; v2[j] = t.ok2 ? v2[j] : 0.f;
+                v3[j] = t.ok3 ? v3[j] : 0.f; v4[j] = t.ok4 ? v4[j] : 0.f;
+            }
             const long long wi = wbase + (long long)(cam * a.L + s) * a.G;
             const float wt = a.weights[wi];
             float gw = 0.f, gh_part = 0.f, gw_part = 0.f;
@@ -410,7 +432,7 @@ __global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
 {
     constexpr int NG = 256 / LPT;            // lane groups per workgroup
     constexpr int PER = kDafChunk / 256;     // taps per thread in phase 1
-    constexpr int UNR = 4;
+    constexpr int UNR = 8;
     __shared__ uint32_t s_id[kDafChunk];
     __shared__ float s_cw[kDafChunk];
     __shared__ uint32_t s_cnt[kDafMaxTileRows + 1];
@@ -432,23 +454,27 @@ __global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
         uint32_t id[PER], rank[PER];
         int lrow[PER];
         float cw[PER];
+        float2 lc[PER];
+        // ids, then sampling locations, then the arithmetic: every load is unconditional (threads past the
+        // end of the item re-read its last tap and drop it afterwards) and issued before the first use --
+        // under `if (ti < t1)` each load waited for itself inside the branch, eight round trips in a row
+#pragma unroll
+        for (int j = 0; j < PER; ++j) id[j] = a.taps[min(t0 + tid + 256 * j, t1 - 1)];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const uint32_t ti = t0 + tid + 256 * j;
-            lrow[j] = -1;
-            if (ti < t1) id[j] = a.taps[ti];
+            const uint32_t pc = (id[j] >> 2) >> a.lvl_bits;  // (point, cam)
+            const size_t sample = (size_t)(pc >> a.cam_bits) * a.cams + (pc & cam_mask);
+            lc[j] = *reinterpret_cast<const float2 *>(a.loc + 2 * sample);
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const uint32_t ti = t0 + tid + 256 * j;
-            if (ti >= t1) continue;
+            lrow[j] = -1;
             const int k = id[j] & 3u;
             const uint32_t q = id[j] >> 2;                  // (point, cam, level)
             const int s = (int)(q & lvl_mask);
-            const uint32_t pc = q >> a.lvl_bits;            // (point, cam)
-            const uint32_t cam = pc & cam_mask, pt = pc >> a.cam_bits;
-            const size_t sample = (size_t)pt * a.cams + cam;
-            const float loc_w = a.loc[2 * sample], loc_h = a.loc[2 * sample + 1];
+            const uint32_t cam = (q >> a.lvl_bits) & cam_mask;
+            const float loc_w = lc[j].x, loc_h = lc[j].y;
             const int h = a.spatial_shape[2 * s], w = a.spatial_shape[2 * s + 1];
             const float h_im = loc_h * h - 0.5f, w_im = loc_w * w - 0.5f;
             const float fh = floorf(h_im), fw = floorf(w_im);
@@ -456,8 +482,10 @@ __global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
             cw[j] = k == 0 ? hh * hw : k == 1 ? hh * lw : k == 2 ? lh * hw : lh * lw;
             const uint32_t row = cam * (uint32_t)a.num_feat + (uint32_t)a.scale_start[s] +
                                  (uint32_t)(((int)fh + (k >> 1)) * w + (int)fw + (k & 1));
-            lrow[j] = (int)(row - row_base);
-            rank[j] = atomicAdd(&s_cnt[lrow[j]], 1u);
+            if (ti < t1) {
+                lrow[j] = (int)(row - row_base);
+                rank[j] = atomicAdd(&s_cnt[lrow[j]], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {  // exclusive scan of the <= 128 row counts: two per lane
