@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void gf_splat_render_general_kernel(RenderA
     general_body<VARIANT, EXP, LABELS>(a);
 }
 
-constexpr int kRenderWavesPerSimd = 6;  // two voxels per lane: 80 VGPRs
+constexpr int kRenderWavesPerSimd = 5;  // five workgroups per CU cover the 1250 tiles of the 200x200 grid in one round; 6 (80 VGPRs) spilled the six deferred position registers
 
 __device__ __forceinline__ void store_row4(float *dst, float4 v) { *reinterpret_cast<float4 *>(dst) = v; }
 
@@ -636,15 +636,16 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
         const bool okB = X < a.H && Y < a.W && ZB < a.D;
         const size_t vA = ((size_t)X * a.W + Y) * a.D + ZA;
         const size_t vB = vA + 4;
-        float pAx = 0.f, pAy = 0.f, pAz = 0.f, pBx = 0.f, pBy = 0.f, pBz = 0.f;
-        if (okA) { pAx = a.pts[3 * vA]; pAy = a.pts[3 * vA + 1]; pAz = a.pts[3 * vA + 2]; }
-        if (okB) { pBx = a.pts[3 * vB]; pBy = a.pts[3 * vB + 1]; pBz = a.pts[3 * vB + 2]; }
+        // unconditional loads (lanes outside the grid read voxel 0 and never store): under `if (ok)` each
+        // load is followed by its own s_waitcnt inside the branch, two cold round trips before the producer
+        const size_t lA = okA ? vA : 0, lB = okB ? vB : 0;
+        const float qAx = a.pts[3 * lA], qAy = a.pts[3 * lA + 1], qAz = a.pts[3 * lA + 2];
+        const float qBx = a.pts[3 * lB], qBy = a.pts[3 * lB + 1], qBz = a.pts[3 * lB + 2];
         Acc A, B;
 #pragma unroll
         for (int ch = 0; ch < kC; ++ch) { A.c[ch] = 0.f; B.c[ch] = 0.f; }
         A.bin = 1.f; A.dens = 0.f; A.psum = 0.f;
         B.bin = 1.f; B.dens = 0.f; B.psum = 0.f;
-        if (zg > 0) word_next = tid < a.nwords ? bm[tid] : 0ull;
 
         // ---- produce / consume.  Producer: one bitmask word of the supertile per thread and
         // kBlock words per chunk; the set bits of a chunk (every Gaussian whose box touches the
@@ -718,20 +719,28 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
 #if GF_TIMELINE
             if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)blockIdx.x + 1] = wall_clock64();
 #endif
+            // The positions are first touched here, after the list has been built: the (A, B) register pairs
+            // the packed evaluation wants are assembled inside the loop (the empty asm keeps the copies from
+            // being hoisted), so the cold point loads overlap the producer instead of being waited for
+            // in front of it.
+            float ax = qAx, ay = qAy, az = qAz, bx = qBx, by = qBy, bz = qBz;
+            asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(bx), "+v"(by), "+v"(bz));
+            const f32x2 px = {ax, bx}, py = {ay, by}, pz = {az, bz};
+            // entry and box of lane's slot in the first batch; lanes past the end re-read the last entry
+            // (masked out below) so that the loads need no branch -- a load under `if` is waited for inside it
             uint32_t eg_n = 0;
             uint2 box_n = make_uint2(0, 0);
-            if (lane < list_len) {
-                eg_n = s_lg[lane];
+            if (list_len > 0) {  // workgroup-uniform
+                eg_n = s_lg[min(lane, list_len - 1)];
                 box_n = a.boxes[eg_n];
             }
             for (int base = 0; base < list_len; base += 64) {
                 const int i = base + lane;
                 const uint32_t eg = eg_n;
                 const uint2 box = box_n;
-                if (i + 64 < list_len) {  // next 64 entries' boxes: in flight during this batch
-                    eg_n = s_lg[i + 64];
-                    box_n = a.boxes[eg_n];
-                }
+                // next 64 entries' boxes: in flight during this batch
+                eg_n = s_lg[min(i + 64, list_len - 1)];
+                box_n = a.boxes[eg_n];
                 uint32_t mAlo = 0, mAhi = 0, mBlo = 0, mBhi = 0;
                 if (i < list_len) {
                     const uint32_t blo = box.x, bhi = box.y;
@@ -763,7 +772,7 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
                     // then the channel FMAs of each brick under its own mask
                     float wA = 0.f, wB = 0.f, eA = 0.f, eB = 0.f;
                     if (__builtin_amdgcn_inverse_ballot_w64(mA | mB)) {
-                        const f32x2 e2 = gauss_exp_pair<EXP>(rec, (f32x2){pAx, pBx}, (f32x2){pAy, pBy}, (f32x2){pAz, pBz});
+                        const f32x2 e2 = gauss_exp_pair<EXP>(rec, px, py, pz);
                         eA = e2.x; eB = e2.y;
                         wA = gauss_weight<VARIANT>(rec, eA);
                         wB = gauss_weight<VARIANT>(rec, eB);
@@ -836,6 +845,10 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
         }
         }
         __syncthreads();  // staging is reused as list storage by the next zg
+        // first bitmask word of the next z group (D > 16 only).  Requested here and not at the top of the
+        // loop: a conditional load is waited for where its branch joins, and at the top that join also
+        // waited for the point loads of the first group.
+        if ((zg + 1) * 16 < a.D) word_next = tid < a.nwords ? bm[tid] : 0ull;
 #if GF_TIMELINE
         if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x + 3] = wall_clock64();
 #endif

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 4) void gf_subm_gemm_kernel(SubmArgs a)
     const unsigned int seg_end = a.t.kstart[k + 1];
     // gathered feature half-row and the W slice: every load is issued before the first use
     const unsigned int myslot = slot0 + i;
-    const int row = myslot < seg_end ? a.pair_in[myslot] : 0;  // padding lanes compute on row 0; never stored
+    const int row = a.pair_in[min(myslot, seg_end - 1)];  // padding lanes repeat the segment's last pair; never stored
     const float *wsrc = a.weight + (size_t)k * CIN * COUT + c_lo;
     float4 wv[WQ];
 #pragma unroll
@@ -301,8 +301,9 @@ __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
     // rows of up to UNR hits are requested together: one at a time the walk is a chain of ~1 us loads.
     for (int k0 = 0; k0 < a.K3; k0 += CG) {
         const int kk = k0 + tc;
-        const int c_mine = live && kk < a.K3 ? cn[kk] : 0;
-        const int s_mine = c_mine ? sf[kk] : 0;
+        const int kc = min(kk, a.K3 - 1);  // both loads unconditional, masked afterwards
+        const int c_raw = cn[kc], s_mine = sf[kc];
+        const int c_mine = live && kk < a.K3 ? c_raw : 0;
         unsigned long long hits = (__ballot(c_mine != 0) >> gshift) & (CG == 64 ? ~0ull : ((1ull << CG) - 1ull));
         while (hits) {  // uniform within the group; other groups of the wave idle through it
             int l[UNR], c[UNR], s0[UNR];
@@ -313,7 +314,9 @@ __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
                 if (hits) hits &= hits - 1;
                 c[u] = l[u] >= 0 ? __shfl(c_mine, max(l[u], 0), CG) : 0;
                 s0[u] = __shfl(s_mine, max(l[u], 0), CG);
-                v[u] = c[u] ? reinterpret_cast<const float4 *>(a.partial + (size_t)s0[u] * COUT)[tc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                // unconditional (slot 0 for the empty entries; their value is never added): a load under a condition
+                // is waited for inside its branch and the four requests would go out one after the other
+                v[u] = reinterpret_cast<const float4 *>(a.partial + (size_t)(c[u] ? s0[u] : 0) * COUT)[tc];
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -336,7 +339,7 @@ __device__ __forceinline__ void wgrad_fetch_idx(int (&idx)[Q], const int *pairs,
 #pragma unroll
     for (int u = 0; u < Q; ++u) {
         const unsigned int p = pb + (threadIdx.x + 256 * u) / (C / 4);
-        idx[u] = p < p1 ? pairs[p] : 0;  // padding pairs read row 0 and are zeroed when staged
+        idx[u] = pairs[min(p, p1 - 1)];  // padding pairs re-read the chunk's last pair (no branch around the load) and are zeroed when staged
     }
 }
 
