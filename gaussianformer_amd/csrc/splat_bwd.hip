@@ -464,24 +464,38 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
             x += qx + carry;
         };
         float2 raw[9];
+        float2 raw2[9];  // prob variant: the logits rows of the same voxels
         float dL[kC];
         float ptx = 0.f, pty = 0.f, ptz = 0.f, ptx_n = 0.f, pty_n = 0.f, ptz_n = 0.f;
         int p = point_of(i, x, y, z), p_n = -1;
         stage_issue(a.out_grad, p, raw, s_pidx, lane);
+        if (VARIANT == GF_SPLAT_PROB) stage_issue(a.logits, p, raw2, s_pidx, lane);
         { const size_t pc = (size_t)max(p, 0); ptx = a.pts[3 * pc]; pty = a.pts[3 * pc + 1]; ptz = a.pts[3 * pc + 2]; }  // unconditional, see stage_issue
+        // prob variant: the four per-voxel scalars travel with the position, one iteration ahead and without a
+        // branch around the loads (inside `if (p >= 0)` each of them was waited for where it was issued)
+        float psum = 0.f, binl = 0.f, bing = 0.f, deng = 0.f, psum_n = 0.f, binl_n = 0.f, bing_n = 0.f, deng_n = 0.f;
+        if (VARIANT == GF_SPLAT_PROB) {
+            const size_t pc = (size_t)max(p, 0);
+            psum = a.probability[pc];
+            if (a.bin_grad) { binl = a.bin_logits[pc]; bing = a.bin_grad[pc]; }  // kernel-uniform conditions
+            if (a.dens_grad) deng = a.dens_grad[pc];
+        }
         for (int base = o0; base < o1; base += 64) {  // wave-uniform trip count
             stage_finish(raw, dL, s_rows, lane);
             float lg[kC];
-            if (VARIANT == GF_SPLAT_PROB) {
-                float2 raw2[9];
-                stage_issue(a.logits, p, raw2, s_pidx, lane);
-                stage_finish(raw2, lg, s_rows, lane);
-            }
+            if (VARIANT == GF_SPLAT_PROB) stage_finish(raw2, lg, s_rows, lane);  // requested one iteration ago, like dL
             advance();
             i += 64;
             p_n = point_of(i, x, y, z);
             stage_issue(a.out_grad, p_n, raw, s_pidx, lane);
+            if (VARIANT == GF_SPLAT_PROB) stage_issue(a.logits, p_n, raw2, s_pidx, lane);
             { const size_t pc = (size_t)max(p_n, 0); ptx_n = a.pts[3 * pc]; pty_n = a.pts[3 * pc + 1]; ptz_n = a.pts[3 * pc + 2]; }
+            if (VARIANT == GF_SPLAT_PROB) {
+                const size_t pc = (size_t)max(p_n, 0);
+                psum_n = a.probability[pc];
+                if (a.bin_grad) { binl_n = a.bin_logits[pc]; bing_n = a.bin_grad[pc]; }
+                if (a.dens_grad) deng_n = a.dens_grad[pc];
+            }
             if (p >= 0) {
                 const float dx = mx - ptx, dy = my - pty, dz = mz - ptz;
                 float power = c1x * dx * dx + c1y * dy * dy + c1z * dz * dz;
@@ -517,7 +531,6 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
                 } else {
                     // model/head/localagg_prob/src/backward.cu:76-107
                     const float prob = kdet * e;
-                    const float psum = a.probability[p];
                     float prob_grad = 0.f;
                     if ((double)psum > 1e-9) {
                         const float coef = prob * opa / psum;
@@ -531,8 +544,8 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
                         og += Asum * prob / psum;
                     }
                     float power_grad = prob_grad * kdet;
-                    if (a.bin_grad) power_grad += (1 - a.bin_logits[p]) / (1 - e + 1e-9f) * a.bin_grad[p];
-                    if (a.dens_grad) power_grad += a.dens_grad[p];
+                    if (a.bin_grad) power_grad += (1 - binl) / (1 - e + 1e-9f) * bing;
+                    if (a.dens_grad) power_grad += deng;
                     dg += prob_grad * prob / 2 / deter;
                     const float pg = power_grad * e;
                     mg0 -= pg * sx; mg1 -= pg * sy; mg2 -= pg * sz;
@@ -541,6 +554,7 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
                 }
             }
             p = p_n; ptx = ptx_n; pty = pty_n; ptz = ptz_n;
+            if (VARIANT == GF_SPLAT_PROB) { psum = psum_n; binl = binl_n; bing = bing_n; deng = deng_n; }
         }
 
         // Reduce across the wave and store: slots 0-17 semantics, 18-23 covariance, 24-26 mean,
