@@ -134,7 +134,32 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     const int g = word * 64 + lane;
     const bool valid = g < a.P;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    if (valid) gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
+    // Small P (one wave per workgroup): the kernel is a chain of memory round trips, so every input of
+    // this lane's Gaussian is requested up front in straight-line code -- the box inputs first, they are
+    // waited for first -- from a clamped index instead of under `if (valid)`: a load inside a branch is
+    // waited for inside it, which put the box, the parameters and the stores one round trip after the other.
+    float c_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sm_in[kC], mean_in[3] = {0.f, 0.f, 0.f}, opa_in = 0.f;
+    if (WAVES == 1) {
+        const int gc = min(g, a.P - 1);
+        const int m0 = a.means_int[3 * gc], m1 = a.means_int[3 * gc + 1], m2 = a.means_int[3 * gc + 2];
+        const int r0 = a.radii[a.per_axis ? 3 * gc : gc], r1 = a.radii[a.per_axis ? 3 * gc + 1 : gc],
+                  r2 = a.radii[a.per_axis ? 3 * gc + 2 : gc];
+        const float *cv = a.cov3D + 6 * (size_t)gc;
+        const float *sm = a.semantics + (size_t)kC * gc;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) c_in[j] = cv[j];
+#pragma unroll
+        for (int j = 0; j < kC; ++j) sm_in[j] = sm[j];
+        mean_in[0] = a.means3D[3 * gc]; mean_in[1] = a.means3D[3 * gc + 1]; mean_in[2] = a.means3D[3 * gc + 2];
+        opa_in = a.opacity[gc];
+        if (valid) {
+            lo[0] = min(a.H, max(0, m0 - r0)); hi[0] = min(a.H, max(0, m0 + r0 + 1));
+            lo[1] = min(a.W, max(0, m1 - r1)); hi[1] = min(a.W, max(0, m1 + r1 + 1));
+            lo[2] = min(a.D, max(0, m2 - r2)); hi[2] = min(a.D, max(0, m2 + r2 + 1));
+        }
+    } else if (valid) {
+        gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
+    }
     const bool nonempty = valid && hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2];
     // supertile range touched by the box
     const int sx_lo = lo[0] / kSuper, sx_hi = nonempty ? (hi[0] - 1) / kSuper : -1;
@@ -151,16 +176,15 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             const uint32_t plo = pack3(lo[0], lo[1], lo[2]);
             const uint32_t phi = nonempty ? pack3(hi[0], hi[1], hi[2]) : plo;
             a.boxes[g] = make_uint2(plo, phi);
-            const float *cv = a.cov3D + 6 * (size_t)g;
-            const float c0 = cv[0], c1 = cv[1], c2 = cv[2], c3 = cv[3], c4 = cv[4], c5 = cv[5];
+            const float c0 = c_in[0], c1 = c_in[1], c2 = c_in[2], c3 = c_in[3], c4 = c_in[4], c5 = c_in[5];
             float kdet = 0.f;
             if (a.variant == GF_SPLAT_PROB) {
                 // model/head/localagg_prob/src/forward.cu:77-78
                 kdet = prob_kdet(c0, c1, c2, c3, c4, c5);
             }
-            const float *sm = a.semantics + (size_t)kC * g;
+            const float *sm = sm_in;
             float4 *rec = reinterpret_cast<float4 *>(a.records + (size_t)g * kRecDwords);
-            rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opacity[g]);
+            rec[0] = make_float4(mean_in[0], mean_in[1], mean_in[2], opa_in);
             if (a.prescale) {
                 // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
                 // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
