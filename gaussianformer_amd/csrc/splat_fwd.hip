@@ -111,11 +111,12 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             int x[4], y[4], z[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const long long n = n0 + k * stride;
-                const bool in = n < a.N;
-                x[k] = in ? a.points_int[3 * n] : 0;
-                y[k] = in ? a.points_int[3 * n + 1] : 0;
-                z[k] = in ? a.points_int[3 * n + 2] : 0;
+                // clamped, not conditional: `in ? load : 0` compiles to a branch around the load and the
+                // load is waited for inside it -- the four requests went out one after the other
+                const long long n = min(n0 + k * stride, (long long)a.N - 1);
+                x[k] = a.points_int[3 * n];
+                y[k] = a.points_int[3 * n + 1];
+                z[k] = a.points_int[3 * n + 2];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
