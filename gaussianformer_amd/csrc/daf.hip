@@ -436,12 +436,20 @@ __global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
     __shared__ uint32_t s_id[kDafChunk];
     __shared__ float s_cw[kDafChunk];
     __shared__ uint32_t s_cnt[kDafMaxTileRows + 1];
+    __shared__ int s_lvl[3 * 16];  // height, width, first pixel row of every level: read per tap from LDS (as global
+                                   // loads indexed by the tap's level they were sixteen serial round trips per thread)
     const int tid = threadIdx.x;
     const int gi = tid / LPT, cl = tid - gi * LPT;
     const int c0 = 4 * cl;
     const int group = c0 / (a.C / a.G);
     const uint32_t lvl_mask = (1u << a.lvl_bits) - 1u, cam_mask = (1u << a.cam_bits) - 1u;
     const uint32_t nitems = a.header[0];
+    if (tid < a.L) {
+        s_lvl[3 * tid] = a.spatial_shape[2 * tid];
+        s_lvl[3 * tid + 1] = a.spatial_shape[2 * tid + 1];
+        s_lvl[3 * tid + 2] = a.scale_start[tid];
+    }
+    __syncthreads();
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         const uint32_t tile = a.item_tile[item];
         const uint32_t chunk = item - a.item_start[tile];
@@ -475,12 +483,12 @@ __global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
             const int s = (int)(q & lvl_mask);
             const uint32_t cam = (q >> a.lvl_bits) & cam_mask;
             const float loc_w = lc[j].x, loc_h = lc[j].y;
-            const int h = a.spatial_shape[2 * s], w = a.spatial_shape[2 * s + 1];
+            const int h = s_lvl[3 * s], w = s_lvl[3 * s + 1];
             const float h_im = loc_h * h - 0.5f, w_im = loc_w * w - 0.5f;
             const float fh = floorf(h_im), fw = floorf(w_im);
             const float lh = h_im - fh, lw = w_im - fw, hh = 1 - lh, hw = 1 - lw;
             cw[j] = k == 0 ? hh * hw : k == 1 ? hh * lw : k == 2 ? lh * hw : lh * lw;
-            const uint32_t row = cam * (uint32_t)a.num_feat + (uint32_t)a.scale_start[s] +
+            const uint32_t row = cam * (uint32_t)a.num_feat + (uint32_t)s_lvl[3 * s + 2] +
                                  (uint32_t)(((int)fh + (k >> 1)) * w + (int)fw + (k & 1));
             if (ti < t1) {
                 lrow[j] = (int)(row - row_base);
@@ -584,7 +592,7 @@ static DafSortPlan daf_sort_plan(int cams, int num_feat, int C, int L, int pts, 
     const int id_bits = 2 + p.lvl_bits + p.cam_bits;
     p.tile_rows = C > 0 && C <= kDafTileFloats ? kDafTileFloats / C : 1;
     const unsigned long long ntiles = (rows + p.tile_rows - 1) / p.tile_rows;
-    p.eligible = C % 4 == 0 && (lpt == 16 || lpt == 32 || lpt == 64) && (C / G) % 4 == 0 && ntiles <= (unsigned)kDafMaxTiles &&
+    p.eligible = C % 4 == 0 && (lpt == 16 || lpt == 32 || lpt == 64) && (C / G) % 4 == 0 && ntiles <= (unsigned)kDafMaxTiles && L <= 16 &&
                  p.max_taps < (1ull << 32) && ((unsigned long long)pts << id_bits) <= (1ull << 32);
     p.ntiles = (int)ntiles;
     p.max_items = p.max_taps / kDafChunk + ntiles + 1;
