@@ -747,7 +747,7 @@ extern "C" int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, 
         hipLaunchKernelGGL(gf_daf_colscan_kernel, dim3((p.ntiles + 255) / 256), dim3(256), 0, stream, sa);
         hipLaunchKernelGGL(gf_daf_tilescan_kernel, dim3(1), dim3(1024), 0, stream, sa);
         hipLaunchKernelGGL(gf_daf_bucket_kernel<true>, dim3(kDafBucketWgs), dim3(1024), 0, stream, sa);
-        const unsigned gblocks = 256 * 8;  // persistent, item-strided
+        const unsigned gblocks = 256 * 4;  // persistent, item-strided; the kernel runs at the same rate from 2 to 8 workgroups per CU (bound by row fetches from Infinity Cache)
         if (lpp == 16) hipLaunchKernelGGL(gf_daf_accumulate_kernel<16>, dim3(gblocks), dim3(256), 0, stream, sa);
         else if (lpp == 32) hipLaunchKernelGGL(gf_daf_accumulate_kernel<32>, dim3(gblocks), dim3(256), 0, stream, sa);
         else hipLaunchKernelGGL(gf_daf_accumulate_kernel<64>, dim3(gblocks), dim3(256), 0, stream, sa);
