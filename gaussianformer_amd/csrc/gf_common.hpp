@@ -41,6 +41,7 @@ struct SplatWorkspace {
     uint32_t *bsum;         // [ceil(P/256)] backward: volume sums per 256 Gaussians (sorted order)
     uint32_t *vols_in;      // [P]  backward: box volumes in input order
     int *order;             // [P]  backward: Gaussian index at each sorted position
+    int *seg;               // [P][8] backward: (index, volume, box lo[3], box hi[3]) of the Gaussian at each sorted position
     uint32_t *sort_hist;    // [64][ceil(P/256)] + [64] backward: per-(cell, block) counts -> offsets, cell totals
     int nwords, nsx, nsy, nsuper;
     size_t total_bytes;
@@ -67,6 +68,7 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.bsum = (uint32_t *)(p + off); off += align256((size_t)((P + 255) / 256) * 4);
     ws.vols_in = (uint32_t *)(p + off); off += align256((size_t)P * 4);
     ws.order = (int *)(p + off); off += align256((size_t)P * 4);
+    ws.seg = (int *)(p + off); off += align256((size_t)P * 32);
     ws.sort_hist = (uint32_t *)(p + off); off += align256(((size_t)64 * ((P + 255) / 256) + 64) * 4);
     ws.total_bytes = off;
     return ws;

@@ -52,6 +52,7 @@ struct BwdArgs {
     uint32_t *bsum;   // [ceil(P/256)] sums of 256 consecutive sorted volumes
     uint32_t *vols_in;    // [P] box volumes in input order
     int *order;           // [P] input index of the Gaussian at each sorted position
+    int *seg;             // [P][8] (input index, volume, box lo[3], box hi[3]) at each sorted position: one scalar fetch per segment
     uint32_t *sort_hist;  // [kSortCells][nblk]
     int P, N, H, W, D, per_axis, force_general, assume_dense, nblk;
 };
@@ -253,6 +254,11 @@ __global__ __launch_bounds__(256) void gf_bwd_sort_scatter_kernel(BwdArgs a)
         const uint32_t v = a.vols_in[g];
         a.order[pos] = g;
         a.vols[pos] = v;
+        int lo[3], hi[3];
+        box_of(a, g, lo, hi);
+        int4 *sg = reinterpret_cast<int4 *>(a.seg + 8 * (size_t)pos);
+        sg[0] = make_int4(g, (int)v, lo[0], lo[1]);
+        sg[1] = make_int4(lo[2], hi[0], hi[1], hi[2]);
     }
 }
 
@@ -392,9 +398,24 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
         g = blo * 256 + (k + 1) * 64;
     }
 
-    // ---- walk Gaussian segments until the range is exhausted
+    // ---- walk Gaussian segments until the range is exhausted.  A segment starts with ONE scalar fetch of
+    // its descriptor (index, volume, box) -- requested while the previous segment was being walked -- where
+    // volume, sorted index and the two box inputs used to be four dependent round trips; the walk always
+    // moves to the next sorted position, so the descriptor after this one can be requested right away.
+    using cint_t = const int __attribute__((address_space(4))) *;
+    auto load_seg = [&](int gg, int (&d)[8]) {
+        cint_t sp = (cint_t)(uintptr_t)(a.seg + 8 * (size_t)__builtin_amdgcn_readfirstlane(min(gg, a.P - 1)));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = sp[q];
+    };
+    int nxt[8];
+    load_seg(g, nxt);
     while (r0 < r1 && g < a.P) {
-        const int vol = (int)a.vols[g];
+        int cur[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+        load_seg(g + 1, nxt);
+        const int vol = cur[1];
         const int o0 = (int)(r0 - gstart);                                  // first voxel of the segment
         const int o1 = (int)min((unsigned long long)vol, r1 - gstart);      // one past its last voxel
         if (vol == 0 || o0 >= vol) {  // empty box (or exactly at its end): next Gaussian
@@ -403,9 +424,8 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
             continue;
         }
         // g is a position in the sorted order; gid is the Gaussian it holds
-        const int gid = __builtin_amdgcn_readfirstlane(((const int __attribute__((address_space(4))) *)(uintptr_t)a.order)[g]);
-        int lo[3], hi[3];
-        box_of(a, gid, lo, hi);
+        const int gid = cur[0];
+        const int lo[3] = {cur[2], cur[3], cur[4]}, hi[3] = {cur[5], cur[6], cur[7]};
         const int ny = hi[1] - lo[1], nz = hi[2] - lo[2];
 
         // wave-uniform Gaussian parameters
@@ -636,7 +656,7 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     a.out_grad = logits_grad;
     a.means_grad = means3D_grad; a.opa_grad = opacity_grad; a.sem_grad = semantics_grad; a.cov_grad = cov3D_grad;
     a.state = (const uint32_t *)state; a.voxel2pts = ws.voxel2pts; a.vols = ws.vols; a.bsum = ws.bsum;
-    a.vols_in = ws.vols_in; a.order = ws.order; a.sort_hist = ws.sort_hist;
+    a.vols_in = ws.vols_in; a.order = ws.order; a.seg = ws.seg; a.sort_hist = ws.sort_hist;
     a.P = P; a.N = N; a.H = H; a.W = W; a.D = D; a.per_axis = radii_per_axis ? 1 : 0; a.nblk = (P + 255) / 256;
     const long long V = (long long)H * W * D;
     a.force_general = ((long long)N != V || (flags & GF_PTS_GENERAL)) ? 1 : 0;
