@@ -11,7 +11,7 @@ detection, inputs and outputs resident in HBM) over one frame: P = 25 601 Gaussi
 P Gaussians into a full partial grid and the partial logits are summed with one RCCL
 all-reduce (weak scaling: per-GPU work is fixed); ``value`` counts the Gaussians
 of all ranks.  Rank 0 prints one JSON line.  Extras next to `value`, never instead of it: `two_stream` (N = 1, two
-frames in flight) and `reduce_scatter_labels` (N > 1, the label-producing variant with half the xGMI traffic).
+frames in flight), `hip_graph` (N = 1, the step replayed as one captured HIP graph) and `reduce_scatter_labels` (N > 1, the label-producing variant with half the xGMI traffic).
 """
 import argparse
 import ctypes
@@ -210,6 +210,32 @@ def main():
         except Exception as exc:  # an extra must never cost the headline line
             rs_labels = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # Extra, N = 1 only: the same step captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed K times --
+    # what a serving loop that splats the same buffers every frame would do.  Never `value`.
+    hip_graph = None
+    if world == 1 and not args.no_two_stream:
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                plan.run()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                plan.run()
+            for _ in range(max(2, args.warmup // 2)):
+                graph.replay()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t3
+            hip_graph = {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
+                         "note": "same K steps as replays of one captured HIP graph (prep + render)"}
+        except Exception as exc:  # an extra must never cost the headline line
+            hip_graph = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * P / (elapsed / args.steps)
@@ -236,6 +262,8 @@ def main():
         }
         if two_stream:
             out["two_stream"] = two_stream
+        if hip_graph:
+            out["hip_graph"] = hip_graph
         if rs_labels:
             out["reduce_scatter_labels"] = rs_labels
         if world == 1 and not args.no_cpu_baseline:

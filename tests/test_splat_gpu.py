@@ -383,3 +383,32 @@ def test_forward_pipeline_two_streams(gpu):
         ev.synchronize()
         assert np.array_equal(logits.cpu().numpy(), ref["logits"])
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_forward_is_graph_capturable(gpu):
+    """The forward C-ABI call only enqueues work on the given stream (no allocation, no synchronisation, no host
+    read), so it can be captured into a HIP graph (torch.cuda.CUDAGraph on ROCm) and replayed."""
+    import torch
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import SplatForwardPlan
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=23, P=2000, H=48, W=40, D=16)
+    pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size,
+                                                      si.scale_multiplier)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
+    plan = SplatForwardPlan(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO)
+    eager = plan.run().clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):      # warm-up on the capture stream, as torch recommends
+        plan.run()
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        plan.run()
+    for _ in range(3):
+        plan.logits.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.logits, eager)
