@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct SubmTables {
     int *head;              // [cells]  first point of the cell's list, -1 = empty
     int *next;              // [N]
-    int *slot_first;        // [N][K3]  first pair slot of (out point, offset), -1 = none
+    int *slot_first;        // [N][K3]  first pair slot of (out point, offset); defined only where cnt > 0 (never cleared)
     unsigned short *cnt;    // [N][K3]  pairs of (out point, offset); a cell with more than 65535 points raises total[1]
     unsigned long long *kcount;  // [K3] pairs per offset (64-bit: crowded cells square their population)
     unsigned int *kstart;   // [K3+1]
@@ -489,7 +489,6 @@ extern "C" int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int
     GF_CHECK_ARG(((uintptr_t)indices & 15) == 0 && ((uintptr_t)tables & 255) == 0, "indices must be 16-byte and tables 256-byte aligned");
     SubmArgs a = subm_args(N, batch, X, Y, Z, K, indices, tables);
     if (hipMemsetAsync(a.t.head, 0xFF, (size_t)a.cells * 4, stream) != hipSuccess ||
-        hipMemsetAsync(a.t.slot_first, 0xFF, (size_t)N * a.K3 * 4, stream) != hipSuccess ||
         hipMemsetAsync(a.t.cnt, 0, (size_t)N * a.K3 * 2, stream) != hipSuccess ||
         hipMemsetAsync(a.t.total, 0, 16, stream) != hipSuccess ||
         hipMemsetAsync(a.t.kcount, 0, (size_t)a.K3 * 8, stream) != hipSuccess) {
