@@ -37,6 +37,7 @@ struct SubmTables {
     unsigned int *kstart;   // [K3+1]
     unsigned int *tile_start;  // [K3+1]
     unsigned int *kcursor;  // [K3]
+    unsigned char *kmask;   // [K*K][N] bit kz: offset (kxy, kz) of the point has a neighbour cell with points (count pass -> fill pass)
     unsigned int *chunk_start;  // [K3+1] weight-gradient chunks before segment k
     unsigned long long *total;  // [0] total pairs, [1] non-zero if a cell is too crowded for the 16-bit counts
 };
@@ -71,6 +72,7 @@ static SubmTables subm_carve(void *base, int N, long long cells, int K3, size_t 
     t.kstart = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
     t.tile_start = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
     t.kcursor = (unsigned int *)(p + off); off += subm_align((size_t)K3 * 4);
+    t.kmask = (unsigned char *)(p + off); off += subm_align((size_t)N * 49);  // K <= 7
     t.chunk_start = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
     t.total = (unsigned long long *)(p + off); off += 256;
     *bytes = off;
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(256) void gf_subm_grid_kernel(SubmArgs a)
 template <bool FILL>
 __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
 {
-    __shared__ unsigned int s_w[4], s_base;
+    constexpr int KMAX = 7;
+    __shared__ unsigned int s_w[KMAX][4], s_base[KMAX];
     const int i = blockIdx.x * 256 + threadIdx.x, kxy = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = a.K / 2;
@@ -112,46 +115,65 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
             z = c.w;
         }
     }
-    for (int kz = 0; kz < a.K; ++kz) {
-        const int k = kxy * a.K + kz, zz = z + kz - r;
-        unsigned int c = 0;
-        int first = -1;
-        if (col >= 0 && zz >= 0 && zz < a.Z) {
-            first = a.t.head[col + zz];
-            for (int j = first; j >= 0; j = a.t.next[j]) ++c;
+    // the count pass leaves one byte per (point, column): which of the K cells along z hold points.  The fill
+    // pass reads it (coalesced) and looks only those cells up -- 6 % of them at the nuScenes density
+    unsigned int seen = 0;
+    if (FILL && i < a.N) seen = a.t.kmask[(size_t)kxy * a.N + i];
+    // All K offsets of the column go through ONE pair of barriers and ONE round of atomics: counts and wave
+    // scans for every kz first, then the cross-wave totals, then thread kz reserves the slots of offset kz.
+    // (One kz at a time it was three barriers and, in the fill pass, a returning atomic per kz: five
+    // serial round trips per workgroup.)
+    unsigned int c[KMAX], incl[KMAX];
+    int first[KMAX];
+#pragma unroll
+    for (int kz = 0; kz < KMAX; ++kz) {
+        c[kz] = 0; first[kz] = -1;
+        const int zz = z + kz - r;
+        if (kz < a.K && col >= 0 && zz >= 0 && zz < a.Z && (!FILL || ((seen >> kz) & 1u))) {
+            first[kz] = a.t.head[col + zz];
+            for (int j = first[kz]; j >= 0; j = a.t.next[j]) ++c[kz];
         }
-        // block exclusive prefix of c
-        unsigned int incl = c;
+        if (!FILL && c[kz]) seen |= 1u << kz;
+        unsigned int v = c[kz];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
+            const unsigned int up = __shfl_up(v, d, 64);
+            if (lane >= d) v += up;
         }
-        __syncthreads();  // s_w / s_base of the previous kz consumed
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        unsigned int before = incl - c, total = 0;
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) before += s_w[w];
-            total += s_w[w];
+        incl[kz] = v;
+        if (lane == 63) s_w[kz][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < a.K) {  // thread kz: total of offset kz over the workgroup
+        const int kz = threadIdx.x, k = kxy * a.K + kz;
+        const unsigned int total = s_w[kz][0] + s_w[kz][1] + s_w[kz][2] + s_w[kz][3];
+        if (total) {
+            if (!FILL) atomicAdd(a.t.kcount + k, (unsigned long long)total);
+            else s_base[kz] = a.t.kstart[k] + atomicAdd(a.t.kcursor + k, total);
         }
-        if (total == 0) continue;  // block-uniform
-        if (!FILL) {
-            if (threadIdx.x == 0) atomicAdd(a.t.kcount + k, (unsigned long long)total);
-            if (c) a.t.cnt[(size_t)i * a.K3 + k] = (unsigned short)min(c, 65535u);
-            if (c > 65535u) atomicOr(a.t.total + 1, 1ull);  // reported next to the pair count; the caller must refuse
-            continue;
+    }
+    if (!FILL) {
+#pragma unroll
+        for (int kz = 0; kz < KMAX; ++kz) {
+            if (!c[kz]) continue;
+            a.t.cnt[(size_t)i * a.K3 + kxy * a.K + kz] = (unsigned short)min(c[kz], 65535u);
+            if (c[kz] > 65535u) atomicOr(a.t.total + 1, 1ull);  // reported next to the pair count; the caller must refuse
         }
-        if (threadIdx.x == 0) s_base = a.t.kstart[k] + atomicAdd(a.t.kcursor + k, total);
-        __syncthreads();
-        if (c) {
-            unsigned int slot = s_base + before;
-            a.t.slot_first[(size_t)i * a.K3 + k] = (int)slot;
-            for (int j = first; j >= 0; j = a.t.next[j]) {
-                a.pair_in[slot] = j;
-                a.pair_out[slot] = i;
-                ++slot;
-            }
+        if (i < a.N) a.t.kmask[(size_t)kxy * a.N + i] = (unsigned char)seen;
+        return;
+    }
+    __syncthreads();  // s_base visible
+#pragma unroll
+    for (int kz = 0; kz < KMAX; ++kz) {
+        if (!c[kz]) continue;
+        unsigned int before = incl[kz] - c[kz];
+        for (int w = 0; w < wave; ++w) before += s_w[kz][w];
+        unsigned int slot = s_base[kz] + before;
+        a.t.slot_first[(size_t)i * a.K3 + kxy * a.K + kz] = (int)slot;
+        for (int j = first[kz]; j >= 0; j = a.t.next[j]) {
+            a.pair_in[slot] = j;
+            a.pair_out[slot] = i;
+            ++slot;
         }
     }
 }
