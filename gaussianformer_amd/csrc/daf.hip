@@ -367,19 +367,37 @@ __global__ __launch_bounds__(1024) void gf_daf_bucket_kernel(DafSortArgs a)
     }
 }
 
-// One thread per tile: exclusive prefix of M[.][tile] over the workgroups; total -> tile_start[tile].
+// Exclusive prefix of M[.][tile] over the bucket workgroups; total -> tile_start[tile].  Eight lanes per tile,
+// each with 32 consecutive workgroups in registers (32 independent loads), combined by an 8-lane scan: one thread
+// per tile walking all 256 rows was a chain of 256 dependent read-modify-writes on eleven workgroups' worth of threads.
 __global__ __launch_bounds__(256) void gf_daf_colscan_kernel(DafSortArgs a)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= a.ntiles) return;
-    uint32_t run = 0;
-#pragma unroll 8
-    for (int wg = 0; wg < kDafBucketWgs; ++wg) {
-        const uint32_t c = a.M[(size_t)wg * a.ntiles + t];
-        a.M[(size_t)wg * a.ntiles + t] = run;
-        run += c;
+    constexpr int kParts = 8, kPer = kDafBucketWgs / kParts;
+    const int gidx = blockIdx.x * 256 + threadIdx.x;
+    const int t = gidx / kParts, part = gidx % kParts;
+    const bool live = t < a.ntiles;
+    const int tc = live ? t : a.ntiles - 1;
+    uint32_t c[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) c[j] = a.M[(size_t)(part * kPer + j) * a.ntiles + tc];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t v = c[j];
+        c[j] = sum;
+        sum += v;
     }
-    a.tile_start[t] = run;  // per-tile total; turned into a prefix by gf_daf_tilescan_kernel
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < kParts; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, kParts);
+        if (part >= d) incl += up;
+    }
+    const uint32_t base = incl - sum;
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) a.M[(size_t)(part * kPer + j) * a.ntiles + t] = base + c[j];
+    if (part == kParts - 1) a.tile_start[t] = incl;  // per-tile total; turned into a prefix by gf_daf_tilescan_kernel
 }
 
 // Single workgroup: prefix over the tiles, work-item table.
@@ -744,7 +762,7 @@ extern "C" int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, 
         sa.grad_out = grad_output + (size_t)b * num_pts * C;
         sa.grad_feat = grad_mc_ms_feat + (size_t)b * num_cams * num_feat * C;
         hipLaunchKernelGGL(gf_daf_bucket_kernel<false>, dim3(kDafBucketWgs), dim3(1024), 0, stream, sa);
-        hipLaunchKernelGGL(gf_daf_colscan_kernel, dim3((p.ntiles + 255) / 256), dim3(256), 0, stream, sa);
+        hipLaunchKernelGGL(gf_daf_colscan_kernel, dim3((p.ntiles * 8 + 255) / 256), dim3(256), 0, stream, sa);
         hipLaunchKernelGGL(gf_daf_tilescan_kernel, dim3(1), dim3(1024), 0, stream, sa);
         hipLaunchKernelGGL(gf_daf_bucket_kernel<true>, dim3(kDafBucketWgs), dim3(1024), 0, stream, sa);
         const unsigned gblocks = 256 * 4;  // persistent, item-strided; the kernel runs at the same rate from 2 to 8 workgroups per CU (bound by row fetches from Infinity Cache)
