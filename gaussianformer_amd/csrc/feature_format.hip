@@ -35,29 +35,34 @@ __global__ __launch_bounds__(256) void gf_feature_format_kernel(FormatArgs a)
     float *tab = a.table + ((size_t)plane * a.num_feat + a.start[lvl]) * a.C;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
     const int p0 = pt * kFmtTile, c0 = ct * kFmtTile;
+    // The sixteen elements a thread moves are loaded together from clamped coordinates (tile edges re-read the
+    // last row / column; those slots are never stored): as `if (in range) s_tile[..] = load` each load sat in its
+    // own branch with its own wait, sixteen round trips in a row.
+    constexpr int kPer = kFmtTile / 4;
+    float v[kPer];
     if (!INVERSE) {
-#pragma unroll 4
-        for (int k = 0; k < kFmtTile / 4; ++k) {  // level[c][p]: p fastest
-            const int c = c0 + ty + 4 * k, p = p0 + tx;
-            if (c < a.C && p < hw) s_tile[ty + 4 * k][tx] = lev[(size_t)c * hw + p];
-        }
+        const int p = min(p0 + tx, hw - 1);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) v[k] = lev[(size_t)min(c0 + ty + 4 * k, a.C - 1) * hw + p];  // level[c][p]: p fastest
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) s_tile[ty + 4 * k][tx] = v[k];
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < kFmtTile / 4; ++k) {  // table[p][c]: c fastest
-            const int p = p0 + ty + 4 * k, c = c0 + tx;
-            if (c < a.C && p < hw) tab[(size_t)p * a.C + c] = s_tile[tx][ty + 4 * k];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {  // table[p][c]: c fastest
+            const int pp = p0 + ty + 4 * k, c = c0 + tx;
+            if (c < a.C && pp < hw) tab[(size_t)pp * a.C + c] = s_tile[tx][ty + 4 * k];
         }
     } else {
-#pragma unroll 4
-        for (int k = 0; k < kFmtTile / 4; ++k) {
-            const int p = p0 + ty + 4 * k, c = c0 + tx;
-            if (c < a.C && p < hw) s_tile[tx][ty + 4 * k] = tab[(size_t)p * a.C + c];
-        }
+        const int c = min(c0 + tx, a.C - 1);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) v[k] = tab[(size_t)min(p0 + ty + 4 * k, hw - 1) * a.C + c];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) s_tile[tx][ty + 4 * k] = v[k];
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < kFmtTile / 4; ++k) {
-            const int c = c0 + ty + 4 * k, p = p0 + tx;
-            if (c < a.C && p < hw) lev[(size_t)c * hw + p] = s_tile[ty + 4 * k][tx];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int cc = c0 + ty + 4 * k, p = p0 + tx;
+            if (cc < a.C && p < hw) lev[(size_t)cc * hw + p] = s_tile[ty + 4 * k][tx];
         }
     }
 }
