@@ -59,3 +59,42 @@ def test_ops_fail_loudly_on_cpu_tensors():
     from model.encoder.gaussian_encoder.ops import DeformableAggregationFunction as DAF
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         DAF.apply(z(1, 1, 4, 8), torch.tensor([[2, 2]]), torch.tensor([0]), z(1, 3, 1, 2), z(1, 3, 1, 1, 4))
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Argument count and class (pointer / integer / long long / size_t / float) of every prototype in
+    include/gf_hip.h against gaussianformer_amd._lib.SIGNATURES -- a mismatch would not fail at load time, it
+    would pass garbage."""
+    import ctypes
+    import os
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "gf_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|size_t|void|const char \*)\s*\*?\s*(gf_\w+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    assert len(protos) == len(_lib.SIGNATURES)
+
+    def klass(decl):
+        decl = " ".join(decl.split())
+        if decl == "void":
+            return None
+        if "*" in decl:
+            return "ptr"
+        if decl.startswith("long long"):
+            return "ll"
+        if decl.startswith("size_t"):
+            return "size"
+        if decl.startswith("float"):
+            return "float"
+        assert decl.startswith("int"), decl
+        return "int"
+
+    def klass_c(t):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "ptr"
+        return {ctypes.c_longlong: "ll", ctypes.c_size_t: "size", ctypes.c_float: "float", ctypes.c_int: "int"}[t]
+
+    for name, args in protos:
+        want = [k for k in (klass(a) for a in args.split(",")) if k]
+        restype, argtypes = _lib.SIGNATURES[name]
+        got = [klass_c(t) for t in argtypes]
+        assert got == want, (name, got, want)
