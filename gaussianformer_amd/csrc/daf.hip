@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void gf_daf_fwd_kernel(DafArgs a)
             const Taps t = make_taps(h_im, w_im, h, w);
             const float *base = fcam + (size_t)a.scale_start[s] * a.C;
             // All four taps are loaded unconditionally from clamped (always valid) pixels and the
-            // out-of-image ones get a zero coefficient: a load under `if (ok)` is followed by its own
+            // out-of-image ones are replaced by zero: a load under `if (ok)` is followed by its own
             // s_waitcnt inside the branch, which made the sixteen taps of a camera a serial chain.
             const Corners c = clamp_corners(t, h, w);
             float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
@@ -123,11 +123,12 @@ __global__ __launch_bounds__(256) void gf_daf_fwd_kernel(DafArgs a)
             vload<VEC>(base + (size_t)c.r3 * a.C, v3);
             vload<VEC>(base + (size_t)c.r4 * a.C, v4);
             const float wt = wts[(cam * a.L + s) * a.G];
-            const float w1 = t.ok1 ? t.w1 : 0.f, w2 = t.ok2 ? t.w2 : 0.f, w3 = t.ok3 ? t.w3 : 0.f, w4 = t.ok4 ? t.w4 : 0.f;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float val = (w1 * v1[j] + w2 * v2[j] + w3 * v3[j] + w4 * v4[j]);  // :51-53
-                acc[j] += val * wt;                                                        // :182
+                // an out-of-image tap contributes exactly 0, whatever the clamped pixel holds (:36-50)
+                const float x1 = t.ok1 ? v1[j] : 0.f, x2 = t.ok2 ? v2[j] : 0.f, x3 = t.ok3 ? v3[j] : 0.f, x4 = t.ok4 ? v4[j] : 0.f;
+                const float val = (t.w1 * x1 + t.w2 * x2 + t.w3 * x3 + t.w4 * x4);  // :51-53
+                acc[j] += val * wt;                                                   // :182
             }
         }
     }
