@@ -74,6 +74,34 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     return ws;
 }
 
+// ---- prob variant: det(Sigma^-1) and (2 pi)^-1.5 sqrt(det) -----------------------------
+// model/head/localagg_prob/src/forward.cu:77-78, backward.cu:78-79:
+//     deter = c0*c1*c2 + 2*c3*c4*c5 - c0*c4*c4 - c1*c5*c5 - c2*c3*c3;   powf(2 * 3.1415926535, -1.5) * powf(deter, 0.5)
+// For an ill-conditioned Sigma^-1 (the Prob config's scales go down to 0.01 m) this sum cancels by up to twelve
+// orders of magnitude: in fp32 every digit depends on which products the compiler fuses, and it can round
+// negative (NaN, in the reference too).  Default = the reference's fp32 value: the fusion the compiled reference
+// applies (first two terms one FMA, the three subtractions unfused; read off the gfx950 ISA of oracle/_ref),
+// spelled out under `contract(off)` so it does not depend on this file's own optimisation context.
+// `exact` (GF_PROB_EXACT_DET) evaluates it in fp64 instead: the value the expression approximates.
+__device__ __forceinline__ float prob_det32(float c0, float c1, float c2, float c3, float c4, float c5)
+{
+#pragma clang fp contract(off)
+    const float t = __builtin_fmaf(c0 * c1, c2, ((c3 + c3) * c4) * c5);
+    return ((t - (c0 * c4) * c4) - (c1 * c5) * c5) - (c2 * c3) * c3;
+}
+__device__ __forceinline__ void prob_det_kdet(float c0, float c1, float c2, float c3, float c4, float c5, int exact,
+                                              float &deter, float &kdet)
+{
+    if (exact) {
+        const double d = (double)c0 * c1 * c2 + 2.0 * c3 * c4 * c5 - (double)c0 * c4 * c4 - (double)c1 * c5 * c5 - (double)c2 * c3 * c3;
+        deter = (float)d;
+        kdet = (float)(0.063493635934240969 * sqrt(d));  // (2 pi)^-1.5 sqrt(det)
+    } else {
+        deter = prob_det32(c0, c1, c2, c3, c4, c5);
+        kdet = powf(2 * 3.1415926535, -1.5) * powf(deter, 0.5);
+    }
+}
+
 // ---- error reporting ----------------------------------------------------------------
 void set_error(const char *fmt, ...);
 bool profile_slot(hipEvent_t *before, hipEvent_t *after);  // gf_api.hip

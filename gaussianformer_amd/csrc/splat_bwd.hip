@@ -54,7 +54,7 @@ struct BwdArgs {
     int *order;           // [P] input index of the Gaussian at each sorted position
     int *seg;             // [P][8] (input index, volume, box lo[3], box hi[3]) at each sorted position: one scalar fetch per segment
     uint32_t *sort_hist;  // [kSortCells][nblk]
-    int P, N, H, W, D, per_axis, force_general, assume_dense, nblk;
+    int P, N, H, W, D, per_axis, force_general, assume_dense, nblk, exact_det;
 };
 
 constexpr int kBwdMaxBlk = 1024;  // LDS prefix capacity: P <= 262 144 Gaussians
@@ -440,12 +440,9 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
         for (int ch = 0; ch < kC; ++ch) sem[ch] = sp[ch];
         float deter = 1.f, kdet = 0.f;
         if (VARIANT == GF_SPLAT_PROB) {
-            // model/head/localagg_prob/src/backward.cu:78-79
-            // in fp64, like the forward's prob_kdet (the fp32 sum cancels by orders of magnitude)
-            const double det64 = (double)c1x * c1y * c1z + 2.0 * c2x * c2y * c2z - (double)c1x * c2y * c2y -
-                                 (double)c1y * c2z * c2z - (double)c1z * c2x * c2x;
-            deter = (float)det64;
-            kdet = (float)(0.063493635934240969 * sqrt(det64));  // (2 pi)^-1.5 sqrt(det)
+            // model/head/localagg_prob/src/backward.cu:78-79: the reference's fp32 value by default, fp64 with
+            // GF_PROB_EXACT_DET -- the same choice the forward made (gf_common.hpp: prob_det_kdet)
+            prob_det_kdet(c1x, c1y, c1z, c2x, c2y, c2z, a.exact_det, deter, kdet);
         }
 
         float mg0 = 0.f, mg1 = 0.f, mg2 = 0.f, og = 0.f, dg = 0.f;
@@ -518,8 +515,11 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
             }
             if (p >= 0) {
                 const float dx = mx - ptx, dy = my - pty, dz = mz - ptz;
-                float power = c1x * dx * dx + c1y * dy * dy + c1z * dz * dz;
-                power = -0.5f * power - (c2x * dx * dy + c2y * dy * dz + c2z * dx * dz);
+                // backward.cu:69-70 with the fusion the compiled reference applies there (gfx950 ISA of oracle/_ref:
+                // the x-term of each sum is the rounded product -- not the forward kernel's choice)
+                const float q_ = fmaf(dz, c1z * dz, fmaf(dy, c1y * dy, (c1x * dx) * dx));
+                const float r_ = fmaf(c2z * dx, dz, fmaf(c2y * dy, dz, (c2x * dx) * dy));
+                const float power = fmaf(q_, -0.5f, -r_);
                 // base: exp via v_exp_f32 (2^(x log2 e)); the argument's rounding adds ~|power| * 6e-8 relative
                 // error.  prob keeps ocml expf: its gradient divides by 1 - e + 1e-9 (backward.cu:93).
                 const float e = VARIANT == GF_SPLAT_PROB ? expf(power) : __builtin_amdgcn_exp2f(power * 1.44269504088896340736f);
@@ -643,6 +643,15 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     GF_CHECK_ARG(N == 0 || (pts && points_int && logits_grad), "null point/grad pointer");
     GF_CHECK_ARG(variant == GF_SPLAT_BASE || N == 0 || (logits && bin_logits && probability),
                  "prob variant needs the forward outputs");
+    if (N == 0) {
+        // no query point: every gradient is zero (the kernels below read row 0 of pts / logits_grad unconditionally)
+        (void)hipMemsetAsync(means3D_grad, 0, sizeof(float) * 3 * (size_t)P, stream);
+        (void)hipMemsetAsync(opacity_grad, 0, sizeof(float) * (size_t)P, stream);
+        (void)hipMemsetAsync(semantics_grad, 0, sizeof(float) * kC * (size_t)P, stream);
+        (void)hipMemsetAsync(cov3D_grad, 0, sizeof(float) * 6 * (size_t)P, stream);
+        GF_CHECK_LAUNCH();
+        return GF_OK;
+    }
     GF_CHECK_ARG(workspace != nullptr, "null workspace");
     SplatWorkspace ws = carve_workspace(workspace, P, N, H, W, D);
     if (workspace_bytes < ws.total_bytes) {
@@ -661,6 +670,7 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     const long long V = (long long)H * W * D;
     a.force_general = ((long long)N != V || (flags & GF_PTS_GENERAL)) ? 1 : 0;
     a.assume_dense = (!a.force_general && (flags & GF_PTS_ASSUME_DENSE)) ? 1 : 0;
+    a.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
 
     const int v2p_blocks = a.assume_dense || N == 0 ? 0 : 2048;
     hipLaunchKernelGGL(gf_bwd_vol_kernel, dim3(a.nblk), dim3(256), 0, stream, a);

@@ -49,7 +49,7 @@ struct PrepArgs {
     uint2 *boxes;
     unsigned long long *bitmask;
     uint32_t *verify_flags;  // [kVerifyBlocks]
-    int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale;
+    int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det;
 };
 
 constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
@@ -72,16 +72,12 @@ __device__ __forceinline__ void gaussian_box(const int *__restrict__ means_int, 
     lo[2] = min(D, max(0, m2 - r2)); hi[2] = min(D, max(0, m2 + r2 + 1));
 }
 
-// (2 pi)^-1.5 sqrt(det Sigma^-1), model/head/localagg_prob/src/forward.cu:77-78.  The determinant of
-// an ill-conditioned Sigma^-1 (scales down to 0.01 m) is a sum that cancels by many orders of
-// magnitude: in fp32 its value depends on the compiler's FMA contraction (nvcc, gcc and hipcc all
-// differ, and it can even come out negative -> NaN).  One fp64 evaluation per Gaussian costs
-// nothing and removes that noise; the result is the correctly rounded value the fp32 expression
-// approximates.
-__device__ __forceinline__ float prob_kdet(float c0, float c1, float c2, float c3, float c4, float c5)
+// (2 pi)^-1.5 sqrt(det Sigma^-1), model/head/localagg_prob/src/forward.cu:77-78 (gf_common.hpp: prob_det_kdet)
+__device__ __forceinline__ float prob_kdet(float c0, float c1, float c2, float c3, float c4, float c5, int exact)
 {
-    const double deter = (double)c0 * c1 * c2 + 2.0 * c3 * c4 * c5 - (double)c0 * c4 * c4 - (double)c1 * c5 * c5 - (double)c2 * c3 * c3;
-    return (float)(0.063493635934240969 * sqrt(deter));  // (2 pi)^-1.5
+    float deter, kdet;
+    prob_det_kdet(c0, c1, c2, c3, c4, c5, exact, deter, kdet);
+    return kdet;
 }
 
 template <int WAVES>
@@ -181,7 +177,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             float kdet = 0.f;
             if (a.variant == GF_SPLAT_PROB) {
                 // model/head/localagg_prob/src/forward.cu:77-78
-                kdet = prob_kdet(c0, c1, c2, c3, c4, c5);
+                kdet = prob_kdet(c0, c1, c2, c3, c4, c5, a.exact_det);
             }
             const float *sm = sm_in;
             float4 *rec = reinterpret_cast<float4 *>(a.records + (size_t)g * kRecDwords);
@@ -250,7 +246,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             float kdet = 0.f;
             if (a.variant == GF_SPLAT_PROB) {
                 // model/head/localagg_prob/src/forward.cu:77-78
-                kdet = prob_kdet(c0, c1, c2, c3, c4, c5);
+                kdet = prob_kdet(c0, c1, c2, c3, c4, c5, a.exact_det);
             }
             float4 *rec = reinterpret_cast<float4 *>(row);
             rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opacity[g]);
@@ -378,8 +374,10 @@ __device__ __forceinline__ float gauss_exp(RecPtr rec, float px, float py, float
         const float t3 = rec[kRecCov + 2] * dz;
         return __builtin_amdgcn_exp2f(fmaf(dx, t1, fmaf(dy, t2, dz * t3)));
     }
-    const float q = fmaf(rec[kRecCov + 2] * dz, dz, fmaf(rec[kRecCov + 1] * dy, dy, (rec[kRecCov] * dx) * dx));
-    const float r = fmaf(rec[kRecCov + 5] * dx, dz, fmaf(rec[kRecCov + 4] * dy, dz, (rec[kRecCov + 3] * dx) * dy));
+    // The fusion the compiled reference applies to forward.cu:67-68 (gfx950 ISA of oracle/_ref, both variants):
+    // the y-term of each sum is the rounded product, the x- and z-terms are fused onto it.
+    const float q = fmaf(rec[kRecCov + 2] * dz, dz, fmaf(rec[kRecCov] * dx, dx, (rec[kRecCov + 1] * dy) * dy));
+    const float r = fmaf(rec[kRecCov + 5] * dx, dz, fmaf(rec[kRecCov + 3] * dx, dy, (rec[kRecCov + 4] * dy) * dz));
     return gf_exp<EXP>(fmaf(-0.5f, q, -r));
 }
 
@@ -404,8 +402,8 @@ __device__ __forceinline__ f32x2 gauss_exp_pair(RecPtr rec, f32x2 px, f32x2 py, 
         e.y = __builtin_amdgcn_exp2f(p2.y);
         return e;
     }
-    const f32x2 q = fma2(rec[kRecCov + 2] * dz, dz, fma2(rec[kRecCov + 1] * dy, dy, (rec[kRecCov] * dx) * dx));
-    const f32x2 r = fma2(rec[kRecCov + 5] * dx, dz, fma2(rec[kRecCov + 4] * dy, dz, (rec[kRecCov + 3] * dx) * dy));
+    const f32x2 q = fma2(rec[kRecCov + 2] * dz, dz, fma2(rec[kRecCov] * dx, dx, (rec[kRecCov + 1] * dy) * dy));
+    const f32x2 r = fma2(rec[kRecCov + 5] * dx, dz, fma2(rec[kRecCov + 3] * dx, dy, (rec[kRecCov + 4] * dy) * dz));
     const f32x2 power = fma2((f32x2)(-0.5f), q, -r);
     if (EXP == kExpLibm) {
         e.x = expf(power.x);
@@ -923,17 +921,30 @@ static void launch_render(bool dense_candidate, const RenderArgs &r, hipStream_t
     }
 }
 
+// exp flavour of a call: GF_LIBM_EXP > GF_COMP_EXP > GF_FAST_EXP > the variant's default -- the prescaled
+// v_exp_f32 for the base splat; for the prob variant the compensated natural-log form, whose quadratic form is
+// evaluated in the reference's own order (the Prob config's form cancels ~1e3 -> ~1e0, where the prescaled
+// coefficients are 1e-4 away from the reference's density; measured against oracle/_ref)
+static int exp_flavour(int variant, int flags)
+{
+    if (flags & GF_LIBM_EXP) return kExpLibm;
+    if (flags & GF_COMP_EXP) return kExpComp;
+    if (flags & GF_FAST_EXP) return kExpFast;
+    return variant == GF_SPLAT_PROB ? kExpComp : kExpFast;
+}
+
 template <int VARIANT>
 static void launch_render_exp(int flags, bool dense_candidate, const RenderArgs &r, hipStream_t stream)
 {
+    const int ex = exp_flavour(VARIANT, flags);
     if (r.out_labels) {
-        if (flags & GF_LIBM_EXP) launch_render<VARIANT, kExpLibm, true>(dense_candidate, r, stream);
-        else if (flags & GF_COMP_EXP) launch_render<VARIANT, kExpComp, true>(dense_candidate, r, stream);
+        if (ex == kExpLibm) launch_render<VARIANT, kExpLibm, true>(dense_candidate, r, stream);
+        else if (ex == kExpComp) launch_render<VARIANT, kExpComp, true>(dense_candidate, r, stream);
         else launch_render<VARIANT, kExpFast, true>(dense_candidate, r, stream);
         return;
     }
-    if (flags & GF_LIBM_EXP) launch_render<VARIANT, kExpLibm, false>(dense_candidate, r, stream);
-    else if (flags & GF_COMP_EXP) launch_render<VARIANT, kExpComp, false>(dense_candidate, r, stream);
+    if (ex == kExpLibm) launch_render<VARIANT, kExpLibm, false>(dense_candidate, r, stream);
+    else if (ex == kExpComp) launch_render<VARIANT, kExpComp, false>(dense_candidate, r, stream);
     else launch_render<VARIANT, kExpFast, false>(dense_candidate, r, stream);
 }
 
@@ -1004,7 +1015,8 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.nwords = ws.nwords; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
     const int prep_waves = P >= 65536 ? 4 : 1;
     pa.variant = variant; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = verify ? 1 : 0;
-    pa.prescale = (flags & (GF_LIBM_EXP | GF_COMP_EXP)) ? 0 : 1;
+    pa.prescale = exp_flavour(variant, flags) == kExpFast ? 1 : 0;
+    pa.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
     const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +

@@ -30,11 +30,13 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes):
-    """Grow-only per-device scratch for the sorted backward (tap ids + counters)."""
-    ws = _workspaces.get(device)
+    """Grow-only scratch for the sorted backward (tap ids + counters), one per (device, stream): the kernels
+    run on torch's current stream and two streams must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 

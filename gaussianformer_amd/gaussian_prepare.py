@@ -36,10 +36,12 @@ def gaussian_prepare(means3D, scales, rotations, pc_min, grid_size, scale_multip
     cov = torch.empty((P, 3, 3) if full_cov else (P, 6), dtype=f32, device=dev)
     import ctypes
     pc = (ctypes.c_float * 3)(*[float(v) for v in pc_min])
-    rc = lib.gf_gaussian_prepare(P, H, W, D, ctypes.cast(pc, ctypes.c_void_p), float(grid_size), float(scale_multiplier),
-                                 int(radii_mode), int(radii_min), _lib.ptr(means3D), _lib.ptr(scales), _lib.ptr(rotations),
-                                 _lib.ptr(means_int), _lib.ptr(radii), None if full_cov else _lib.ptr(cov),
-                                 _lib.ptr(cov) if full_cov else None, _lib.ptr(status), _lib.current_stream(dev))
+    with torch.cuda.device(dev):
+        rc = lib.gf_gaussian_prepare(P, H, W, D, ctypes.cast(pc, ctypes.c_void_p), float(grid_size),
+                                     float(scale_multiplier), int(radii_mode), int(radii_min), _lib.ptr(means3D),
+                                     _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(means_int), _lib.ptr(radii),
+                                     None if full_cov else _lib.ptr(cov), _lib.ptr(cov) if full_cov else None,
+                                     _lib.ptr(status), _lib.current_stream(dev))
     _lib.check(rc, "gf_gaussian_prepare")
     return means_int, radii, cov
 
@@ -57,10 +59,11 @@ class _CovInverse(torch.autograd.Function):
         cov = torch.empty((P, 6) if packed else (P, 3, 3), dtype=f32, device=s.device)
         import ctypes
         pc = (ctypes.c_float * 3)(0.0, 0.0, 0.0)
-        rc = lib.gf_gaussian_prepare(P, 1, 1, 1, ctypes.cast(pc, ctypes.c_void_p), 1.0, 1.0, _lib.GF_RADII_SCALAR, 1,
-                                     None, _lib.ptr(s), _lib.ptr(q), None, None,
-                                     _lib.ptr(cov) if packed else None, None if packed else _lib.ptr(cov), None,
-                                     _lib.current_stream(s.device))
+        with torch.cuda.device(s.device):
+            rc = lib.gf_gaussian_prepare(P, 1, 1, 1, ctypes.cast(pc, ctypes.c_void_p), 1.0, 1.0, _lib.GF_RADII_SCALAR, 1,
+                                         None, _lib.ptr(s), _lib.ptr(q), None, None,
+                                         _lib.ptr(cov) if packed else None, None if packed else _lib.ptr(cov), None,
+                                         _lib.current_stream(s.device))
         _lib.check(rc, "gf_gaussian_prepare")
         ctx.save_for_backward(s, q)
         ctx.packed = packed
@@ -73,8 +76,9 @@ class _CovInverse(torch.autograd.Function):
         g = _c(cov_grad)
         P = s.shape[0]
         sg, qg = torch.empty_like(s), torch.empty_like(q)
-        rc = lib.gf_gaussian_prepare_backward(P, 0 if ctx.packed else 1, _lib.ptr(s), _lib.ptr(q), _lib.ptr(g),
-                                              _lib.ptr(sg), _lib.ptr(qg), _lib.current_stream(s.device))
+        with torch.cuda.device(s.device):
+            rc = lib.gf_gaussian_prepare_backward(P, 0 if ctx.packed else 1, _lib.ptr(s), _lib.ptr(q), _lib.ptr(g),
+                                                  _lib.ptr(sg), _lib.ptr(qg), _lib.current_stream(s.device))
         _lib.check(rc, "gf_gaussian_prepare_backward")
         return sg, qg, None
 
@@ -99,8 +103,9 @@ class _GaussianPrepare(torch.autograd.Function):
         lib = _lib.load()
         g = _c(cov_grad)
         sg, qg = torch.empty_like(s), torch.empty_like(q)
-        rc = lib.gf_gaussian_prepare_backward(s.shape[0], 0, _lib.ptr(s), _lib.ptr(q), _lib.ptr(g), _lib.ptr(sg),
-                                              _lib.ptr(qg), _lib.current_stream(s.device))
+        with torch.cuda.device(s.device):
+            rc = lib.gf_gaussian_prepare_backward(s.shape[0], 0, _lib.ptr(s), _lib.ptr(q), _lib.ptr(g), _lib.ptr(sg),
+                                                  _lib.ptr(qg), _lib.current_stream(s.device))
         _lib.check(rc, "gf_gaussian_prepare_backward")
         return (None, sg, qg) + (None,) * 9
 

@@ -18,12 +18,14 @@ _C18 = _lib.GF_NUM_CHANNELS
 
 
 class _Workspace:
-    """Per-device scratch reused across calls (stream-ordered, like any torch temp)."""
+    """Scratch reused across calls, one grow-only buffer per (device, stream): the kernels of a call run on torch's
+    current stream, so two calls on different streams must not share records / bitmask / verdict words.  A buffer
+    is allocated while its stream is current, so the caching allocator frees it in that stream's order."""
     _cache = {}
 
     @classmethod
     def get(cls, device, nbytes):
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = cls._cache.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -142,7 +144,11 @@ class SplatForwardPlan:
     def run(self, stream=None):
         if stream is None:
             stream = _lib.current_stream(self.device)
-        rc = self.lib.gf_splat_forward(*self.args, stream)
+        if torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):   # the launch goes to the tensors' device, not the current one
+                rc = self.lib.gf_splat_forward(*self.args, stream)
+        else:
+            rc = self.lib.gf_splat_forward(*self.args, stream)
         if rc:
             _lib.check(rc, "gf_splat_forward")
         return self.logits
@@ -183,8 +189,14 @@ def splat_backward(variant, pts, points_int, means3D, means3D_int, opacities, se
     ``(logits, bin_logits, density, probability)`` for the prob variant.
     Returns ``(means3D_grad, opacity_grad, semantics_grad, cov3D_grad)``."""
     lib = _lib.load()
+    _lib.require_gpu(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D, logits_grad)
     dev = pts.device
-    f32 = torch.float32
+    f32, i32 = torch.float32, torch.int32
+    # the same coercions as the forward (the reference calls .contiguous().data<float>() on every backward
+    # argument, local_aggregate.cu:116-127): autograd saves the caller's tensors, which may be strided views
+    # or another dtype
+    pts, means3D, opacities, semantics, cov3D = (_contig(t, f32) for t in (pts, means3D, opacities, semantics, cov3D))
+    points_int, means3D_int, radii = (_contig(t, i32) for t in (points_int, means3D_int, radii))
     N, P, C = pts.shape[0], means3D.shape[0], semantics.shape[1]
     per_axis = int(radii.dim() == 2)
     logits_grad = _contig(logits_grad, f32)
@@ -295,16 +307,28 @@ class _AggregatorBase(nn.Module):
         # model/head/localagg/local_aggregate/__init__.py:137-141
         points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
         means3D_int = ((means3D.detach() - self.pc_min) / self.grid_size).to(torch.int)
+        self._violations = None
         if self.check_inputs:
-            # the reference asserts these on every call (8 host syncs, :138-142); here they
-            # are opt-in so the default path never synchronises.
-            assert points_int.min() >= 0 and points_int[:, 0].max() < self.H and points_int[:, 1].max() < self.W \
-                and points_int[:, 2].max() < self.D
-            assert means3D_int.min() >= 0 and means3D_int[:, 0].max() < self.H \
-                and means3D_int[:, 1].max() < self.W and means3D_int[:, 2].max() < self.D
+            # the reference's range asserts (:138-140), evaluated on the device and read back ONCE per call by
+            # _raise_on_violation (the reference synchronises eight times here)
+            hi = points_int.new_tensor([self.H, self.W, self.D])
+            self._violations = torch.stack([
+                (points_int < 0).any() | (points_int >= hi).any(),
+                (means3D_int < 0).any() | (means3D_int >= hi).any()])
         return pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D
 
     _radii_mode = _lib.GF_RADII_SCALAR
+
+    def _raise_on_violation(self, radii):
+        """One host read for the three range conditions the reference asserts one by one
+        (local_aggregate/__init__.py:138,140,142): same AssertionError, one synchronisation."""
+        if not self.check_inputs:
+            return
+        bad = torch.cat([self._violations, (radii < 1).any().reshape(1)]).tolist()
+        self._violations = None
+        assert not bad[0], "points outside the voxel grid (points_int out of [0,H)x[0,W)x[0,D))"
+        assert not bad[1], "Gaussian centres outside the voxel grid (means3D_int out of range)"
+        assert not bad[2], "radii must be >= 1"
 
     def forward_from_rotations(self, pts, means3D, opacities, semantics, scales, rotations):
         """Fused entry: takes the Gaussians' ``rotations [1,g,4]`` instead of
@@ -331,9 +355,12 @@ class _AggregatorBase(nn.Module):
 
 class LocalAggregator(_AggregatorBase):
     """Drop-in for ``local_aggregate.LocalAggregator``
-    (model/head/localagg/local_aggregate/__init__.py:108-161)."""
+    (model/head/localagg/local_aggregate/__init__.py:108-161).  ``check_inputs`` (extra keyword, default on)
+    keeps the reference's per-call range asserts -- evaluated on the device, one host read instead of eight;
+    ``check_inputs=False`` makes the call fully asynchronous (boxes of out-of-grid centres are then clipped
+    the way ``getRect`` clips them)."""
 
-    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, inv_softmax=False, check_inputs=False):
+    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, inv_softmax=False, check_inputs=True):
         super().__init__()
         self.scale_multiplier = scale_multiplier
         self.H = H
@@ -352,15 +379,12 @@ class LocalAggregator(_AggregatorBase):
         pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D = self._prepare(
             pts, means3D, opacities, semantics, scales, cov3D)
         radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
-        if self.check_inputs:
-            assert radii.min() >= 1
-        cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
+        self._raise_on_violation(radii)
+        cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]   # (xx, yy, zz, xy, yz, xz) of the 3x3, :143
         logits = _LocalAggregate.apply(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
                                        self.H, self.W, self.D)
-        if not self.inv_softmax:
-            return logits  # n, c
-        else:
-            assert False  # unreachable in the reference as well (:158-161)
+        assert not self.inv_softmax, "inv_softmax=True is an `assert False` in the reference too (:158-161)"
+        return logits
 
 
 class LocalAggregatorProb(_AggregatorBase):
@@ -369,7 +393,7 @@ class LocalAggregatorProb(_AggregatorBase):
     selects ``local_aggregate_prob_fast`` behaviour (…_prob_fast/__init__.py:151)."""
     per_axis_radii = False
 
-    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, radii_min=1, check_inputs=False):
+    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, radii_min=1, check_inputs=True):
         super().__init__()
         self.scale_multiplier = scale_multiplier
         self.H = H
@@ -396,12 +420,10 @@ class LocalAggregatorProb(_AggregatorBase):
         else:
             radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
         radii = radii.clamp(min=self.radii_min)
-        if self.check_inputs:
-            assert radii.min() >= 1
+        self._raise_on_violation(radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
-        logits, bin_logits, density = _LocalAggregateProb.apply(
-            pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D, self.H, self.W, self.D)
-        return logits, bin_logits, density  # n, c; n; n
+        return _LocalAggregateProb.apply(pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D,
+                                         self.H, self.W, self.D)
 
     @torch.no_grad()
     def forward_pieces(self, pts, means3D, opas, semantics, scales, cov3D):
@@ -415,6 +437,7 @@ class LocalAggregatorProb(_AggregatorBase):
         else:
             radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
         radii = radii.clamp(min=self.radii_min)
+        self._raise_on_violation(radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
         numerator, bin_logits, density, probability, _ = splat_forward(
             _lib.GF_SPLAT_PROB, pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D,

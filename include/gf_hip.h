@@ -41,16 +41,23 @@ extern "C" {
 #define GF_PTS_AUTO 0          /* verify on device whether pts is the dense voxel-centre grid */
 #define GF_PTS_ASSUME_DENSE 1  /* caller guarantees point n lies in voxel n (N == H*W*D) */
 #define GF_PTS_GENERAL 2       /* always take the arbitrary-points path */
-/* exp() flavour.  Default: the prep kernel pre-multiplies the quadratic form by log2(e) (fp64,
- * rounded once) and the render kernel issues a bare v_exp_f32 -- measured max error vs the
- * fp32 oracle 3.7e-6 at gs25600 (2.9e-6 for the two alternatives), tolerance 1e-4. */
-#define GF_FAST_EXP 4          /* (default behaviour; kept for ABI compatibility) */
+/* exp() flavour (forward).  GF_FAST_EXP: the prep kernel pre-multiplies the quadratic form by log2(e) (fp64,
+ * rounded once) and the render kernel issues a bare v_exp_f32 -- measured max error vs the reference 3.7e-6 at
+ * gs25600 (2.9e-6 for the two alternatives), tolerance 1e-4.  With none of the three flags the base variant uses
+ * GF_FAST_EXP and the prob variant GF_COMP_EXP: the Prob config's quadratic form cancels ~1e3 -> ~1e0, and only the
+ * natural-log form, evaluated in the reference's own operation order, stays within 1e-4 of the reference there. */
+#define GF_FAST_EXP 4          /* prescaled form + bare v_exp_f32 (default of the base variant) */
 #define GF_LIBM_EXP 8          /* natural-log form + ocml expf (13 VALU per exp) */
 #define GF_COMP_EXP 16         /* natural-log form + v_exp_f32 with a compensated argument (<= 3 ulp) */
 /* prob variant, forward only: `logits` receives the un-normalised numerator sum_g semantics_g * prob_g instead of
  * numerator / probability (localagg_prob/src/forward.cu:92-98 is left to the caller).  For Gaussian-sharded inference:
  * numerators, probability and density add up over shards, 1 - bin_logits multiplies. */
 #define GF_PROB_NUMERATOR 32
+/* prob variant, forward and backward: evaluate det(Sigma^-1) (localagg_prob/src/forward.cu:77, backward.cu:78) in
+ * fp64 instead of the reference's fp32 expression.  The default reproduces the reference's arithmetic (and its
+ * cancellation noise on ill-conditioned Gaussians, including the NaN of a determinant that rounds negative); this
+ * flag trades that parity for the correctly rounded value.  Pass the same flag to forward and backward. */
+#define GF_PROB_EXACT_DET 64
 
 int gf_abi_version(void);
 const char *gf_last_error(void);

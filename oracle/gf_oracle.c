@@ -6,18 +6,21 @@
  * only as the checker / reported CPU baseline.  The product path (gaussianformer_amd/)
  * never imports, links or executes this file.
  *
- * PARITY UNPINNED BY THE REFERENCE: huang-yh/GaussianFormer ships no tests, golden
- * vectors or CPU implementation for this path and its CUDA
- * extensions cannot be built in this image (no nvcc, no GPU).  This file is therefore a
- * line-by-line restatement of the reference CUDA kernels in plain C, pinned instead by
- * an independent dense fp64 formulation with autograd (oracle/dense_ref.py,
- * tests/test_oracle_*.py) and by frozen fixtures under tests/golden/.
+ * PINNED BY THE REFERENCE ITSELF: huang-yh/GaussianFormer ships no tests, golden vectors
+ * or CPU implementation for this path, so this line-by-line
+ * restatement of its CUDA kernels is checked against the reference's own kernels,
+ * compiled for gfx950 from the sources where they lie (oracle/ref_build.py ->
+ * oracle/_ref) and executed on the GPU: tests/test_ref_parity.py (binning bit-exact,
+ * values, gradients).  The deformable-aggregation part is additionally pinned on the
+ * CPU against outputs of the reference's torch fallback (tests/golden/daf_ref.npz).
+ * An independent dense fp64 formulation with autograd (oracle/dense_ref.py,
+ * tests/test_oracle_*.py) and frozen fixtures under tests/golden/ remain as second pins.
  *
  * Every function cites the reference file:line it follows (paths relative to the
  * reference root).  Arithmetic is fp32 in source order, compiled with
- * -ffp-contract=off so the result is a well-defined IEEE-754 evaluation of the
- * reference expressions (nvcc may contract mul+add into FMA; differences are at the
- * 1e-7 relative level and sit inside the 1e-4 parity tolerance).
+ * -ffp-contract=off so the result is a well-defined IEEE-754 evaluation; the two
+ * expressions whose value depends on FMA contraction (quadratic form, determinant)
+ * spell out the fusion the compiled reference applies (gfo_power / gfo_deter).
  *
  * Conventions shared with the reference:
  *   - grid = (H, W, D); voxel key = x*W*D + y*D + z   (aggregator_impl.cu:79, forward.cu:53)
@@ -118,6 +121,35 @@ static void gfo_free_bins(gfo_bins *b)
     free(b->list);
 }
 
+/* The two fp32 expressions of the reference whose value depends on FMA contraction.  The source reads
+ *     power = c0*dx*dx + c1*dy*dy + c2*dz*dz;  power = -0.5f*power - (c3*dx*dy + c4*dy*dz + c5*dx*dz);
+ *     deter = c0*c1*c2 + 2*c3*c4*c5 - c0*c4*c4 - c1*c5*c5 - c2*c3*c3;
+ * (forward.cu:67-68, localagg_prob/src/forward.cu:77) and both CUDA compilers fuse a*b+c inside an expression
+ * (nvcc --fmad=true and clang -ffp-contract=fast are the defaults; setup.py passes neither flag).  For the Prob
+ * config (scales down to 0.01 m) the determinant cancels by up to twelve orders of magnitude, so WHICH products
+ * are fused decides every digit of the result.  This file is built with -ffp-contract=off and spells out the
+ * fusion the hipcc build of the reference (oracle/_ref) applies -- read off its gfx950 ISA and checked against
+ * its outputs on the GPU in tests/test_ref_parity.py: a sum of three products becomes one rounded product plus
+ * two FMAs (WHICH product is the rounded one differs between the forward and the backward kernel), `a - b*c`
+ * stays an unfused subtraction. */
+static inline float gfo_power(const float *cv, float dx, float dy, float dz)
+{   /* forward kernels (both variants): the y-terms are the rounded products */
+    const float q = fmaf(cv[2] * dz, dz, fmaf(cv[0] * dx, dx, (cv[1] * dy) * dy));
+    const float r = fmaf(cv[5] * dx, dz, fmaf(cv[3] * dx, dy, (cv[4] * dy) * dz));
+    return fmaf(-0.5f, q, -r);
+}
+static inline float gfo_power_bwd(const float *cv, float dx, float dy, float dz)
+{   /* backward kernels: the x-terms are the rounded products */
+    const float q = fmaf(cv[2] * dz, dz, fmaf(cv[1] * dy, dy, (cv[0] * dx) * dx));
+    const float r = fmaf(cv[5] * dx, dz, fmaf(cv[4] * dy, dz, (cv[3] * dx) * dy));
+    return fmaf(-0.5f, q, -r);
+}
+static inline float gfo_deter(const float *cv)
+{
+    const float t = fmaf(cv[0] * cv[1], cv[2], ((2 * cv[3]) * cv[4]) * cv[5]);
+    return ((t - (cv[0] * cv[4]) * cv[4]) - (cv[1] * cv[5]) * cv[5]) - (cv[2] * cv[3]) * cv[3];
+}
+
 /* Splat forward.
  *   variant 0: base   -- FORWARD::renderCUDA, model/head/localagg/src/forward.cu:34-82
  *   variant 1: prob   -- model/head/localagg_prob/src/forward.cu:34-102
@@ -153,17 +185,14 @@ int64_t gfo_splat_forward(int variant, int per_axis, int P, int N, int C, int H,
             const float dx = means3D[3 * (int64_t)g] - px;     /* forward.cu:66 */
             const float dy = means3D[3 * (int64_t)g + 1] - py;
             const float dz = means3D[3 * (int64_t)g + 2] - pz;
-            float power = cv[0] * dx * dx + cv[1] * dy * dy + cv[2] * dz * dz; /* :67 */
-            power = -0.5f * power - (cv[3] * dx * dy + cv[4] * dy * dz + cv[5] * dx * dz); /* :68 */
+            float power = gfo_power(cv, dx, dy, dz); /* :67-68 */
             if (variant == 0) {
                 power = opacity[g] * expf(power); /* :69 */
                 for (int ch = 0; ch < C; ++ch)
                     Cacc[ch] += semantic[(int64_t)C * g + ch] * power; /* :71-74 */
             } else {
                 power = expf(power); /* prob forward.cu:76 */
-                const float deter = cv[0] * cv[1] * cv[2] + 2 * cv[3] * cv[4] * cv[5] -
-                                    cv[0] * cv[4] * cv[4] - cv[1] * cv[5] * cv[5] -
-                                    cv[2] * cv[3] * cv[3]; /* :77 */
+                const float deter = gfo_deter(cv); /* :77 */
                 const float prob = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f) *
                                    power * opacity[g]; /* :78 */
                 for (int ch = 0; ch < C; ++ch)
@@ -243,8 +272,8 @@ int gfo_splat_backward_base(int per_axis, int P, int N, int C, int H, int W, int
             const int p = voxel2pts[voxel];
             if (p < 0) continue; /* backward.cu:66 */
             const float dx = mx - pts[3 * (int64_t)p], dy = my - pts[3 * (int64_t)p + 1], dz = mz - pts[3 * (int64_t)p + 2];
-            float power = c1x * dx * dx + c1y * dy * dy + c1z * dz * dz;
-            power = -0.5f * power - (c2x * dx * dy + c2y * dy * dz + c2z * dx * dz);
+            const float cv_[6] = {c1x, c1y, c1z, c2x, c2y, c2z};
+            float power = gfo_power_bwd(cv_, dx, dy, dz); /* backward.cu:69-70 */
             power = expf(power); /* :71 */
             for (int ch = 0; ch < C; ++ch) {
                 const float g_o = power * out_grad[(int64_t)p * C + ch]; /* :74 */
@@ -312,11 +341,10 @@ int gfo_splat_backward_prob(int per_axis, int P, int N, int C, int H, int W, int
             const int p = voxel2pts[voxel];
             if (p < 0) continue;
             const float dx = mx - pts[3 * (int64_t)p], dy = my - pts[3 * (int64_t)p + 1], dz = mz - pts[3 * (int64_t)p + 2];
-            float power = c1x * dx * dx + c1y * dy * dy + c1z * dz * dz;
-            power = -0.5f * power - (c2x * dx * dy + c2y * dy * dz + c2z * dx * dz);
+            const float cv_[6] = {c1x, c1y, c1z, c2x, c2y, c2z};
+            float power = gfo_power_bwd(cv_, dx, dy, dz); /* backward.cu:69-70 */
             power = expf(power);
-            const float deter = c1x * c1y * c1z + 2 * c2x * c2y * c2z - c1x * c2y * c2y -
-                                c1y * c2z * c2z - c1z * c2x * c2x; /* :78 */
+            const float deter = gfo_deter(cv_); /* :78 */
             const float prob = powf((float)(2 * 3.1415926535), -1.5f) * powf(deter, 0.5f) * power; /* :79 (no opa) */
             float power_grad = 0.f, deter_grad = 0.f, prob_grad = 0.f;
             const float prob_sum = probability[p];

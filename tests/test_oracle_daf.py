@@ -1,6 +1,6 @@
 """Pins the CPU oracle of the deformable aggregation against an independent fp64
 ``grid_sample`` formulation (values and, through autograd, all three gradients), the
-operator's edge rules, and the frozen fixture."""
+operator's edge rules, and the frozen fixture of reference outputs."""
 import os
 
 import numpy as np
@@ -50,10 +50,13 @@ def test_gate_and_multithreading():
 
 
 def test_golden_fixture():
+    """tests/golden/daf.npz holds the REFERENCE's outputs (oracle/_ref run on an MI355X by tools/make_golden.py):
+    the C restatement must reproduce them to fp32 rounding (the gradients are float-atomic sums there)."""
     d = np.load(os.path.join(GOLDEN, "daf.npz"))
+    assert "oracle/_ref" in str(d["producer"])
     ins = {k: d[k] for k in ("mc_ms_feat", "spatial_shape", "scale_start_index", "sampling_location", "weights")}
-    np.testing.assert_allclose(oracle.daf_forward(**ins), d["output"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(oracle.daf_forward(**ins), d["output"], rtol=1e-5, atol=1e-6)
     gf, gl, gw = oracle.daf_backward(*ins.values(), d["grad_output"])
-    np.testing.assert_allclose(gf, d["grad_mc_ms_feat"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(gl, d["grad_sampling_location"], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(gw, d["grad_weights"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gf, d["grad_mc_ms_feat"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(gl, d["grad_sampling_location"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(gw, d["grad_weights"], rtol=1e-5, atol=2e-6)

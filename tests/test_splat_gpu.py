@@ -412,3 +412,85 @@ def test_forward_is_graph_capturable(gpu):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(plan.logits, eager)
+
+
+def test_module_backward_with_strided_and_fp64_inputs(gpu):
+    """Autograd saves the caller's tensors: strided views (``semantics = output[..., 10:]``-style slices,
+    means as an anchor slice) and fp64 inputs must give the gradients of the contiguous fp32 call -- the
+    backward coerces its arguments like the forward does (the reference: ``.contiguous().data<float>()`` on
+    every backward argument, local_aggregate.cu:116-127)."""
+    import torch
+    import local_aggregate
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=33, P=300, H=24, W=20, D=16)
+    agg = local_aggregate.LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)
+    P = si.means3D.shape[0]
+    g = torch.from_numpy(np.random.default_rng(34).standard_normal((si.pts.shape[0], 18)).astype(np.float32)).to(gpu)
+    tt = lambda a: torch.from_numpy(a).to(gpu)
+
+    def run(make):
+        packed = torch.zeros(1, P, 3 + 5 + 18, device=gpu, dtype=make)      # anchor-like row: mean | pad | semantics
+        packed[0, :, :3] = tt(si.means3D).to(make)
+        packed[0, :, 8:] = tt(si.semantics).to(make)
+        packed.requires_grad_(True)
+        opa = tt(si.opacities).to(make)[None].requires_grad_(True)
+        cov = tt(si.cov3D).to(make)[None].requires_grad_(True)
+        means, sem = packed[..., :3], packed[..., 8:]                       # non-contiguous views
+        assert not sem.is_contiguous()
+        logits = agg(tt(si.pts)[None], means, opa, sem, tt(si.scales)[None], cov)
+        logits.backward(g)
+        return logits.detach(), packed.grad.float(), opa.grad.float(), cov.grad.float()
+
+    base = run(torch.float32)
+    # contiguous fp32 reference call
+    m, o, s_, c = (tt(a)[None].requires_grad_(True) for a in (si.means3D, si.opacities, si.semantics, si.cov3D))
+    ref_logits = agg(tt(si.pts)[None], m, o, s_, tt(si.scales)[None], c)
+    ref_logits.backward(g)
+    assert torch.equal(base[0], ref_logits.detach())
+    # gradients of boxes split over several waves are combined with float atomics: equal up to summation order
+    close = lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+    assert close(base[1][0, :, :3], m.grad[0]) and close(base[1][0, :, 8:], s_.grad[0])
+    assert float(base[1][0, :, 3:8].abs().max()) == 0.0
+    assert close(base[2], o.grad) and close(base[3], c.grad)
+    dbl = run(torch.float64)
+    for a, b in zip(dbl[1:], base[1:]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+
+
+def test_backward_without_points(gpu):
+    """N == 0 with P > 0: zero gradients, no fault (the kernels read row 0 of pts / logits_grad unconditionally)."""
+    import torch
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import splat_backward
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=35, P=50, H=12, W=12, D=8)
+    pi, mi, radii, cov6 = prep(si)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in
+         (si.pts[:0], pi[:0], si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
+    grads = splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, torch.zeros(0, 18, device=gpu))
+    torch.cuda.synchronize()
+    assert all(float(x.abs().max()) == 0.0 for x in grads)
+
+
+def test_module_range_asserts_like_the_reference(gpu):
+    """The reference asserts in-grid points / centres and radii >= 1 on every call
+    (local_aggregate/__init__.py:138-142); the drop-in keeps that by default."""
+    import torch
+    import local_aggregate
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=36, P=40, H=12, W=12, D=8)
+    agg = local_aggregate.LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)
+    tt = lambda a: torch.from_numpy(a).to(gpu)[None]
+    args = [tt(si.pts), tt(si.means3D), tt(si.opacities), tt(si.semantics), tt(si.scales), tt(si.cov3D)]
+    agg(*args)
+    bad = [a.clone() for a in args]
+    bad[1][0, 3, 0] += 100.0                      # a centre outside the grid
+    with pytest.raises(AssertionError):
+        agg(*bad)
+    bad = [a.clone() for a in args]
+    bad[0][0, 5, 2] -= 50.0                       # a query point outside the grid
+    with pytest.raises(AssertionError):
+        agg(*bad)
+    quiet = local_aggregate.LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size,
+                                            check_inputs=False).to(gpu)
+    bad = [a.clone() for a in args]
+    bad[1][0, 3, 0] += 100.0
+    quiet(*bad)                                    # opt-out: boxes are clipped like getRect
+    torch.cuda.synchronize()
