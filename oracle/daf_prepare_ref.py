@@ -13,6 +13,36 @@ import torch
 DEPTH_EPS = 1e-5  # :277, :281
 
 
+def safe_sigmoid(t):
+    """model/utils/safe_ops.py:7-9"""
+    return torch.sigmoid(torch.clamp(t, -9.21, 9.21))
+
+
+def key_points(anchor, instance_feature, fix_scale, learnable_fc_weight, learnable_fc_bias, pc_range, scale_range,
+               learnable_fixed_scale=1.0):
+    """SparseGaussian3DKeyPointsGenerator.forward (deformable_module.py:51-90) with the default sigmoid activations:
+    ``[bs, A, 7 + k, 3]`` key points = Gaussian-frame offsets (fixed + learned) * scale, rotated by R(q)^T^T, plus the
+    centre.  ``anchor [bs,A,>=10]`` is (xyz, scale, quaternion, ...) before activation.  Pinned through
+    tests/golden/caller_dfa.npz (the sampling locations the reference caller handed to the op)."""
+    from .prepare_ref import rotation_matrix
+    bs, A = anchor.shape[:2]
+    fix = anchor.new_tensor(fix_scale)
+    scale = fix[None, None].tile([bs, A, 1, 1])
+    if learnable_fc_weight is not None:
+        k = learnable_fc_weight.shape[0] // 3
+        learned = safe_sigmoid(torch.nn.functional.linear(instance_feature, learnable_fc_weight, learnable_fc_bias)
+                               .reshape(bs, A, k, 3)) - 0.5
+        scale = torch.cat([scale, learned * learnable_fixed_scale], dim=-2)
+    gs = scale_range[0] + (scale_range[1] - scale_range[0]) * safe_sigmoid(anchor[..., None, 3:6])
+    kp = scale * gs
+    rot = rotation_matrix(anchor[..., 6:10]).transpose(-1, -2)           # :72-73
+    kp = torch.matmul(rot[:, :, None], kp[..., None]).squeeze(-1)
+    xyz = safe_sigmoid(anchor[..., :3])
+    lo = anchor.new_tensor(pc_range[:3])
+    hi = anchor.new_tensor(pc_range[3:])
+    return kp + (xyz * (hi - lo) + lo).unsqueeze(2)
+
+
 def project_points(key_points, projection_mat, image_wh=None):
     """key_points [b, A, p, 3], projection_mat [b, cams, 4, 4], image_wh [b, cams, 2] | None
     -> (uv [b, cams, A, p, 2], visible [b, cams, A, p])."""
