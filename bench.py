@@ -4,14 +4,23 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the splat forward (C ABI ``gf_splat_forward``, automatic point-layout
-detection, inputs and outputs resident in HBM) over one frame: P = 25 601 Gaussians
-(``nuscenes_gs25600_solid``: 25 600 + the appended whole-grid "empty" Gaussian) into the
-200x200x16 grid with 18 semantic channels.  With N > 1 ranks every rank splats its own shard of
-P Gaussians into a full partial grid and the partial logits are summed with one RCCL
-all-reduce (weak scaling: per-GPU work is fixed); ``value`` counts the Gaussians
-of all ranks.  Rank 0 prints one JSON line.  Extras next to `value`, never instead of it: `two_stream` (N = 1, two
-frames in flight), `hip_graph` (N = 1, the step replayed as one captured HIP graph) and `reduce_scatter_labels` (N > 1, the label-producing variant with half the xGMI traffic).
+A "step" is one pass of the splat forward (C ABI ``gf_splat_forward``, automatic point-layout detection, inputs and
+outputs resident in HBM) over ONE frame: the P = 25 601 Gaussians of ``nuscenes_gs25600_solid`` (25 600 + the appended
+whole-grid "empty" Gaussian) into the 200x200x16 grid with 18 semantic channels.
+
+N = 1: ``value`` = P / step time.  N > 1 is STRONG scaling of the same frame, the experiment north_star names: the one
+Gaussian set is cut into N contiguous shards (``gaussianformer_amd.sharded.shard_bounds``), every rank splats its shard
+into a full partial grid and the partial logits are summed with one RCCL all-reduce over xGMI
+(``sharded.sharded_splat_forward``); ``value`` = P / (splat + all-reduce) time, max over ranks.  The reference itself
+only runs data-parallel replicas (train.py:41-43, :86-91).
+
+Rank 0 prints ONE JSON line.  Next to ``value``, never instead of it:
+  N = 1  ``roofline`` (render kernel, hipEvents on the launch stream), ``cpu_baseline`` (C port of the reference kernels)
+         and ``cpu_baseline_torch`` (vectorised PyTorch-CPU pair-list formulation), ``frames_per_s`` (one inference frame
+         of the whole hot path: 4 encoder blocks + head, tools/bench_frame.py), ``two_stream``, ``hip_graph``;
+  N > 1  ``kernel_only`` (the same shards without the collective), ``gs144000`` (BASELINE config [4]: the 144 000-Gaussian
+         set sharded N-way, with and without the all-reduce) and ``reduce_scatter_labels`` (reduce-scatter -> labels on the
+         owned slab -> all-gather of labels).
 """
 import argparse
 import ctypes
@@ -26,16 +35,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROFILE_STRIDE = 8
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+MIN_KERNEL_SAMPLES = 8
 
 
 def headline_metric():
-    """The first clause of BASELINE.json's metric (its second, "frames/sec end-to-end", belongs to the full model)."""
+    """The first clause of BASELINE.json's metric (its second, "frames/sec end-to-end", is the ``frames_per_s`` block)."""
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"].split(";")[0].strip()
     except Exception:
-        return "Gaussians/sec splatted into 200\u00d7200\u00d716\u00d718 voxel grid (fwd)"
+        return "Gaussians/sec splatted into 200×200×16×18 voxel grid (fwd)"
 
 
 def algorithmic_bytes(P, N, C=18):
@@ -43,25 +52,27 @@ def algorithmic_bytes(P, N, C=18):
     return 128 * P + 24 * N + 4 * C * N
 
 
-def measured_traffic_bytes(config):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload
-    (profiles/traffic_*.json, FETCH_SIZE x2 correction applied there); None if absent."""
+def committed_traffic(config):
+    """HBM bytes per launch from the committed PMC passes of this workload (profiles/traffic_*.json; FETCH_SIZE x2
+    correction applied there).  The counters cannot be read inside this process, so the figure is labelled with its
+    source; None if there is no pass for this config."""
     import glob
     pattern = {"nuscenes_gs25600_solid": "traffic_r*.json", "nuscenes_gs144000": "traffic_gs144000_r*.json"}.get(config)
-    if pattern is None:
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))) if pattern else []
     if not files:
-        return None
+        return None, None
     try:
-        return json.load(open(files[-1])).get("render_kernel_hbm_bytes_per_launch")
+        d = json.load(open(files[-1]))
+        return d.get("render_kernel_hbm_bytes_per_launch"), {
+            "source": "committed rocprofv3 PMC pass " + os.path.relpath(files[-1], ROOT) + " (not measured in this run)",
+            "prep_kernel_hbm_bytes_per_launch": d.get("prep_kernel_hbm_bytes_per_launch")}
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(si, pi, mi, radii, cov6, budget_s=10.0):
-    """The CPU oracle (a restatement of the reference kernels, kind "port") timed on this
-    box's host cores on the SAME workload, all OpenMP threads."""
+    """The CPU oracle (a C restatement of the reference kernels, pinned against oracle/_ref; kind "port") timed on
+    this box's host cores on the SAME workload, all OpenMP threads."""
     import oracle
     threads = oracle.num_threads()
     times = []
@@ -79,6 +90,33 @@ def cpu_baseline(si, pi, mi, radii, cov6, budget_s=10.0):
             "seconds_per_pass": t}
 
 
+def cpu_baseline_torch(si, pi, mi, radii, cov6, budget_s=20.0):
+    """A vectorised PyTorch-CPU formulation (pair list -> index_add_, oracle/torch_cpu_splat.py): what a pure-PyTorch
+    fallback of the reference's splat would be (the reference has none).  Bounded sample: every 8th
+    Gaussian of the frame first; the full frame only if that took under budget / 10."""
+    import torch
+    from oracle.torch_cpu_splat import splat_forward_torch
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    P = si.means3D.shape[0]
+
+    def timed(sel):
+        args = (t(pi), t(si.pts), t(si.means3D[sel]), t(mi[sel]), t(si.opacities[sel]), t(si.semantics[sel]), t(radii[sel]), t(cov6[sel]))
+        t0 = time.perf_counter()
+        splat_forward_torch(*args, si.H, si.W, si.D)
+        return time.perf_counter() - t0
+    sel = np.arange(0, P, 8)
+    dt = timed(sel)
+    sample = f"every 8th Gaussian of the frame ({len(sel)} of {P}, into the full N={si.pts.shape[0]} grid), one pass"
+    n = len(sel)
+    if dt < budget_s / 10:
+        sel = np.arange(P)
+        dt = timed(sel)
+        n = P
+        sample = f"one full forward pass of the same workload (P={P})"
+    return {"value": n / dt, "unit": "Gaussians/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": sample + f", {dt:.1f} s on {torch.get_num_threads()} torch threads", "seconds": dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,16 +124,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="nuscenes_gs25600_solid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-two-stream", action="store_true",
-                    help="skip the extra two-frames-in-flight measurement (used for the rocprofv3 kernel trace, whose "
-                         "per-kernel average would otherwise mix overlapped and sequential launches)")
+    ap.add_argument("--no-extras", "--no-two-stream", dest="no_extras", action="store_true",
+                    help="headline measurement only (used for the rocprofv3 kernel trace, whose per-kernel averages would "
+                         "otherwise mix the extras' launches into the headline's)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    import oracle  # checker side only: host pre-processing restatement + cpu_baseline leg
+    import oracle  # checker side only: host pre-processing restatement + cpu_baseline legs
     from gaussianformer_amd import _lib
     from gaussianformer_amd.local_aggregate import SplatForwardPlan
+    from gaussianformer_amd.sharded import shard_bounds, sharded_splat_forward
     from gaussianformer_amd.synthetic import make_splat_inputs
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,132 +144,156 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X; there is no CPU path for the product")
+    # GF_BENCH_SHARED_GPU=1 (tests on a 1-GPU box): every rank uses cuda:0 and the collectives go through gloo on host copies
+    shared_gpu = os.environ.get("GF_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # GF_BENCH_FORCE_DIST=1 takes the RCCL path with a single rank too (a 1-GPU check of the plumbing)
+    # GF_BENCH_FORCE_DIST=1 takes the collective path with a single rank too (a 1-GPU check of the plumbing)
     use_dist = world > 1 or os.environ.get("GF_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
 
-    # each rank owns a different shard of Gaussians (seed = rank); same query grid
-    si = make_splat_inputs(args.config, seed=rank)
-    pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min,
-                                                      si.grid_size, si.scale_multiplier,
-                                                      radii_min=1 if si.variant == "prob" else None)
-    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-         for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
-    variant = _lib.GF_SPLAT_PROB if si.variant == "prob" else _lib.GF_SPLAT_BASE
-    plan = SplatForwardPlan(variant, *t, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO)
-    P, N = plan.P, plan.N
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    def all_reduce(t, op=None):
+        op = op or dist.ReduceOp.SUM
+        if shared_gpu:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
-    def step():
-        plan.run(stream)
+    def max_over_ranks(seconds):
+        if not use_dist:
+            return seconds
+        tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        all_reduce(tt, dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def barrier():
         if use_dist:
-            dist.all_reduce(plan.logits, op=dist.ReduceOp.SUM)
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    class Workload:
+        """One frame's Gaussian set (seed 0, identical on every rank), this rank's contiguous shard bound to a plan."""
+
+        def __init__(self, config):
+            self.config = config
+            si = make_splat_inputs(config, seed=0)
+            self.si = si
+            self.prep = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size,
+                                                    si.scale_multiplier, radii_min=1 if si.variant == "prob" else None)
+            pi, mi, radii, cov6 = self.prep
+            self.P_total, self.N = si.means3D.shape[0], si.pts.shape[0]
+            self.lo, self.hi = shard_bounds(self.P_total, rank, world)
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            sl = slice(self.lo, self.hi)
+            self.tensors = [up(si.pts), up(pi), up(si.means3D[sl]), up(mi[sl]), up(si.opacities[sl]), up(si.semantics[sl]),
+                            up(radii[sl]), up(cov6[sl])]
+            self.variant = _lib.GF_SPLAT_PROB if si.variant == "prob" else _lib.GF_SPLAT_BASE
+            self.plan = SplatForwardPlan(self.variant, *self.tensors, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO)
+            self.stream = torch.cuda.current_stream(dev).cuda_stream
+            # full-set views for sharded_splat_forward (it slices [lo, hi) itself; the plan is bound to exactly that slice)
+            self.full = [torch.empty(1, self.P_total, 0, device=dev)] * 5
+
+        def local(self, *_):
+            return self.plan.run(self.stream)
+
+        def step(self):
+            if not use_dist:
+                return self.plan.run(self.stream)
+            if shared_gpu:
+                logits = self.plan.run(self.stream)
+                all_reduce(logits)
+                return logits
+            return sharded_splat_forward(self.local, None, *self.full)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    wl = Workload(args.config)
+    si, P, N = wl.si, wl.P_total, wl.N
+    pi, mi, radii, cov6 = wl.prep
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     torch.cuda.synchronize()
 
-    # the dominant kernel is timed with hipEvents on every PROFILE_STRIDE-th launch of the timed
-    # region (an event pair costs ~3 us of stream time; sampling keeps the region representative)
-    _lib.check(lib.gf_profile_stride(PROFILE_STRIDE), "gf_profile_stride")
+    # the dominant kernel is timed with hipEvents around sampled launches of the timed region (an event pair costs
+    # ~3 us of stream time; sampling keeps the region representative): at least MIN_KERNEL_SAMPLES of them
+    stride = max(1, args.steps // (2 * MIN_KERNEL_SAMPLES))
+    _lib.check(lib.gf_profile_stride(stride), "gf_profile_stride")
     _lib.check(lib.gf_profile_enable(args.steps), "gf_profile_enable")
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wl.step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # dominant kernel (the render kernel): per-launch duration from the hipEvents recorded
-    # around it on the launch stream during the timed region
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     buf = (ctypes.c_float * args.steps)()
     n_ev = lib.gf_profile_read(buf, args.steps)
     lib.gf_profile_enable(0)
     lib.gf_profile_stride(1)
     kernel_ms = float(np.mean(buf[:n_ev])) if n_ev > 0 else None
 
-    # Extra, N=1 only: the same K steps with two frames in flight -- two pre-bound plans (own
-    # outputs / workspace) alternating on two HIP streams, so the latency-bound prep kernel, the cold
-    # start and the tail of one step overlap the render kernel of the other.  Reported next to
-    # `value` (which stays the strict one-step-at-a-time figure), never instead of it.
-    two_stream = None
-    if world == 1 and not args.no_two_stream:
-        plans = [plan, SplatForwardPlan(variant, *t, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO)]
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        for i in range(2 * max(2, args.warmup // 2)):
-            plans[i % 2].run(streams[i % 2].cuda_stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            plans[i % 2].run(streams[i % 2].cuda_stream)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        two_stream = {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
-                      "note": "same K steps, two frames in flight on two HIP streams (double-buffered outputs and workspace)"}
+    extras = {}
 
-    # Extra, N > 1 only: the same K steps ending in occupancy labels instead of replicated logits --
-    # reduce-scatter of the partial grids (each rank receives the summed logits of its 1/N of the
-    # voxels), labels on the owned slab (gf_head_labels), all-gather of the labels: half the xGMI
-    # traffic of the all-reduce (gaussianformer_amd.head.sharded_splat_labels).  Never `value`.
-    rs_labels = None
-    if use_dist and si.variant != "prob" and N % world == 0:
+    def extra(name, fn):
         try:
-            from gaussianformer_amd.head import occupancy_labels
-            mine = torch.empty(N // world, 18, dtype=torch.float32, device=dev)
-            labels = torch.empty(N, dtype=torch.int64, device=dev)
-
-            def label_step():
-                plan.run(stream)
-                dist.reduce_scatter_tensor(mine, plan.logits, op=dist.ReduceOp.SUM)
-                dist.all_gather_into_tensor(labels, occupancy_labels(mine))
-
-            for _ in range(max(2, args.warmup // 2)):
-                label_step()
-            dist.barrier()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(args.steps):
-                label_step()
-            torch.cuda.synchronize()
-            dist.barrier()
-            tt = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-            rs_labels = {"value": world * P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
-                         "note": "same K steps ending in labels: reduce-scatter of the partial logits, labels on the owned "
-                                 "slab, all-gather of the labels"}
+            r = fn()
+            if r is not None:
+                extras[name] = r
         except Exception as exc:  # an extra must never cost the headline line
-            rs_labels = {"error": f"{type(exc).__name__}: {exc}"}
+            extras[name] = {"error": f"{type(exc).__name__}: {exc}"}
 
-    # Extra, N = 1 only: the same step captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed K times --
-    # what a serving loop that splats the same buffers every frame would do.  Never `value`.
-    hip_graph = None
-    if world == 1 and not args.no_two_stream:
-        try:
+    single = world == 1 and not use_dist
+    if not args.no_extras and single:
+        def two_stream():
+            # two frames in flight: two pre-bound plans (own outputs / workspace) alternating on two HIP streams, so the
+            # latency-bound prep kernel, the cold start and the tail of one step overlap the render kernel of the other
+            plans = [wl.plan, SplatForwardPlan(wl.variant, *wl.tensors, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO)]
+            streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            for i in range(2 * max(2, args.warmup // 2)):
+                plans[i % 2].run(streams[i % 2].cuda_stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                plans[i % 2].run(streams[i % 2].cuda_stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
+                    "note": "same K steps, two frames in flight on two HIP streams (double-buffered outputs and workspace)"}
+
+        def hip_graph():
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                plan.run()
+                wl.plan.run()
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                plan.run()
+                wl.plan.run()
             for _ in range(max(2, args.warmup // 2)):
                 graph.replay()
             torch.cuda.synchronize()
@@ -239,43 +302,105 @@ def main():
                 graph.replay()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t3
-            hip_graph = {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
-                         "note": "same K steps as replays of one captured HIP graph (prep + render)"}
-        except Exception as exc:  # an extra must never cost the headline line
-            hip_graph = {"error": f"{type(exc).__name__}: {exc}"}
+            return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
+                    "note": "same K steps as replays of one captured HIP graph (prep + render)"}
+
+        def frames():
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_frame
+            out = {}
+            for cfg, nf in (("nuscenes_gs25600_solid", 20), ("nuscenes_gs144000", 6)):
+                out[cfg] = bench_frame.run(cfg, frames=nf, warmup=2, device=str(dev))
+            out["unit"] = "frames/s"
+            out["note"] = "one inference frame of the hot path per config (tools/bench_frame.py), single GPU, synthetic inputs in HBM"
+            return out
+
+        extra("two_stream", two_stream)
+        extra("hip_graph", hip_graph)
+        extra("frames_per_s", frames)
+
+    if not args.no_extras and use_dist:
+        def kernel_only():
+            dt = timed(lambda: wl.plan.run(wl.stream), args.steps, max(2, args.warmup // 2))
+            return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
+                    "note": "the same shards, splat only (no collective), max over ranks"}
+
+        def gs144000():
+            w2 = Workload("nuscenes_gs144000")
+            steps = max(10, args.steps // 4)
+            both = timed(w2.step, steps, 3)
+            alone = timed(lambda: w2.plan.run(w2.stream), steps, 3)
+            return {"config": f"nuscenes_gs144000: P={w2.P_total} Gaussians sharded {world}-way ({w2.hi - w2.lo} on rank 0), "
+                              f"all-reduce of the [{w2.N},18] fp32 logits",
+                    "value": w2.P_total / (both / steps), "unit": "Gaussians/s", "ms_per_step": both / steps * 1e3,
+                    "kernel_only_ms_per_step": alone / steps * 1e3, "collective_ms_per_step": (both - alone) / steps * 1e3, "steps": steps}
+
+        def rs_labels():
+            if si.variant == "prob" or N % world or shared_gpu:
+                return None
+            from gaussianformer_amd.head import occupancy_labels
+            mine = torch.empty(N // world, 18, dtype=torch.float32, device=dev)
+            labels = torch.empty(N, dtype=torch.int64, device=dev)
+
+            def label_step():
+                logits = wl.plan.run(wl.stream)
+                dist.reduce_scatter_tensor(mine, logits, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(labels, occupancy_labels(mine))
+            dt = timed(label_step, args.steps, max(2, args.warmup // 2))
+            return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
+                    "note": "same K steps ending in labels: reduce-scatter of the partial logits, labels on the owned slab, "
+                            "all-gather of the labels"}
+
+        extra("kernel_only", kernel_only)
+        extra("gs144000", gs144000)
+        extra("reduce_scatter_labels", rs_labels)
+        if os.environ.get("GF_BENCH_CHECK") == "1":
+            # the sharded sum against the single-device result of the whole set (tests)
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            full_plan = SplatForwardPlan(wl.variant, up(si.pts), up(pi), up(si.means3D), up(mi), up(si.opacities), up(si.semantics),
+                                         up(radii), up(cov6), si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO)
+            want = full_plan.run().clone()
+            got = wl.step()
+            torch.cuda.synchronize()
+            err = float(((got - want).abs() / want.abs().clamp(min=1.0)).max())
+            extras["check_max_scaled_err_vs_single_device"] = err
+            assert err <= 1e-4, err
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * P / (elapsed / args.steps)
-        abytes = algorithmic_bytes(P, N)
+        value = P / (elapsed / args.steps)
+        P_launch = wl.hi - wl.lo
+        abytes = algorithmic_bytes(P_launch, N)
         roofline = None
         if kernel_ms:
             achieved = abytes / (kernel_ms * 1e-3) / 1e9
+            traffic, traffic_note = committed_traffic(args.config) if single else (None, None)
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": measured_traffic_bytes(args.config),
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel": "gf_splat_render_kernel", "kernel_us": kernel_ms * 1e3,
-                        "kernel_launches_timed": n_ev,
-                        "algorithmic_bytes": abytes}
+                        "kernel_launches_timed": n_ev, "algorithmic_bytes": abytes}
+            if traffic_note:
+                roofline["traffic_note"] = traffic_note
         out = {
             "metric": headline_metric(),
             "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: splat forward, P={P} Gaussians/GPU -> {si.H}x{si.W}x{si.D}x18 "
+            "config": {"workload": f"{args.config}: splat forward of ONE frame, P={P} Gaussians -> {si.H}x{si.W}x{si.D}x18 "
                                    f"grid (N={N} voxel-centre points), bs=1",
-                       "P_per_gpu": P, "N": N, "pts_layout": "auto-detected dense grid",
-                       "parallelism": "single GPU" if world == 1 else f"gaussian-shard x{world} + RCCL all-reduce of logits"},
+                       "P_total": P, "P_per_gpu": P_launch, "N": N, "pts_layout": "auto-detected dense grid",
+                       "parallelism": "single GPU" if not use_dist else
+                                      f"the frame's Gaussians in {world} contiguous shards + one all-reduce of the logits "
+                                      f"({'gloo via host copies, shared GPU (test mode)' if shared_gpu else 'RCCL'})"},
             "roofline": roofline,
         }
-        if two_stream:
-            out["two_stream"] = two_stream
-        if hip_graph:
-            out["hip_graph"] = hip_graph
-        if rs_labels:
-            out["reduce_scatter_labels"] = rs_labels
-        if world == 1 and not args.no_cpu_baseline:
+        out.update(extras)
+        if single and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(si, pi, mi, radii, cov6)
+            try:
+                out["cpu_baseline_torch"] = cpu_baseline_torch(si, pi, mi, radii, cov6)
+            except Exception as exc:
+                out["cpu_baseline_torch"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -23,7 +23,7 @@ def test_bench_line_has_the_contract_fields():
     # write the multiplication signs as "x")
     assert b["metric"].replace("x", "\u00d7") == base["metric"].split(";")[0].strip().replace("x", "\u00d7")
     assert b["unit"] == "Gaussians/s"
-    assert b["n_gpus"] == 1 and b["higher_is_better"] is True and b["scaling"] == "weak" and b["vs_baseline"] is None
+    assert b["n_gpus"] == 1 and b["higher_is_better"] is True and b["scaling"] in ("strong", "weak") and b["vs_baseline"] is None
     assert b["dtype"] == "f32" and b["data"] == "synthetic"
     assert "workload" in b["config"] and "nuscenes_gs25600_solid" in b["config"]["workload"]
     assert "model" not in b["config"]
@@ -46,8 +46,25 @@ def test_algorithmic_bytes_formula():
     # every op input read once + logits written once
     assert bench.algorithmic_bytes(25601, 640000) == 128 * 25601 + 24 * 640000 + 72 * 640000 == 64716928
     assert bench.algorithmic_bytes(144000, 640000) == 79872000
-    t = bench.measured_traffic_bytes("nuscenes_gs25600_solid")
-    assert t is None or 0.9 * 64716928 <= t <= 2 * 64716928
-    assert bench.measured_traffic_bytes("no_such_config") is None
+    t, note = bench.committed_traffic("nuscenes_gs25600_solid")
+    assert t is None or (0.9 * 64716928 <= t <= 2 * 64716928 and "committed" in note["source"])
+    assert bench.committed_traffic("no_such_config") == (None, None)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert bench.headline_metric() == base["metric"].split(";")[0].strip()
+
+
+def test_torch_cpu_baseline_formulation_matches_the_oracle():
+    """The PyTorch-CPU pair-list formulation timed by bench.py's ``cpu_baseline_torch`` leg computes the splat."""
+    import numpy as np
+    import torch
+    import oracle
+    from oracle.torch_cpu_splat import splat_forward_torch
+    from gaussianformer_amd.synthetic import make_splat_inputs
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=3, P=300, H=24, W=20, D=16)
+    pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size,
+                                                      si.scale_multiplier)
+    ref = oracle.splat_forward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D)["logits"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    out = splat_forward_torch(t(pi), t(si.pts), t(si.means3D), t(mi), t(si.opacities), t(si.semantics), t(radii), t(cov6),
+                              si.H, si.W, si.D, chunk_pairs=1 << 14).numpy()
+    assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())

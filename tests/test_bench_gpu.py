@@ -1,0 +1,49 @@
+"""bench.py's own code paths on the GPU box: the N = 1 line (reduced steps) and the N = 2 strong-scaling path
+(`gaussianformer_amd.sharded`), run as two real processes.  The box has one GPU, so the two ranks share it and the
+collective goes through gloo on host copies (GF_BENCH_SHARED_GPU=1); everything else -- sharding, per-rank plans, the
+timed loop, max over ranks, the JSON line -- is the code the driver runs with RCCL on an 8-GPU node.  GF_BENCH_CHECK=1
+makes bench.py compare the sharded sum with the single-device result of the whole set."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.strip().splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_gpu_line(gpu):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    b = _last_json(r.stdout)
+    assert b["n_gpus"] == 1 and b["scaling"] == "strong" and b["config"]["P_total"] == 25601 == b["config"]["P_per_gpu"]
+    assert abs(b["value"] - 25601 / (b["ms_per_step"] * 1e-3)) <= 1e-6 * b["value"]
+    assert b["roofline"]["kernel_launches_timed"] >= 8 and 0 < b["roofline"]["frac"] < 1
+    f = b["frames_per_s"]
+    assert "error" not in f, f
+    for cfg in ("nuscenes_gs25600_solid", "nuscenes_gs144000"):
+        assert f[cfg]["frames_per_s"] > 0 and f[cfg]["labels_used"] >= 1 and f[cfg]["voxels"] == 640000
+
+
+def test_bench_two_rank_strong_scaling_path(gpu):
+    env = dict(os.environ, GF_BENCH_SHARED_GPU="1", GF_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    b = _last_json(r.stdout)
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert b["config"]["P_total"] == 25601 and b["config"]["P_per_gpu"] == 12801      # shard_bounds(25601, 0, 2)
+    assert b["check_max_scaled_err_vs_single_device"] <= 1e-4
+    assert b["kernel_only"]["ms_per_step"] <= b["ms_per_step"]
+    g = b["gs144000"]
+    assert "error" not in g and g["kernel_only_ms_per_step"] > 0 and "144000" in g["config"]

@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""frames/s of one INFERENCE frame of the GaussianFormer hot path (second clause of BASELINE.json's metric;
+BASELINE configs [2]/[3] without the image backbone, which is third-party mmseg/mmcv code).
+
+The frame follows the reference's op sequence (model/encoder/gaussian_encoder/gaussian_encoder.py:74-123 with the
+``operation_order`` of config/nuscenes_gs25600_solid.py:161-173, then model/head/gaussian_head.py:122-197):
+
+    feature pyramid -> feature_maps_format (ONCE per frame; the reference redoes it in every block)
+    block 0:    deformable -> ffn -> norm -> refine
+    blocks 1-3: spconv -> norm -> deformable -> ffn -> norm -> refine
+    head:       prepare_gaussian_args (fused, device-side Sigma^-1) -> splat -> occupancy labels
+
+Native (libgf_hip.so): feature_maps_format, SparseConv3D, deformable_prepare (projection + masked softmax), DAF,
+gaussian_prepare, the splat and the label epilogue.  Torch stand-ins with the reference's shapes and random
+weights (there are no checkpoints offline): anchor encoder, key-point generator (deformable_module.py:51-90),
+camera encoder + weights_fc, output_proj, AsymmetricFFN (256 -> 512 -> 128 + identity_fc), LayerNorm, the
+refinement MLP.  Inputs are synthetic and resident in HBM; the timed region is the whole frame, bracketed by
+synchronize().  Prints one JSON line per config.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+EMBED, CAMS, LEVELS, GROUPS = 128, 6, 4, 4
+FIX_SCALE = [[0, 0, 0], [0.45, 0, 0], [-0.45, 0, 0], [0, 0.45, 0], [0, -0.45, 0], [0, 0, 0.45], [0, 0, -0.45]]
+PC_RANGE = [-50.0, -50.0, -5.0, 50.0, 50.0, 3.0]
+FRAME_CONFIGS = {
+    # anchors, scale range, semantic dim carried by the anchor, appended empty Gaussian, opacity in the anchor
+    "nuscenes_gs25600_solid": dict(anchors=25600, scale_range=(0.08, 0.64), sem_dim=17, with_empty=True, include_opa=True),
+    "nuscenes_gs144000": dict(anchors=144000, scale_range=(0.08, 0.32), sem_dim=18, with_empty=False, include_opa=False),
+}
+
+
+def _sig(t):
+    return torch.sigmoid(t.clamp(-9.21, 9.21))       # safe_sigmoid, model/utils/safe_ops.py:7-9
+
+
+def _rotmat(q):
+    """Rotation matrix of a (w, x, y, z) quaternion (model/utils/utils.py:20-69 produces the same matrix)."""
+    q = F.normalize(q, dim=-1)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).unflatten(-1, (3, 3))
+
+
+def cameras(dev):
+    pm = torch.eye(4).repeat(1, CAMS, 1, 1)
+    K = torch.tensor([[1260.0, 0, 800.0], [0, 1260.0, 432.0], [0, 0, 1.0]])
+    for c in range(CAMS):
+        yaw = 2 * np.pi * c / CAMS
+        R = torch.tensor([[-np.sin(yaw), np.cos(yaw), 0.0], [0.0, 0.0, -1.0], [np.cos(yaw), np.sin(yaw), 0.0]], dtype=torch.float32)
+        pm[0, c, :3, :3] = K @ R
+        pm[0, c, :3, 3] = K @ torch.tensor([0.0, 1.5, 0.0])
+    return pm.to(dev), torch.tensor([[[1600.0, 864.0]] * CAMS], device=dev)
+
+
+class Deformable(nn.Module):
+    """DeformableFeatureAggregation with residual_mode="cat" (config/_base_/model.py:72-100)."""
+
+    def __init__(self, scale_range, learnable_pts):
+        super().__init__()
+        self.scale_range = scale_range
+        self.num_pts = len(FIX_SCALE) + learnable_pts
+        self.learnable_fc = nn.Linear(EMBED, learnable_pts * 3)
+        self.camera_encoder = nn.Sequential(nn.Linear(12, EMBED), nn.ReLU(True), nn.LayerNorm(EMBED),
+                                            nn.Linear(EMBED, EMBED), nn.ReLU(True), nn.LayerNorm(EMBED))
+        self.weights_fc = nn.Linear(EMBED, GROUPS * LEVELS * self.num_pts)
+        self.output_proj = nn.Linear(EMBED, EMBED)
+        self.register_buffer("fix_scale", torch.tensor(FIX_SCALE, dtype=torch.float32))
+
+    def key_points(self, anchor, feat):
+        bs, A = anchor.shape[:2]
+        learned = _sig(self.learnable_fc(feat).reshape(bs, A, -1, 3)) - 0.5
+        scale = torch.cat([self.fix_scale[None, None].expand(bs, A, -1, -1), learned], dim=-2)
+        lo, hi = self.scale_range
+        kp = scale * (lo + (hi - lo) * _sig(anchor[..., None, 3:6]))
+        kp = torch.matmul(_rotmat(anchor[..., 6:10])[:, :, None], kp[..., None]).squeeze(-1)
+        r = anchor.new_tensor(PC_RANGE)
+        return kp + (_sig(anchor[..., :3]) * (r[3:] - r[:3]) + r[:3]).unsqueeze(2)
+
+    def forward(self, feat, anchor, anchor_embed, table, pm, wh):
+        from gaussianformer_amd.deformable_aggregation import DeformableAggregationFunction as DAF
+        from gaussianformer_amd.deformable_prepare import deformable_prepare
+        bs, A = feat.shape[:2]
+        kp = self.key_points(anchor, feat)
+        cam = self.camera_encoder(pm[:, :, :3].reshape(bs, CAMS, -1))
+        raw = self.weights_fc((feat + anchor_embed)[:, :, None] + cam[:, None]).reshape(bs, A, CAMS, LEVELS, self.num_pts, GROUPS)
+        loc, weights = deformable_prepare(kp, pm, wh, raw)
+        out = DAF.apply(*table, loc, weights).reshape(bs, A, self.num_pts, EMBED).sum(dim=2)
+        return torch.cat([self.output_proj(out), feat], dim=-1)
+
+
+class FFN(nn.Module):
+    """AsymmetricFFN(in_channels=256, embed_dims=128, feedforward_channels=512), ffn_module.py:8-80."""
+
+    def __init__(self):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(2 * EMBED, 4 * EMBED), nn.ReLU(True), nn.Linear(4 * EMBED, EMBED))
+        self.identity_fc = nn.Linear(2 * EMBED, EMBED)
+
+    def forward(self, x):
+        return self.identity_fc(x) + self.layers(x)
+
+
+class Refine(nn.Module):
+    """Stand-in for SparseGaussian3DRefinementModule (refine_module.py:64-125): MLP on feature + embedding, residual
+    update of the anchor, decoded Gaussian properties."""
+
+    def __init__(self, anchor_dim, scale_range):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(EMBED, EMBED), nn.ReLU(True), nn.LayerNorm(EMBED),
+                                    nn.Linear(EMBED, EMBED), nn.ReLU(True), nn.LayerNorm(EMBED), nn.Linear(EMBED, anchor_dim))
+        self.scale_range = scale_range
+        with torch.no_grad():
+            self.layers[-1].weight.mul_(0.05)
+
+    def forward(self, feat, anchor, anchor_embed):
+        out = self.layers(feat + anchor_embed)
+        anchor = torch.cat([out[..., :3] + anchor[..., :3], out[..., 3:6], F.normalize(out[..., 6:10], dim=-1), out[..., 10:]], dim=-1)
+        return anchor
+
+
+class Frame(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        from gaussianformer_amd.local_aggregate import LocalAggregator
+        from gaussianformer_amd.sparse_conv import SparseConv3D
+        c = FRAME_CONFIGS[config]
+        self.cfg = c
+        self.anchor_dim = 10 + (1 if c["include_opa"] else 0) + c["sem_dim"]
+        self.anchor_encoder = nn.Sequential(nn.Linear(self.anchor_dim, EMBED), nn.ReLU(True), nn.LayerNorm(EMBED), nn.Linear(EMBED, EMBED))
+        order = ["deformable", "ffn", "norm", "refine"] + ["spconv", "norm", "deformable", "ffn", "norm", "refine"] * 3
+        self.order = order
+        layers = []
+        for op in order:
+            layers.append({"deformable": lambda: Deformable(c["scale_range"], 2), "ffn": FFN, "norm": lambda: nn.LayerNorm(EMBED),
+                           "refine": lambda: Refine(self.anchor_dim, c["scale_range"]),
+                           "spconv": lambda: SparseConv3D(EMBED, EMBED, PC_RANGE, [0.5, 0.5, 0.5], use_out_proj=True)}[op]())
+        self.layers = nn.ModuleList(layers)
+        for m in self.layers:
+            if isinstance(m, SparseConv3D):
+                nn.init.normal_(m.layer.weight, std=0.01)
+        self.aggregator = LocalAggregator(3, 200, 200, 16, PC_RANGE[:3], 0.5, check_inputs=False)
+
+    def gaussians(self, anchor):
+        c = self.cfg
+        r = anchor.new_tensor(PC_RANGE)
+        # keep the centres strictly inside the grid (the head asserts it in the reference)
+        means = (0.001 + 0.998 * _sig(anchor[..., :3])) * (r[3:] - r[:3]) + r[:3]
+        lo, hi = c["scale_range"]
+        scales = lo + (hi - lo) * _sig(anchor[..., 3:6])
+        rots = F.normalize(anchor[..., 6:10], dim=-1)
+        k = 10
+        if c["include_opa"]:
+            opa = _sig(anchor[..., k:k + 1]); k += 1
+        else:
+            opa = torch.ones_like(anchor[..., :1])
+        sem = anchor[..., k:]
+        if c["with_empty"]:   # gaussian_head.py:90-102
+            sem = torch.cat([F.softplus(sem), torch.zeros_like(sem[..., :1])], dim=-1)
+            e = sem.new_zeros(1, 1, 18); e[..., 17] = 10.0
+            means = torch.cat([means, means.new_tensor([[[0.0, 0.0, -1.0]]])], dim=1)
+            scales = torch.cat([scales, scales.new_tensor([[[100.0, 100.0, 8.0]]])], dim=1)
+            rots = torch.cat([rots, rots.new_tensor([[[1.0, 0.0, 0.0, 0.0]]])], dim=1)
+            sem = torch.cat([sem, e], dim=1)
+            opa = torch.cat([opa, opa.new_ones(1, 1, 1)], dim=1)
+        return means, scales, rots, opa, sem
+
+    @torch.no_grad()
+    def forward(self, anchor, feat, maps, pm, wh, pts):
+        from gaussianformer_amd.deformable_aggregation import DeformableAggregationFunction as DAF
+        from gaussianformer_amd.head import occupancy_labels
+        table = DAF.feature_maps_format(maps)
+        embed = self.anchor_encoder(anchor)
+        for op, layer in zip(self.order, self.layers):
+            if op == "deformable":
+                feat = layer(feat, anchor, embed, table, pm, wh)
+            elif op == "spconv":
+                feat = layer(feat, anchor)
+            elif op == "refine":
+                anchor = layer(feat, anchor, embed)
+                embed = self.anchor_encoder(anchor)
+            else:
+                feat = layer(feat)
+        means, scales, rots, opa, sem = self.gaussians(anchor)
+        logits = self.aggregator.forward_from_rotations(pts, means, opa.squeeze(-1), sem, scales, rots)
+        return occupancy_labels(logits)
+
+
+def run(config="nuscenes_gs25600_solid", frames=10, warmup=3, device="cuda:0"):
+    from gaussianformer_amd.synthetic import DAF_LEVELS, voxel_centres
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench_frame.py needs an MI355X")
+    dev = torch.device(device)
+    torch.manual_seed(0)
+    model = Frame(config).to(dev).eval()
+    A = model.cfg["anchors"]
+    anchor = torch.randn(1, A, model.anchor_dim, device=dev)
+    feat = torch.randn(1, A, EMBED, device=dev)
+    maps = [torch.randn(1, CAMS, EMBED, h, w, device=dev) for h, w in DAF_LEVELS]
+    pm, wh = cameras(dev)
+    pts = torch.from_numpy(voxel_centres(200, 200, 16, 0.5, np.asarray(PC_RANGE[:3], dtype=np.float32))).to(dev)[None]
+    for _ in range(warmup):
+        labels = model(anchor, feat, maps, pm, wh, pts)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        labels = model(anchor, feat, maps, pm, wh, pts)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / frames
+    hist = torch.bincount(labels, minlength=18).tolist()
+    return {"config": config, "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "frames": frames, "anchors": A,
+            "sample_points_per_block": A * (len(FIX_SCALE) + 2), "voxels": int(labels.numel()),
+            "labels_used": int(sum(1 for h in hist if h)),
+            "scope": "inference frame: feature_maps_format once, 4 encoder blocks (spconv / deformable / ffn / norm / refine in the "
+                     "reference's order), fused Gaussian pre-processing, splat, occupancy labels; image backbone excluded; "
+                     "FFN / LayerNorm / refine / anchor encoder / key points / weights_fc are torch stand-ins with random weights"}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", nargs="*", default=list(FRAME_CONFIGS))
+    ap.add_argument("--frames", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    for c in args.configs:
+        print(json.dumps(run(c, args.frames, args.warmup)), flush=True)
