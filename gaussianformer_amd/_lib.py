@@ -40,6 +40,7 @@ SIGNATURES = {
     "gf_subm_tables_bytes": (_sz, [_i] * 6),
     "gf_subm_rulebook_count": (_i, [_i] * 6 + [_vp, _vp, _sz, _vp]),
     "gf_subm_rulebook_fill": (_i, [_i] * 6 + [_vp] * 4 + [_vp]),
+    "gf_subm_rulebook_build": (_i, [_i] * 6 + [_vp, _vp, _sz, _vp, _vp, ctypes.c_longlong, _vp]),
     "gf_subm_conv_apply": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
     "gf_subm_conv_weight_grad": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
     "gf_feature_maps_format": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
@@ -48,6 +49,8 @@ SIGNATURES = {
     "gf_daf_prepare_backward": (_i, [_i] * 6 + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare": (_i, [_i] * 4 + [_vp, _f, _f, _i, _i] + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare_backward": (_i, [_i] * 2 + [_vp] * 5 + [_vp]),
+    "gf_key_points": (_i, [_i] * 4 + [_vp] * 4 + [_f] * 3 + [_vp, _vp]),
+    "gf_key_points_backward": (_i, [_i] * 4 + [_vp] * 4 + [_f] * 3 + [_vp] * 3 + [_vp]),
     "gf_profile_enable": (_i, [_i]),
     "gf_profile_stride": (_i, [_i]),
     "gf_profile_read": (_i, [_vp, _i]),

@@ -55,7 +55,10 @@ struct SubmArgs {
     float *grad_weight;    // [K3, Cin, Cout]
     int N, batch, X, Y, Z, K, K3, Cin, Cout;
     long long cells;
+    long long pair_capacity;  // > 0: the pair arrays hold this many entries; a larger rulebook raises total[1] bit 2 and stays empty
 };
+
+constexpr unsigned long long kSubmOverCapacity = 4ull;  // bit of total[1]
 
 inline size_t subm_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
 {
     constexpr int KMAX = 7;
     __shared__ unsigned int s_w[KMAX][4], s_base[KMAX];
+    if (FILL && a.pair_capacity > 0 && (a.t.total[1] & kSubmOverCapacity)) return;  // kernel-uniform: nothing fits, nothing is written
     const int i = blockIdx.x * 256 + threadIdx.x, kxy = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = a.K / 2;
@@ -184,10 +188,15 @@ __global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
     const int lane = threadIdx.x;
     unsigned int run = 0, tiles = 0, chunks = 0;
     unsigned long long total64 = 0;
+    for (int k0 = 0; k0 < a.K3; k0 += 64) total64 += k0 + lane < a.K3 ? a.t.kcount[k0 + lane] : 0ull;
+    for (int d = 32; d >= 1; d >>= 1) total64 += __shfl_xor(total64, d, 64);
+    // Sync-free use (gf_subm_rulebook_build): the caller sized the pair arrays without reading the count.  A rulebook
+    // that does not fit is left EMPTY (all segments, tiles and chunks zero, the fill and reduce passes stand down) and
+    // flagged; the host finds out when it next looks at total[1].
+    const bool over = a.pair_capacity > 0 && total64 > (unsigned long long)a.pair_capacity;
     for (int k0 = 0; k0 < a.K3; k0 += 64) {
         const int k = k0 + lane;
-        const unsigned long long c64 = k < a.K3 ? a.t.kcount[k] : 0ull;
-        total64 += c64;  // per lane; summed over the wave at the end
+        const unsigned long long c64 = (k < a.K3 && !over) ? a.t.kcount[k] : 0ull;
         const unsigned int c = (unsigned int)c64;
         const unsigned int tl = (c + kPairTile - 1) / kPairTile, ch = (c + kWgradChunk - 1) / kWgradChunk;
         unsigned int ic = c, it = tl, ih = ch;
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
         chunks += __shfl(ih, 63, 64);
     }
     // pair slots are 32-bit ints: more than 2^31 - 1 pairs is reported like a crowded cell (the prefixes above wrapped)
-    for (int d = 32; d >= 1; d >>= 1) total64 += __shfl_xor(total64, d, 64);
     if (lane == 0 && total64 >= (1ull << 31)) atomicOr(a.t.total + 1, 2ull);
+    if (lane == 0 && over) atomicOr(a.t.total + 1, kSubmOverCapacity);
     if (lane == 0) {
         a.t.kstart[a.K3] = run;
         a.t.tile_start[a.K3] = tiles;
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
     const int i = blockIdx.x * ROWS + threadIdx.x / CG;
     const int lane = threadIdx.x & 63;
     const int gshift = lane & ~(CG - 1);  // first lane of this point's group inside the wave
-    const bool live = i < a.N;
+    const bool live = i < a.N && !(a.t.total[1] & kSubmOverCapacity);  // an over-capacity rulebook is empty: zeros
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int *sf = a.t.slot_first + (size_t)(live ? i : 0) * a.K3;
     const unsigned short *cn = a.t.cnt + (size_t)(live ? i : 0) * a.K3;
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
             }
         }
     }
-    if (live) reinterpret_cast<float4 *>(a.out + (size_t)i * COUT)[tc] = acc;
+    if (i < a.N) reinterpret_cast<float4 *>(a.out + (size_t)i * COUT)[tc] = acc;  // zeros for an over-capacity rulebook
 }
 
 // staging helpers of the weight gradient: thread tid owns float4 (tid + 256 u) of the 32 x C block, u < Q
@@ -500,8 +509,8 @@ extern "C" size_t gf_subm_tables_bytes(int N, int batch, int X, int Y, int Z, in
     return bytes;
 }
 
-extern "C" int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
-                                      size_t tables_bytes, void *stream_)
+static int subm_rulebook_count_impl(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                                    size_t tables_bytes, long long pair_capacity, void *stream_)
 {
     using namespace gf;
     hipStream_t stream = (hipStream_t)stream_;
@@ -510,6 +519,7 @@ extern "C" int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int
     GF_CHECK_ARG(N == 0 || indices, "null pointer");
     GF_CHECK_ARG(((uintptr_t)indices & 15) == 0 && ((uintptr_t)tables & 255) == 0, "indices must be 16-byte and tables 256-byte aligned");
     SubmArgs a = subm_args(N, batch, X, Y, Z, K, indices, tables);
+    a.pair_capacity = pair_capacity;
     if (hipMemsetAsync(a.t.head, 0xFF, (size_t)a.cells * 4, stream) != hipSuccess ||
         hipMemsetAsync(a.t.cnt, 0, (size_t)N * a.K3 * 2, stream) != hipSuccess ||
         hipMemsetAsync(a.t.total, 0, 16, stream) != hipSuccess ||
@@ -526,8 +536,14 @@ extern "C" int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int
     return GF_OK;
 }
 
-extern "C" int gf_subm_rulebook_fill(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
-                                     int *pair_in, int *pair_out, void *stream_)
+extern "C" int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                                      size_t tables_bytes, void *stream)
+{
+    return subm_rulebook_count_impl(N, batch, X, Y, Z, K, indices, tables, tables_bytes, 0, stream);
+}
+
+static int subm_rulebook_fill_impl(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                                   int *pair_in, int *pair_out, long long pair_capacity, void *stream_)
 {
     using namespace gf;
     hipStream_t stream = (hipStream_t)stream_;
@@ -535,10 +551,25 @@ extern "C" int gf_subm_rulebook_fill(int N, int batch, int X, int Y, int Z, int 
     GF_CHECK_ARG(tables && (N == 0 || (indices && pair_in && pair_out)), "null pointer");
     if (N == 0) return GF_OK;
     SubmArgs a = subm_args(N, batch, X, Y, Z, K, indices, tables);
+    a.pair_capacity = pair_capacity;
     a.pair_in = pair_in; a.pair_out = pair_out;
     hipLaunchKernelGGL(gf_subm_pairs_kernel<true>, dim3((N + 255) / 256, K * K), dim3(256), 0, stream, a);
     GF_CHECK_LAUNCH();
     return GF_OK;
+}
+
+extern "C" int gf_subm_rulebook_fill(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                                     int *pair_in, int *pair_out, void *stream)
+{
+    return subm_rulebook_fill_impl(N, batch, X, Y, Z, K, indices, tables, pair_in, pair_out, 0, stream);
+}
+
+extern "C" int gf_subm_rulebook_build(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                                      size_t tables_bytes, int *pair_in, int *pair_out, long long pair_capacity, void *stream)
+{
+    GF_CHECK_ARG(pair_capacity > 0 && pair_capacity < (1ll << 31), "pair_capacity out of range");
+    if (int rc = subm_rulebook_count_impl(N, batch, X, Y, Z, K, indices, tables, tables_bytes, pair_capacity, stream)) return rc;
+    return subm_rulebook_fill_impl(N, batch, X, Y, Z, K, indices, tables, pair_in, pair_out, pair_capacity, stream);
 }
 
 #define GF_SUBM_DISPATCH(CALL)                                         \

@@ -16,9 +16,14 @@ f32, i32 = torch.float32, torch.int32
 
 
 class Rulebook:
-    """Neighbour pairs of one point set (reusable across layers and by the backward pass)."""
+    """Neighbour pairs of one point set (reusable across layers and by the backward pass).
 
-    def __init__(self, indices, batch_size, spatial_shape, kernel_size):
+    ``pair_capacity=None``: the pair count is read back once to size the pair arrays (spconv reads its pair counts
+    the same way).  ``pair_capacity=n``: nothing is read back -- the arrays hold ``n`` pairs, a point set with more
+    pairs produces an empty rulebook (zero output) and a refusal flag that :meth:`check` raises on; call it at a
+    point where the stream is synchronised anyway."""
+
+    def __init__(self, indices, batch_size, spatial_shape, kernel_size, pair_capacity=None):
         _lib.require_gpu(indices)
         lib = _lib.load()
         self.indices = indices.detach().to(i32).contiguous()
@@ -30,21 +35,38 @@ class Rulebook:
         if nbytes == 0:
             raise RuntimeError(f"unsupported sparse-conv geometry {self.dims}")
         self.tables = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._status = self.tables[nbytes - 256:nbytes - 240].view(torch.int64)   # (pair count, refusal bits)
+        self.checked = pair_capacity is None
         with torch.cuda.device(dev):
+            if pair_capacity is not None:
+                self.total = max(int(pair_capacity), 1)
+                self.pair_in = torch.empty(self.total, dtype=i32, device=dev)
+                self.pair_out = torch.empty(self.total, dtype=i32, device=dev)
+                rc = lib.gf_subm_rulebook_build(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes,
+                                                _lib.ptr(self.pair_in), _lib.ptr(self.pair_out), self.total, _lib.current_stream(dev))
+                _lib.check(rc, "gf_subm_rulebook_build")
+                return
             rc = lib.gf_subm_rulebook_count(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes,
                                             _lib.current_stream(dev))
             _lib.check(rc, "gf_subm_rulebook_count")
-            # the one host read (spconv reads its pair counts the same way)
-            total, refused = self.tables[nbytes - 256:nbytes - 240].view(torch.int64).tolist()
-            if refused:
-                raise RuntimeError("sparse-conv rulebook refused: " +
-                                   ("a cell holds more than 65535 points" if refused & 1 else "more than 2^31 - 1 neighbour pairs"))
+            total = self.check()   # the one host read
             self.total = int(total)
             self.pair_in = torch.empty(max(self.total, 1), dtype=i32, device=dev)
             self.pair_out = torch.empty(max(self.total, 1), dtype=i32, device=dev)
             rc = lib.gf_subm_rulebook_fill(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables),
                                            _lib.ptr(self.pair_in), _lib.ptr(self.pair_out), _lib.current_stream(dev))
             _lib.check(rc, "gf_subm_rulebook_fill")
+
+    def check(self):
+        """Reads the device status (synchronises): returns the pair count, raises if the point set was refused."""
+        total, refused = self._status.tolist()
+        self.checked = True
+        if refused:
+            raise RuntimeError("sparse-conv rulebook refused: " +
+                               ("a cell holds more than 65535 points" if refused & 1 else
+                                "more than 2^31 - 1 neighbour pairs" if refused & 2 else
+                                f"{total} neighbour pairs exceed the pair_capacity of {self.total}"))
+        return total
 
     def apply(self, features, weight):
         """``out[N, Cout]`` for ``features [N, Cin]`` and ``weight [K^3, Cin, Cout]`` (no autograd)."""
@@ -129,8 +151,13 @@ class SparseConv3D(nn.Module):
     rulebook -- a submanifold convolution keeps the active set."""
 
     def __init__(self, in_channels, embed_channels, pc_range, grid_size, xyz_activation="sigmoid", use_out_proj=False,
-                 kernel_size=5, use_multi_layer=False, **kwargs):
+                 kernel_size=5, use_multi_layer=False, pairs_per_point=None, **kwargs):
         super().__init__()
+        # extra keyword: with ``pairs_per_point=n`` the rulebook is built for at most n * points neighbour pairs without
+        # reading the pair count back (no host synchronisation in the encoder loop); ``self.last_rulebook.check()``
+        # reports a point set that did not fit.  None = exact size, one host read per rulebook (like spconv).
+        self.pairs_per_point = pairs_per_point
+        self.last_rulebook = None
         if use_multi_layer:
             self.layer = nn.ModuleList()
             for i in range(3):
@@ -164,10 +191,11 @@ class SparseConv3D(nn.Module):
         bs, g, _ = instance_feature.shape
         indices = self.voxel_indices(anchor)
         feats = instance_feature.flatten(0, 1)
+        cap = None if self.pairs_per_point is None else int(self.pairs_per_point) * indices.shape[0]
+        rb = self.last_rulebook = Rulebook(indices, bs, self._spatial, self.kernel_size, pair_capacity=cap)
         if isinstance(self.layer, SubMConv3d):
-            out = self.layer(feats, indices, bs, self._spatial)
+            out = self.layer(feats, indices, bs, self._spatial, rulebook=rb)
         else:
-            rb = Rulebook(indices, bs, self._spatial, self.kernel_size)
             out = feats
             for m in self.layer:
                 out = m(out, indices, bs, self._spatial, rulebook=rb) if isinstance(m, SubMConv3d) else m(out)

@@ -245,6 +245,10 @@ int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const
  *   3. gf_subm_rulebook_fill;
  *   4. gf_subm_conv_apply, any number of times (the gradient w.r.t. the features is the same call with
  *      weight'[k] = weight[K^3-1-k]^T), and gf_subm_conv_weight_grad.
+ * Without the host read: gf_subm_rulebook_build does steps 1 and 3 in one call for pair arrays the caller sized in
+ * advance (`pair_capacity` entries; partial f32 [pair_capacity, Cout]; pass pair_capacity as `total_pairs` below).  A
+ * point set with more pairs than that leaves the rulebook EMPTY (apply returns zeros) and sets bit 2 of the refusal
+ * word, which the caller reads whenever it next synchronises.
  * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  Both products run on the f32 matrix
  * cores (v_mfma_f32_32x32x2_f32: exact f32, an fmaf chain); results are deterministic except the weight gradient of
  * segments longer than 512 pairs (float atomics between their chunks).
@@ -254,6 +258,8 @@ int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int K, const i
                            size_t tables_bytes, void *stream);
 int gf_subm_rulebook_fill(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
                           int *pair_in, int *pair_out, void *stream);
+int gf_subm_rulebook_build(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
+                           size_t tables_bytes, int *pair_in, int *pair_out, long long pair_capacity, void *stream);
 int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
                        const float *features, const float *weight, const void *tables, const int *pair_in,
                        float *partial, float *out, void *stream);
@@ -311,6 +317,28 @@ int gf_daf_prepare_backward(int B, int A, int pts, int cams, int L, int G, const
                             const float *projection_mat, const float *image_wh, const float *weights,
                             const float *grad_weights, const float *grad_points_2d, float *grad_raw_weights,
                             float *grad_key_points, void *stream);
+
+/*
+ * ---- key points of the deformable aggregation (first step of the caller preparation) --------
+ * Replaces SparseGaussian3DKeyPointsGenerator.forward (model/encoder/gaussian_encoder/deformable_module.py:51-90)
+ * with its default sigmoid activations: per anchor, F fixed + K learned offsets, times the activated scale
+ * (scale_lo + (scale_hi - scale_lo) * safe_sigmoid(anchor[3:6])), rotated by get_rotation_matrix(anchor[6:10])^T
+ * (model/utils/utils.py:20-69), plus the activated centre (pc_range, safe_sigmoid(anchor[0:3])).
+ *   anchor     f32 [n, anchor_dim >= 10]  (xyz, scale, quaternion (w,x,y,z), ...) before activation; n = bs * anchors
+ *   learned    f32 [n, K, 3]   raw output of learnable_fc (may be NULL when K == 0)
+ *   fix_scale  f32 [F, 3]      device pointer, F <= 16
+ *   pc_range   6 floats, HOST pointer
+ *   key_points f32 [n, F + K, 3]
+ */
+int gf_key_points(int n, int anchor_dim, int F, int K, const float *anchor, const float *learned, const float *fix_scale,
+                  const float *pc_range, float scale_lo, float scale_hi, float learnable_fixed_scale, float *key_points,
+                  void *stream);
+
+/* Its gradient: grad_anchor [n, anchor_dim] (columns >= 10 are written as zero), grad_learned [n, K, 3]. */
+int gf_key_points_backward(int n, int anchor_dim, int F, int K, const float *anchor, const float *learned,
+                           const float *fix_scale, const float *pc_range, float scale_lo, float scale_hi,
+                           float learnable_fixed_scale, const float *grad_key_points, float *grad_anchor,
+                           float *grad_learned, void *stream);
 
 /* Time only every `every`-th dominant-kernel launch (default 1): the two event records cost a few
  * microseconds of stream time each, so sampling keeps the timed region close to the un-instrumented one. */

@@ -214,3 +214,42 @@ def test_subm_conv_crowded_cells():
     crowd = torch.zeros(66000, 4, dtype=torch.int32, device=dev)          # 66 000 points in one cell
     with pytest.raises(RuntimeError, match="65535"):
         Rulebook(crowd, 1, (2, 2, 2), 1)
+
+
+def test_subm_conv_without_host_read():
+    """gf_subm_rulebook_build: pair arrays sized in advance, no count read back.  Same output and gradients as the exact
+    rulebook when the pairs fit; an EMPTY rulebook (zero output) and a refusal that check() raises when they do not."""
+    from gaussianformer_amd.sparse_conv import Rulebook, SparseConv3D, subm_conv3d
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    N, batch, shape, K = 1500, 1, (14, 12, 6), 5
+    idx = _points(rng, N, batch, shape).to(dev)
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(N, 128, generator=g).to(dev)
+    weight = (torch.randn(K ** 3, 128, 128, generator=g) * 0.1).to(dev)
+    gout = torch.randn(N, 128, generator=g).to(dev)
+    exact = Rulebook(idx, batch, shape, K)
+    outs = []
+    for rb in (exact, Rulebook(idx, batch, shape, K, pair_capacity=exact.total + 777)):
+        f, w = feat.clone().requires_grad_(True), weight.clone().requires_grad_(True)
+        out = subm_conv3d(f, idx, w, batch, shape, K, rulebook=rb)
+        out.backward(gout)
+        outs.append((out.detach(), f.grad, w.grad))
+    # two builds may chain the points of a shared cell in a different order (atomicExch): equal up to summation order
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max()))
+    small = Rulebook(idx, batch, shape, K, pair_capacity=exact.total - 1)
+    out = subm_conv3d(feat, idx, weight, batch, shape, K, rulebook=small)
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="pair_capacity"):
+        small.check()
+    # module keyword
+    m = SparseConv3D(128, 128, [0.0, 0.0, 0.0, 30.0, 30.0, 8.0], [0.5, 0.5, 0.5], pairs_per_point=125).to(dev)
+    ref = SparseConv3D(128, 128, [0.0, 0.0, 0.0, 30.0, 30.0, 8.0], [0.5, 0.5, 0.5]).to(dev)
+    ref.load_state_dict(m.state_dict())
+    anchor = torch.randn(1, 800, 11, device=dev)
+    x = torch.randn(1, 800, 128, device=dev)
+    ya, yb = m(x, anchor), ref(x, anchor)
+    assert torch.allclose(ya, yb, rtol=1e-5, atol=1e-5 * float(yb.abs().max()))
+    assert m.last_rulebook.check() == ref.last_rulebook.total

@@ -10,10 +10,9 @@ The frame follows the reference's op sequence (model/encoder/gaussian_encoder/ga
     blocks 1-3: spconv -> norm -> deformable -> ffn -> norm -> refine
     head:       prepare_gaussian_args (fused, device-side Sigma^-1) -> splat -> occupancy labels
 
-Native (libgf_hip.so): feature_maps_format, SparseConv3D, deformable_prepare (projection + masked softmax), DAF,
-gaussian_prepare, the splat and the label epilogue.  Torch stand-ins with the reference's shapes and random
-weights (there are no checkpoints offline): anchor encoder, key-point generator (deformable_module.py:51-90),
-camera encoder + weights_fc, output_proj, AsymmetricFFN (256 -> 512 -> 128 + identity_fc), LayerNorm, the
+Native (libgf_hip.so): feature_maps_format, SparseConv3D, key points, deformable_prepare (projection + masked softmax),
+DAF, gaussian_prepare, the splat and the label epilogue.  Torch stand-ins with the reference's shapes and random
+weights (there are no checkpoints offline): anchor encoder, learnable_fc, camera encoder + weights_fc, output_proj, AsymmetricFFN (256 -> 512 -> 128 + identity_fc), LayerNorm, the
 refinement MLP.  Inputs are synthetic and resident in HBM; the timed region is the whole frame, bracketed by
 synchronize().  Prints one JSON line per config.
 """
@@ -80,14 +79,9 @@ class Deformable(nn.Module):
         self.register_buffer("fix_scale", torch.tensor(FIX_SCALE, dtype=torch.float32))
 
     def key_points(self, anchor, feat):
+        from gaussianformer_amd.key_points import key_points
         bs, A = anchor.shape[:2]
-        learned = _sig(self.learnable_fc(feat).reshape(bs, A, -1, 3)) - 0.5
-        scale = torch.cat([self.fix_scale[None, None].expand(bs, A, -1, -1), learned], dim=-2)
-        lo, hi = self.scale_range
-        kp = scale * (lo + (hi - lo) * _sig(anchor[..., None, 3:6]))
-        kp = torch.matmul(_rotmat(anchor[..., 6:10])[:, :, None], kp[..., None]).squeeze(-1)
-        r = anchor.new_tensor(PC_RANGE)
-        return kp + (_sig(anchor[..., :3]) * (r[3:] - r[:3]) + r[:3]).unsqueeze(2)
+        return key_points(anchor, self.learnable_fc(feat).reshape(bs, A, -1, 3), self.fix_scale, PC_RANGE, self.scale_range)
 
     def forward(self, feat, anchor, anchor_embed, table, pm, wh):
         from gaussianformer_amd.deformable_aggregation import DeformableAggregationFunction as DAF
@@ -95,7 +89,12 @@ class Deformable(nn.Module):
         bs, A = feat.shape[:2]
         kp = self.key_points(anchor, feat)
         cam = self.camera_encoder(pm[:, :, :3].reshape(bs, CAMS, -1))
-        raw = self.weights_fc((feat + anchor_embed)[:, :, None] + cam[:, None]).reshape(bs, A, CAMS, LEVELS, self.num_pts, GROUPS)
+        # weights_fc is linear: W (f + e + c_cam) + b = [W (f + e) + b] + W c_cam.  The reference applies it to the
+        # broadcast sum (deformable_module.py:253-262: an [A*cams, 128] x [128, 144] GEMM, 3.0 ms at 25 600 anchors);
+        # the anchor part and the camera part are multiplied separately here (1/6 of the GEMM) and added on the fly.
+        per_anchor = self.weights_fc(feat + anchor_embed)                              # [bs, A, 144]
+        per_cam = F.linear(cam, self.weights_fc.weight)                                # [bs, cams, 144]
+        raw = (per_anchor[:, :, None] + per_cam[:, None]).reshape(bs, A, CAMS, LEVELS, self.num_pts, GROUPS)
         loc, weights = deformable_prepare(kp, pm, wh, raw)
         out = DAF.apply(*table, loc, weights).reshape(bs, A, self.num_pts, EMBED).sum(dim=2)
         return torch.cat([self.output_proj(out), feat], dim=-1)
@@ -146,7 +145,8 @@ class Frame(nn.Module):
         for op in order:
             layers.append({"deformable": lambda: Deformable(c["scale_range"], 2), "ffn": FFN, "norm": lambda: nn.LayerNorm(EMBED),
                            "refine": lambda: Refine(self.anchor_dim, c["scale_range"]),
-                           "spconv": lambda: SparseConv3D(EMBED, EMBED, PC_RANGE, [0.5, 0.5, 0.5], use_out_proj=True)}[op]())
+                           "spconv": lambda: SparseConv3D(EMBED, EMBED, PC_RANGE, [0.5, 0.5, 0.5], use_out_proj=True,
+                                                          pairs_per_point=64)}[op]())   # no host read per rulebook
         self.layers = nn.ModuleList(layers)
         for m in self.layers:
             if isinstance(m, SparseConv3D):
@@ -197,6 +197,12 @@ class Frame(nn.Module):
         logits = self.aggregator.forward_from_rotations(pts, means, opa.squeeze(-1), sem, scales, rots)
         return occupancy_labels(logits)
 
+    def check(self):
+        """After a synchronisation: did every rulebook of the last frame fit its capacity?"""
+        for m in self.layers:
+            if getattr(m, "last_rulebook", None) is not None:
+                m.last_rulebook.check()
+
 
 def run(config="nuscenes_gs25600_solid", frames=10, warmup=3, device="cuda:0"):
     from gaussianformer_amd.synthetic import DAF_LEVELS, voxel_centres
@@ -219,13 +225,14 @@ def run(config="nuscenes_gs25600_solid", frames=10, warmup=3, device="cuda:0"):
         labels = model(anchor, feat, maps, pm, wh, pts)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / frames
+    model.check()
     hist = torch.bincount(labels, minlength=18).tolist()
     return {"config": config, "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "frames": frames, "anchors": A,
             "sample_points_per_block": A * (len(FIX_SCALE) + 2), "voxels": int(labels.numel()),
             "labels_used": int(sum(1 for h in hist if h)),
             "scope": "inference frame: feature_maps_format once, 4 encoder blocks (spconv / deformable / ffn / norm / refine in the "
                      "reference's order), fused Gaussian pre-processing, splat, occupancy labels; image backbone excluded; "
-                     "FFN / LayerNorm / refine / anchor encoder / key points / weights_fc are torch stand-ins with random weights"}
+                     "FFN / LayerNorm / refine / anchor encoder / weights_fc (applied to the anchor and camera parts separately) are torch stand-ins with random weights"}
 
 
 if __name__ == "__main__":
