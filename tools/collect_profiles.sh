@@ -25,7 +25,7 @@ cp $OUT/traffic_gs144000_$R.json profiles/traffic_gs144000_$R.json
 python bench.py --steps 200 --warmup 20 > $OUT/bench_$R.json 2> $OUT/bench_$R.err
 cat $OUT/bench_$R.json
 rm -rf gpurun_out/kt_$R
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$R -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-two-stream > $OUT/kernel_trace_bench_$R.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$R -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $OUT/kernel_trace_bench_$R.log 2>&1
 cp $(find gpurun_out/kt_$R -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_bench_$R.csv
 cat $OUT/kernel_stats_bench_$R.csv
 cat $OUT/pmc_$R.txt

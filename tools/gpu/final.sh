@@ -7,6 +7,11 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$R.log 2>&
 bash tools/collect_profiles.sh $R > gpurun_out/collect_$R.log 2>&1; head -3 gpurun_out/collect_$R.log | cut -c1-600
 timeout 600 python tools/bench_ops.py > gpurun_out/profiles_$R/bench_ops_$R.jsonl 2> gpurun_out/bench_ops.err; cat gpurun_out/profiles_$R/bench_ops_$R.jsonl
 timeout 300 python tools/timeline.py > gpurun_out/profiles_$R/timeline_render_$R.txt 2>&1; tail -20 gpurun_out/profiles_$R/timeline_render_$R.txt
+timeout 300 python tools/bench_frame.py --frames 20 > gpurun_out/profiles_$R/bench_frame_$R.jsonl 2> gpurun_out/bench_frame.err; cut -c1-140 gpurun_out/profiles_$R/bench_frame_$R.jsonl
+rm -rf gpurun_out/kt_frame; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_frame -- python tools/bench_frame.py --configs nuscenes_gs25600_solid --frames 10 > gpurun_out/kt_frame.log 2>&1; cp $(find gpurun_out/kt_frame -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_frame_gs25600_$R.csv
+timeout 300 python tools/uniform_experiment.py > gpurun_out/profiles_$R/uniform_experiment_$R.txt 2>&1
+[ -x tools/microbench/mfma4x4 ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/microbench/mfma4x4 tools/microbench/mfma4x4.hip 2>/dev/null
+./tools/microbench/mfma4x4 > gpurun_out/profiles_$R/microbench_mfma4x4_$R.txt 2>&1
 for m in valu mfma lanes; do [ -x tools/microbench/$m ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/microbench/$m tools/microbench/$m.hip 2>/dev/null; done
 ./tools/microbench/valu > gpurun_out/profiles_$R/microbench_valu_$R.txt 2>&1
 ./tools/microbench/mfma > gpurun_out/profiles_$R/microbench_mfma_$R.txt 2>&1
@@ -19,5 +24,5 @@ timeout 300 python tools/bench_step.py > gpurun_out/profiles_$R/bench_step_$R.js
 rm -rf gpurun_out/kt_step; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_step -- python tools/bench_step.py --steps 5 --warmup 2 > gpurun_out/kt_step.log 2>&1; cp $(find gpurun_out/kt_step -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_step_$R.csv
 # BASELINE config [3]: nuscenes_gs144000 inference
 python bench.py --config nuscenes_gs144000 --no-cpu-baseline > gpurun_out/profiles_$R/bench_gs144000_$R.json 2> gpurun_out/bench_gs144000.err
-rm -rf gpurun_out/kt_144; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_144 -- python bench.py --config nuscenes_gs144000 --no-cpu-baseline --no-two-stream > gpurun_out/kt_144.log 2>&1; cp $(find gpurun_out/kt_144 -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_bench_gs144000_$R.csv
+rm -rf gpurun_out/kt_144; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_144 -- python bench.py --config nuscenes_gs144000 --no-cpu-baseline --no-extras > gpurun_out/kt_144.log 2>&1; cp $(find gpurun_out/kt_144 -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_bench_gs144000_$R.csv
 cp gpurun_out/pytest_gpu_$R.log gpurun_out/smoke_$R.log gpurun_out/profiles_$R/

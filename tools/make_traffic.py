@@ -12,11 +12,11 @@ config = sys.argv[5] if len(sys.argv) > 5 else "nuscenes_gs25600_solid"
 P = int(sys.argv[6]) if len(sys.argv) > 6 else 25601
 
 
-def mean_counter(d, counter):
+def mean_counter(d, counter, kernel="gf_splat_render_kernel"):
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "gf_splat_render_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and kernel in r["Kernel_Name"]:
                 acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     (name, vals), = acc.items()
     return name, sum(vals) / len(vals), len(vals)
@@ -24,6 +24,8 @@ def mean_counter(d, counter):
 
 name, fetch, n = mean_counter(fetch_dir, "FETCH_SIZE")
 _, write, _ = mean_counter(write_dir, "WRITE_SIZE")
+_, pfetch, _ = mean_counter(fetch_dir, "FETCH_SIZE", "gf_splat_prep_kernel")
+_, pwrite, _ = mean_counter(write_dir, "WRITE_SIZE", "gf_splat_prep_kernel")
 N = 640000
 json.dump({
     "source": f"profiles/pmc_{tag}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, {n} launches each, {config})",
@@ -34,6 +36,8 @@ json.dump({
     "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
     "render_kernel_hbm_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
     "render_kernel_hbm_bytes_per_launch_uncorrected": int(round((fetch + write) * 1024)),
+    "prep_kernel_hbm_bytes_per_launch": int(round((2 * pfetch + pwrite) * 1024)),
+    "step_hbm_bytes": int(round((2 * (fetch + pfetch) + write + pwrite) * 1024)),
     "algorithmic_bytes_per_launch": 128 * P + 24 * N + 72 * N,
 }, open(out, "w"), indent=2)
 print(open(out).read())
