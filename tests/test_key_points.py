@@ -72,4 +72,9 @@ def test_generator_module_matches_the_reference_caller(gpu):
     uv, _ = daf_prepare_ref.project_points(kp.cpu(), torch.from_numpy(d["projection_mat"]), torch.from_numpy(d["image_wh"]))
     bs, cams, A, K, _ = uv.shape
     loc = uv.permute(0, 2, 3, 1, 4).reshape(bs, A * K, cams, 2).numpy()
-    assert np.allclose(loc, d["call_sampling_location"], rtol=1e-5, atol=2e-5)
+    # points behind a camera are divided by the 1e-5 depth clamp (|uv| ~ 1e5): an fp32 ulp of the key point moves them by
+    # ~1e-2, so those are compared relatively; the visible ones (0 < uv < 1) must agree to 2e-5
+    want = d["call_sampling_location"]
+    assert np.allclose(loc, want, rtol=1e-4, atol=2e-5)
+    vis = (want > 0).all(-1) & (want < 1).all(-1)
+    assert vis.mean() > 0.1 and np.abs(loc - want)[vis].max() <= 2e-5
