@@ -10,7 +10,10 @@ typedef float f16x __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-template <int MODE>  // 0 full, 1 MFMA only, 2 VALU part only
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+union H8 { h8 v; fp16x2 p[4]; };
+
+template <int MODE>  // 0 full, 1 MFMA only, 2 VALU part only, 3 full with the tuned VALU part, 4 tuned VALU part only
 __global__ __launch_bounds__(64) void k(float *out, const unsigned *masks, int iters)
 {
     const int lane = threadIdx.x;
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(64) void k(float *out, const unsigned *masks, int i
             f16x d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
-            if (MODE != 2) {
+            if (MODE != 2 && MODE != 4) {
                 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(th1, phi[b], d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(th2, phi[b], d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(th3, phi[b], d, 0, 0, 0);
@@ -43,7 +46,30 @@ __global__ __launch_bounds__(64) void k(float *out, const unsigned *masks, int i
                 for (int r = 0; r < 16; ++r) d[r] = acc[b][r] * 0.001f - 1.0f;
             }
             h8 wh0, wh1, wl0, wl1;
-            if (MODE != 1) {
+            if (MODE == 3 || MODE == 4) {
+                // tuned: the box mask of (register r, lane half) is a wave-uniform 64-bit word (the Gaussian's own voxel
+                // mask): v_cndmask with an SGPR pair; hi = round-toward-zero pack of two values (v_cvt_pkrtz_f16_f32),
+                // lo = pack of the exact residuals w - hi (v_fma_mix reads the f16 halves directly)
+                float w[16];
+                unsigned long long mk = ((unsigned long long)gm << 32) | (gm * 2654435761u);
+                mk = __builtin_amdgcn_readfirstlane((unsigned)mk) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mk >> 32)) << 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(d[r]);
+                    const unsigned long long mr = mk ^ (0x9e3779b97f4a7c15ull * (unsigned)(r + 1));   // stands in for the r-th mask pair
+                    w[r] = __builtin_amdgcn_inverse_ballot_w64(mr) ? e : 0.f;
+                }
+                H8 Hh0, Hh1, Hl0, Hl1;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const fp16x2 hi = __builtin_amdgcn_cvt_pkrtz(w[r], w[r + 1]);
+                    const float r0 = w[r] - (float)hi[0], r1 = w[r + 1] - (float)hi[1];
+                    const fp16x2 lo = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+                    if (r < 8) { Hh0.p[r / 2] = hi; Hl0.p[r / 2] = lo; } else { Hh1.p[(r - 8) / 2] = hi; Hl1.p[(r - 8) / 2] = lo; }
+                }
+                wh0 = Hh0.v; wh1 = Hh1.v; wl0 = Hl0.v; wl1 = Hl1.v;
+                gm = gm * 1664525u + 1013904223u;
+            } else if (MODE != 1) {
                 float w[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -62,7 +88,7 @@ __global__ __launch_bounds__(64) void k(float *out, const unsigned *masks, int i
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { wh0[i] = (_Float16)d[i]; wh1[i] = (_Float16)d[8 + i]; wl0[i] = wh0[i]; wl1[i] = wh1[i]; }
             }
-            if (MODE != 2) {
+            if (MODE != 2 && MODE != 4) {
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh0, wh0, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh0, wl0, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl0, wh0, acc[b], 0, 0, 0);
@@ -104,7 +130,10 @@ int main()
         const float full = timeit([&] { hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(64), 0, 0, out, m, iters); });
         const float mf = timeit([&] { hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(64), 0, 0, out, m, iters); });
         const float va = timeit([&] { hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(64), 0, 0, out, m, iters); });
-        printf("%d wave(s)/SIMD: full %6.0f   MFMA only (9 per block) %6.0f   VALU part only %6.0f\n", wps, full * per, mf * per, va * per);
+        const float full2 = timeit([&] { hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(64), 0, 0, out, m, iters); });
+        const float va2 = timeit([&] { hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(64), 0, 0, out, m, iters); });
+        printf("%d wave(s)/SIMD: full %6.0f   MFMA only (9 per block) %6.0f   VALU part only %6.0f  | tuned VALU part: full %6.0f  VALU only %6.0f\n", wps,
+               full * per, mf * per, va * per, full2 * per, va2 * per);
     }
     return 0;
 }
