@@ -43,6 +43,7 @@ struct SplatWorkspace {
     int *order;             // [P]  backward: Gaussian index at each sorted position
     int *seg;               // [P][8] backward: (index, volume, box lo[3], box hi[3]) of the Gaussian at each sorted position
     uint32_t *sort_hist;    // [64][ceil(P/256)] + [64] backward: per-(cell, block) counts -> offsets, cell totals
+    float *dotlg;           // [N]  prob backward: sum_c dL/dlogits[n][c] * logits[n][c]
     int nwords, nsx, nsy, nsuper;
     size_t total_bytes;
 };
@@ -51,7 +52,6 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, int D)
 {
-    (void)N;
     SplatWorkspace ws;
     ws.nwords = (P + 63) / 64;
     ws.nsx = (H + kSuper - 1) / kSuper;
@@ -70,6 +70,7 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.order = (int *)(p + off); off += align256((size_t)P * 4);
     ws.seg = (int *)(p + off); off += align256((size_t)P * 32);
     ws.sort_hist = (uint32_t *)(p + off); off += align256(((size_t)64 * ((P + 255) / 256) + 64) * 4);
+    ws.dotlg = (float *)(p + off); off += align256((size_t)(N > 0 ? N : 0) * 4);
     ws.total_bytes = off;
     return ws;
 }

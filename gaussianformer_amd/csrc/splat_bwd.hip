@@ -54,6 +54,7 @@ struct BwdArgs {
     int *order;           // [P] input index of the Gaussian at each sorted position
     int *seg;             // [P][8] (input index, volume, box lo[3], box hi[3]) at each sorted position: one scalar fetch per segment
     uint32_t *sort_hist;  // [kSortCells][nblk]
+    float *dotlg;         // prob only, [N]: sum_c out_grad[n][c] * logits[n][c]
     int P, N, H, W, D, per_axis, force_general, assume_dense, nblk, exact_det;
 };
 
@@ -262,6 +263,25 @@ __global__ __launch_bounds__(256) void gf_bwd_sort_scatter_kernel(BwdArgs a)
     }
 }
 
+// prob variant: the reference's per-pair sum  A = sum_c dL[c] * (sem_g[c] - logits_v[c])  (backward.cu:88-91) splits
+// into a per-Gaussian part and  sum_c dL[c] * logits_v[c], which depends on the voxel only: taken once per point
+// here, so the gradient kernel gathers ONE 72-byte row per pair instead of two.
+__global__ __launch_bounds__(256) void gf_bwd_dot_kernel(BwdArgs a)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.N) return;
+    const float2 *g = reinterpret_cast<const float2 *>(a.out_grad + (size_t)n * kC);
+    const float2 *l = reinterpret_cast<const float2 *>(a.logits + (size_t)n * kC);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < kC / 2; ++j) {
+        const float2 x = g[j], y = l[j];
+        acc = fmaf(x.x, y.x, acc);
+        acc = fmaf(x.y, y.y, acc);
+    }
+    a.dotlg[n] = acc;
+}
+
 // Sums of 256 consecutive sorted volumes (the coarse level of the range search).
 __global__ __launch_bounds__(256) void gf_bwd_bsum_kernel(BwdArgs a)
 {
@@ -328,7 +348,7 @@ __device__ __forceinline__ int reduce_slot(int lane)
 }
 
 template <int VARIANT>
-__global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_splat_bwd_kernel(BwdArgs a)
+__global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 3) void gf_splat_bwd_kernel(BwdArgs a)
 {
     __shared__ unsigned long long s_pref[kBwdMaxBlk + 1];  // exclusive prefix of the block sums
     __shared__ __attribute__((aligned(16))) float s_rows_all[4 * 64 * kC];
@@ -444,6 +464,7 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
             // GF_PROB_EXACT_DET -- the same choice the forward made (gf_common.hpp: prob_det_kdet)
             prob_det_kdet(c1x, c1y, c1z, c2x, c2y, c2z, a.exact_det, deter, kdet);
         }
+        const float half_inv_deter = 0.5f / deter;
 
         float mg0 = 0.f, mg1 = 0.f, mg2 = 0.f, og = 0.f, dg = 0.f;
         float cg0 = 0.f, cg1 = 0.f, cg2 = 0.f, cg3 = 0.f, cg4 = 0.f, cg5 = 0.f;
@@ -481,35 +502,33 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
             x += qx + carry;
         };
         float2 raw[9];
-        float2 raw2[9];  // prob variant: the logits rows of the same voxels
         float dL[kC];
         float ptx = 0.f, pty = 0.f, ptz = 0.f, ptx_n = 0.f, pty_n = 0.f, ptz_n = 0.f;
         int p = point_of(i, x, y, z), p_n = -1;
         stage_issue(a.out_grad, p, raw, s_pidx, lane);
-        if (VARIANT == GF_SPLAT_PROB) stage_issue(a.logits, p, raw2, s_pidx, lane);
         { const size_t pc = (size_t)max(p, 0); ptx = a.pts[3 * pc]; pty = a.pts[3 * pc + 1]; ptz = a.pts[3 * pc + 2]; }  // unconditional, see stage_issue
         // prob variant: the four per-voxel scalars travel with the position, one iteration ahead and without a
         // branch around the loads (inside `if (p >= 0)` each of them was waited for where it was issued)
         float psum = 0.f, binl = 0.f, bing = 0.f, deng = 0.f, psum_n = 0.f, binl_n = 0.f, bing_n = 0.f, deng_n = 0.f;
+        float dot = 0.f, dot_n = 0.f;  // sum_c dL[c] * logits[c] of the voxel (gf_bwd_dot_kernel)
         if (VARIANT == GF_SPLAT_PROB) {
             const size_t pc = (size_t)max(p, 0);
             psum = a.probability[pc];
+            dot = a.dotlg[pc];
             if (a.bin_grad) { binl = a.bin_logits[pc]; bing = a.bin_grad[pc]; }  // kernel-uniform conditions
             if (a.dens_grad) deng = a.dens_grad[pc];
         }
         for (int base = o0; base < o1; base += 64) {  // wave-uniform trip count
             stage_finish(raw, dL, s_rows, lane);
-            float lg[kC];
-            if (VARIANT == GF_SPLAT_PROB) stage_finish(raw2, lg, s_rows, lane);  // requested one iteration ago, like dL
             advance();
             i += 64;
             p_n = point_of(i, x, y, z);
             stage_issue(a.out_grad, p_n, raw, s_pidx, lane);
-            if (VARIANT == GF_SPLAT_PROB) stage_issue(a.logits, p_n, raw2, s_pidx, lane);
             { const size_t pc = (size_t)max(p_n, 0); ptx_n = a.pts[3 * pc]; pty_n = a.pts[3 * pc + 1]; ptz_n = a.pts[3 * pc + 2]; }
             if (VARIANT == GF_SPLAT_PROB) {
                 const size_t pc = (size_t)max(p_n, 0);
                 psum_n = a.probability[pc];
+                dot_n = a.dotlg[pc];
                 if (a.bin_grad) { binl_n = a.bin_logits[pc]; bing_n = a.bin_grad[pc]; }
                 if (a.dens_grad) deng_n = a.dens_grad[pc];
             }
@@ -550,23 +569,32 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
                     mg0 -= K * sx; mg1 -= K * sy; mg2 -= K * sz;
                 } else {
                     // model/head/localagg_prob/src/backward.cu:76-107
+                    // The reference's five quotients per pair (x / psum three times, / (1 - e + 1e-9), / 2 / deter) are
+                    // products with a reciprocal here (v_rcp_f32, 1 ulp; 0.5 / deter once per Gaussian): ~1e-7 relative
+                    // on gradients whose bound is 1e-3, and 40 instructions fewer per pair.
                     const float prob = kdet * e;
                     float prob_grad = 0.f;
                     if ((double)psum > 1e-9) {
-                        const float coef = prob * opa / psum;
-                        float Asum = 0.f;
+                        const float inv_psum = __builtin_amdgcn_rcpf(psum);
+                        const float coef = prob * opa * inv_psum;
+                        f32x2 A2 = {0.f, 0.f};
 #pragma unroll
-                        for (int ch = 0; ch < kC; ++ch) {
-                            sg[ch] += dL[ch] * coef;
-                            Asum += dL[ch] * (sem[ch] - lg[ch]);
+                        for (int ch = 0; ch < kC; ch += 2) {
+                            const f32x2 d2 = {dL[ch], dL[ch + 1]};
+                            const f32x2 s2 = {sem[ch], sem[ch + 1]};
+                            A2 = __builtin_elementwise_fma(s2, d2, A2);
+                            f32x2 g2 = {sg[ch], sg[ch + 1]};
+                            g2 = __builtin_elementwise_fma((f32x2){coef, coef}, d2, g2);
+                            sg[ch] = g2.x; sg[ch + 1] = g2.y;
                         }
-                        prob_grad = Asum * opa / psum;
-                        og += Asum * prob / psum;
+                        const float Asum = (A2.x + A2.y) - dot;  // = sum_c dL[c] * (sem[c] - logits[c])
+                        prob_grad = Asum * opa * inv_psum;
+                        og += Asum * prob * inv_psum;
                     }
                     float power_grad = prob_grad * kdet;
-                    if (a.bin_grad) power_grad += (1 - binl) / (1 - e + 1e-9f) * bing;
+                    if (a.bin_grad) power_grad += (1 - binl) * __builtin_amdgcn_rcpf(1 - e + 1e-9f) * bing;
                     if (a.dens_grad) power_grad += deng;
-                    dg += prob_grad * prob / 2 / deter;
+                    dg += prob_grad * prob * half_inv_deter;
                     const float pg = power_grad * e;
                     mg0 -= pg * sx; mg1 -= pg * sy; mg2 -= pg * sz;
                     cg0 += pg * (-0.5f * dx * dx); cg1 += pg * (-0.5f * dy * dy); cg2 += pg * (-0.5f * dz * dz);
@@ -574,7 +602,7 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 2) void gf_spla
                 }
             }
             p = p_n; ptx = ptx_n; pty = pty_n; ptz = ptz_n;
-            if (VARIANT == GF_SPLAT_PROB) { psum = psum_n; binl = binl_n; bing = bing_n; deng = deng_n; }
+            if (VARIANT == GF_SPLAT_PROB) { psum = psum_n; dot = dot_n; binl = binl_n; bing = bing_n; deng = deng_n; }
         }
 
         // Reduce across the wave and store: slots 0-17 semantics, 18-23 covariance, 24-26 mean,
@@ -665,7 +693,7 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     a.out_grad = logits_grad;
     a.means_grad = means3D_grad; a.opa_grad = opacity_grad; a.sem_grad = semantics_grad; a.cov_grad = cov3D_grad;
     a.state = (const uint32_t *)state; a.voxel2pts = ws.voxel2pts; a.vols = ws.vols; a.bsum = ws.bsum;
-    a.vols_in = ws.vols_in; a.order = ws.order; a.seg = ws.seg; a.sort_hist = ws.sort_hist;
+    a.vols_in = ws.vols_in; a.order = ws.order; a.seg = ws.seg; a.sort_hist = ws.sort_hist; a.dotlg = ws.dotlg;
     a.P = P; a.N = N; a.H = H; a.W = W; a.D = D; a.per_axis = radii_per_axis ? 1 : 0; a.nblk = (P + 255) / 256;
     const long long V = (long long)H * W * D;
     a.force_general = ((long long)N != V || (flags & GF_PTS_GENERAL)) ? 1 : 0;
@@ -678,10 +706,12 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     hipLaunchKernelGGL(gf_bwd_sort_scatter_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(gf_bwd_bsum_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
     const int blocks = 1024;  // 4096 waves, 4 workgroups per CU (VGPR-limited)
-    if (variant == GF_SPLAT_BASE)
+    if (variant == GF_SPLAT_BASE) {
         hipLaunchKernelGGL(gf_splat_bwd_kernel<GF_SPLAT_BASE>, dim3(blocks), dim3(256), 0, stream, a);
-    else
+    } else {
+        hipLaunchKernelGGL(gf_bwd_dot_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(gf_splat_bwd_kernel<GF_SPLAT_PROB>, dim3(blocks), dim3(256), 0, stream, a);
+    }
     GF_CHECK_LAUNCH();
     return GF_OK;
 }
