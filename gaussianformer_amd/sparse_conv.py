@@ -57,6 +57,21 @@ class Rulebook:
                                            _lib.ptr(self.pair_in), _lib.ptr(self.pair_out), _lib.current_stream(dev))
             _lib.check(rc, "gf_subm_rulebook_fill")
 
+    def representative_mask(self):
+        """``[N,1]`` fp32, 1 for the point with the LARGEST index of its cell (and for points outside the grid), 0 for the
+        others: the ``duplicates="last"`` mode of :func:`subm_conv3d` (cached)."""
+        if getattr(self, "_rep_mask", None) is None:
+            N, B, X, Y, Z, _ = self.dims
+            idx = self.indices.long()
+            b, x, y, z = idx.unbind(1)
+            valid = (b >= 0) & (b < B) & (x >= 0) & (x < X) & (y >= 0) & (y < Y) & (z >= 0) & (z < Z)
+            key = (((b * X + x) * Y + y) * Z + z).clamp(min=0, max=B * X * Y * Z - 1)
+            me = torch.arange(N, device=idx.device)
+            last = torch.full((B * X * Y * Z,), -1, dtype=torch.long, device=idx.device)
+            last.scatter_reduce_(0, key[valid], me[valid], reduce="amax")
+            self._rep_mask = ((last[key] == me) | ~valid).to(f32)[:, None]
+        return self._rep_mask
+
     def check(self):
         """Reads the device status (synchronises): returns the pair count, raises if the point set was refused."""
         total, refused = self._status.tolist()
@@ -117,10 +132,24 @@ class _SubMConv(Function):
         return g_feat, g_w, None
 
 
-def subm_conv3d(features, indices, weight, batch_size, spatial_shape, kernel_size, rulebook=None):
+DUPLICATES = ("sum", "last")
+
+
+def subm_conv3d(features, indices, weight, batch_size, spatial_shape, kernel_size, rulebook=None, duplicates="sum"):
     """Functional submanifold convolution; ``indices`` int ``[N,4]`` = (batch, x, y, z),
-    ``weight [K^3, Cin, Cout]`` (offsets in [K,K,K] order).  Returns ``[N, Cout]``."""
+    ``weight [K^3, Cin, Cout]`` (offsets in [K,K,K] order).  Returns ``[N, Cout]``.
+
+    ``duplicates`` says what several points in ONE cell mean.  ``"sum"`` (default): all of them are sources and each
+    receives the cell's output -- the dense convolution of the scattered-and-summed features.  ``"last"``: only the point
+    with the largest index of a cell is a source for its neighbours (every point still receives an output), which is one
+    of the outcomes of spconv's hash insert, where the duplicate that ends up in the table is a race
+    (spconv3d_module.py:73-77 hands the duplicates to ``spconv.SparseConvTensor`` as they are); the others get no
+    gradient.  It is the same operator on features whose non-representative rows are zeroed."""
+    if duplicates not in DUPLICATES:
+        raise ValueError(f"duplicates must be one of {DUPLICATES}")
     rb = rulebook if rulebook is not None else Rulebook(indices, batch_size, spatial_shape, kernel_size)
+    if duplicates == "last":
+        features = features * rb.representative_mask()
     return _SubMConv.apply(features, weight, rb)
 
 
@@ -128,8 +157,11 @@ class SubMConv3d(nn.Module):
     """``spconv.SubMConv3d(in_channels, out_channels, kernel_size, stride=1, padding=k//2, bias=...)``
     as used by the reference (spconv3d_module.py:28-44); weight ``[K^3, Cin, Cout]``."""
 
-    def __init__(self, in_channels, out_channels, kernel_size=5, bias=True):
+    def __init__(self, in_channels, out_channels, kernel_size=5, bias=True, duplicates="sum"):
         super().__init__()
+        if duplicates not in DUPLICATES:
+            raise ValueError(f"duplicates must be one of {DUPLICATES}")
+        self.duplicates = duplicates
         self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
         self.weight = nn.Parameter(torch.empty(kernel_size ** 3, in_channels, out_channels))
         nn.init.kaiming_uniform_(self.weight.view(-1, out_channels), a=math.sqrt(5))
@@ -140,7 +172,8 @@ class SubMConv3d(nn.Module):
             self.register_parameter("bias", None)
 
     def forward(self, features, indices, batch_size, spatial_shape, rulebook=None):
-        out = subm_conv3d(features, indices, self.weight, batch_size, spatial_shape, self.kernel_size, rulebook)
+        out = subm_conv3d(features, indices, self.weight, batch_size, spatial_shape, self.kernel_size, rulebook,
+                          duplicates=self.duplicates)
         return out if self.bias is None else out + self.bias
 
 
@@ -151,8 +184,9 @@ class SparseConv3D(nn.Module):
     rulebook -- a submanifold convolution keeps the active set."""
 
     def __init__(self, in_channels, embed_channels, pc_range, grid_size, xyz_activation="sigmoid", use_out_proj=False,
-                 kernel_size=5, use_multi_layer=False, pairs_per_point=None, **kwargs):
+                 kernel_size=5, use_multi_layer=False, pairs_per_point=None, duplicates="sum", **kwargs):
         super().__init__()
+        # extra keyword ``duplicates`` ("sum" | "last"): what several anchors in one cell mean, see subm_conv3d
         # extra keyword: with ``pairs_per_point=n`` the rulebook is built for at most n * points neighbour pairs without
         # reading the pair count back (no host synchronisation in the encoder loop); ``self.last_rulebook.check()``
         # reports a point set that did not fit.  None = exact size, one host read per rulebook (like spconv).
@@ -161,11 +195,12 @@ class SparseConv3D(nn.Module):
         if use_multi_layer:
             self.layer = nn.ModuleList()
             for i in range(3):
-                self.layer.append(SubMConv3d(in_channels if i == 0 else embed_channels, embed_channels, kernel_size))
+                self.layer.append(SubMConv3d(in_channels if i == 0 else embed_channels, embed_channels, kernel_size,
+                                             duplicates=duplicates))
                 self.layer.append(nn.LayerNorm(embed_channels))
                 self.layer.append(nn.ReLU(True))
         else:
-            self.layer = SubMConv3d(in_channels, embed_channels, kernel_size, bias=False)
+            self.layer = SubMConv3d(in_channels, embed_channels, kernel_size, bias=False, duplicates=duplicates)
         self.kernel_size = kernel_size
         self.output_proj = nn.Linear(embed_channels, embed_channels) if use_out_proj else nn.Identity()
         self.use_sigmoid = xyz_activation == "sigmoid"

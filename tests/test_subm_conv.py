@@ -253,3 +253,69 @@ def test_subm_conv_without_host_read():
     ya, yb = m(x, anchor), ref(x, anchor)
     assert torch.allclose(ya, yb, rtol=1e-5, atol=1e-5 * float(yb.abs().max()))
     assert m.last_rulebook.check() == ref.last_rulebook.total
+
+
+def _representative_reference(feat, idx, weight, batch, shape, K):
+    """``duplicates="last"`` stated directly (fp64, differentiable): a hash of cell -> the LARGEST point index in it, then
+    out[i] = sum_k feat[table[cell(i) + offset_k]] . W[k] -- what spconv's SubMConv3d computes when that duplicate is the
+    one its hash insert kept."""
+    X, Y, Z = shape
+    table = {}
+    for i, (b, x, y, z) in enumerate(idx.tolist()):
+        if 0 <= b < batch and 0 <= x < X and 0 <= y < Y and 0 <= z < Z:
+            table[(b, x, y, z)] = i                      # ascending i: the last one stays
+    r = K // 2
+    rows = []
+    for i, (b, x, y, z) in enumerate(idx.tolist()):
+        acc = feat.new_zeros(weight.shape[2])
+        if (b, x, y, z) in table:
+            for kx in range(K):
+                for ky in range(K):
+                    for kz in range(K):
+                        j = table.get((b, x + kx - r, y + ky - r, z + kz - r))
+                        if j is not None:
+                            acc = acc + feat[j] @ weight[(kx * K + ky) * K + kz]
+        rows.append(acc)
+    return torch.stack(rows)
+
+
+def test_subm_conv_last_duplicate_mode():
+    """``duplicates="last"``: one representative per cell as the neighbour source (the spconv-compatible reading of points
+    that share a cell), forward and both gradients against the direct statement; without duplicates it equals "sum"."""
+    from gaussianformer_amd.sparse_conv import SparseConv3D, subm_conv3d
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(21)
+    N, batch, shape, K, cin, cout = 260, 2, (5, 6, 3), 3, 32, 32
+    idx = _points(rng, N, batch, shape, dup=0.5, outside=3)
+    g = torch.Generator().manual_seed(4)
+    feat, weight = torch.randn(N, cin, generator=g), torch.randn(K ** 3, cin, cout, generator=g) * 0.2
+    f64, w64 = feat.double().requires_grad_(True), weight.double().requires_grad_(True)
+    ref = _representative_reference(f64, idx, w64, batch, shape, K)
+    go = torch.randn(N, cout, generator=g)
+    ref.backward(go.double())
+    fd, wd = feat.to(dev).requires_grad_(True), weight.to(dev).requires_grad_(True)
+    out = subm_conv3d(fd, idx.to(dev), wd, batch, shape, K, duplicates="last")
+    out.backward(go.to(dev))
+    scale = float(ref.abs().max())
+    assert (out.detach().cpu().double() - ref.detach()).abs().max() <= 3e-5 * scale
+    assert (fd.grad.cpu().double() - f64.grad).abs().max() <= 3e-5 * (float(f64.grad.abs().max()) + 1e-6)
+    assert (wd.grad.cpu().double() - w64.grad).abs().max() <= 1e-4 * (float(w64.grad.abs().max()) + 1e-6)
+    # points that are not the representative of their cell are no source: no gradient reaches them
+    keys = [tuple(r) for r in idx.tolist()]
+    last = {k: i for i, k in enumerate(keys)}
+    shadowed = [i for i, k in enumerate(keys) if last[k] != i and 0 <= k[1] < shape[0]]
+    assert shadowed and float(fd.grad[shadowed].abs().max()) == 0.0
+    # and it differs from the default there
+    out_sum = subm_conv3d(feat.to(dev), idx.to(dev), weight.to(dev), batch, shape, K)
+    assert float((out_sum - out.detach()).abs().max()) > 1e-3
+    # no duplicates: the two modes are the same operator
+    uniq = torch.from_numpy(np.unique(idx.numpy(), axis=0))
+    fu = torch.randn(uniq.shape[0], cin, generator=g).to(dev)
+    a = subm_conv3d(fu, uniq.to(dev), weight.to(dev), batch, shape, K, duplicates="last")
+    b = subm_conv3d(fu, uniq.to(dev), weight.to(dev), batch, shape, K)
+    assert torch.equal(a, b)
+    # module keyword
+    m = SparseConv3D(32, 32, [0, 0, 0, 5, 6, 3], [1.0, 1.0, 1.0], kernel_size=3, duplicates="last").to(dev)
+    assert m.layer.duplicates == "last"
+    with pytest.raises(ValueError):
+        SparseConv3D(32, 32, [0, 0, 0, 5, 6, 3], [1.0, 1.0, 1.0], duplicates="first")
