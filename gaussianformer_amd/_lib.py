@@ -20,6 +20,7 @@ GF_PREPARE_MEAN_OUT_OF_GRID, GF_PREPARE_RADIUS_BELOW_ONE = 1, 2
 GF_PTS_AUTO, GF_PTS_ASSUME_DENSE, GF_PTS_GENERAL, GF_FAST_EXP, GF_LIBM_EXP, GF_COMP_EXP = 0, 1, 2, 4, 8, 16
 GF_PROB_NUMERATOR = 32
 GF_PROB_EXACT_DET = 64
+GF_MFMA_SPLAT = 128
 
 _vp, _i, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
 

@@ -45,11 +45,12 @@ struct PrepArgs {
     const int *radii;
     const float *cov3D;
     const int *points_int;
+    const float *pts;        // verification of the lattice only (GF_MFMA_SPLAT)
     float *records;
     uint2 *boxes;
     unsigned long long *bitmask;
-    uint32_t *verify_flags;  // [kVerifyBlocks]
-    int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det;
+    uint32_t *verify_flags;  // [kVerifyBlocks]: bit 0 = a point is not in its voxel, bit 1 = pts is not an exact affine lattice
+    int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det, lattice;
 };
 
 constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
@@ -100,11 +101,21 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         // ---- verification role: is point n in voxel n for all n?  Each wave reports its own
         // slice unconditionally (no zero-initialised flag needed).
         const int vb = ((int)blockIdx.x - a.nprep_blocks) * WAVES + wave;
-        bool bad = false;
+        bool bad = false, bad_lattice = false;
         const long long stride = (long long)kVerifyBlocks * 64;
+        // lattice (matrix-core render kernel only): pts[n] == p0 + index * step per axis, exactly, in fp64 -- the kernel
+        // evaluates its polynomial at those positions without reading pts
+        double p0x = 0, p0y = 0, p0z = 0, sx = 0, sy = 0, sz = 0;
+        if (a.lattice) {
+            p0x = a.pts[0]; p0y = a.pts[1]; p0z = a.pts[2];
+            sx = a.H > 1 ? (double)a.pts[3 * (size_t)a.W * a.D] - p0x : 1.0;
+            sy = a.W > 1 ? (double)a.pts[3 * (size_t)a.D + 1] - p0y : 1.0;
+            sz = a.D > 1 ? (double)a.pts[3 + 2] - p0z : 1.0;
+        }
         for (long long n0 = (long long)vb * 64 + lane; n0 < a.N; n0 += 4 * stride) {
             // four independent loads in flight per round trip
             int x[4], y[4], z[4];
+            float px[4] = {0, 0, 0, 0}, py[4] = {0, 0, 0, 0}, pz[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 // clamped, not conditional: `in ? load : 0` compiles to a branch around the load and the
@@ -113,18 +124,25 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 x[k] = a.points_int[3 * n];
                 y[k] = a.points_int[3 * n + 1];
                 z[k] = a.points_int[3 * n + 2];
+                if (a.lattice) {  // kernel-uniform
+                    px[k] = a.pts[3 * n]; py[k] = a.pts[3 * n + 1]; pz[k] = a.pts[3 * n + 2];
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const long long n = n0 + k * stride;
                 // unique decomposition of n: y in [0,W), z in [0,D) and the key equals n
-                if (n < a.N)
+                if (n < a.N) {
                     bad |= !(y[k] >= 0 && y[k] < a.W && z[k] >= 0 && z[k] < a.D &&
                              ((long long)x[k] * a.W + y[k]) * a.D + z[k] == n);
+                    if (a.lattice)
+                        bad_lattice |= !((double)px[k] == p0x + (double)x[k] * sx && (double)py[k] == p0y + (double)y[k] * sy &&
+                                         (double)pz[k] == p0z + (double)z[k] * sz);
+                }
             }
         }
-        const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
-        if (lane == 0) a.verify_flags[vb] = any ? 1u : 0u;
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(bad), any2 = __builtin_amdgcn_ballot_w64(bad_lattice);
+        if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u);
         return;
     }
     const int word = blockIdx.x * WAVES + wave;  // bitmask word of this wave
@@ -631,7 +649,7 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
 
     // Is pts the dense voxel-centre grid?  (verdict of the prep kernel's verification waves)
     int nondense = 0;
-    if (a.verify_dense) nondense = __syncthreads_or((vf.x | vf.y | vf.z | vf.w) != 0u);
+    if (a.verify_dense) nondense = __syncthreads_or(((vf.x | vf.y | vf.z | vf.w) & 1u) != 0u);
     if (blockIdx.x == 0 && tid == 0 && a.state) a.state[0] = nondense ? 1u : 0u;
     if (nondense) {
         general_body<VARIANT, EXP, LABELS>(a);
@@ -878,6 +896,422 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Matrix-core render kernel (base variant, dense lattice): GF_MFMA_SPLAT.
+//
+// The exponent of a (Gaussian, voxel) pair is a quadratic polynomial of the voxel's offset u from the centre of the
+// wave's double brick (pts is an exact affine lattice -- verified by the prep kernel -- so u is a half-integer vector):
+//     log2(e) * power = theta(g) . phi(u),   phi = (1, ux, uy, uz, ux^2 | uy^2, uz^2, ux uy, uy uz, ux uz)
+// theta is formed in fp64 from the record and split into three f16 terms, phi is exact in f16, so 32 Gaussians x 32
+// voxels are three v_mfma_f32_32x32x16_f16 (fp32 accumulate).  Then w = box ? exp2(.) : 0 on the 16 values a lane
+// holds, split into f16 hi + lo, and  C[channel, voxel] += (opacity * semantics)[channel, g] . w[g, voxel]  is six more
+// (hi.hi + hi.lo + lo.hi): the accumulator layout of step 1 (lane = voxel, register = Gaussian) IS the B-operand layout
+// of step 2, no lane traffic between them.  Measured against an fp64 evaluation (tools/microbench/dense_proto.hip):
+// 2e-6 for scales >= 0.08 m, 7e-6 down to 0.01 m -- the class of the prescaled VALU kernel.
+//
+// Work decomposition as in gf_splat_render_kernel (tile = workgroup, double brick = wave, the supertile's candidates in
+// an LDS list); the hits of a wave are compacted into a per-wave LDS queue (id + the four 32-voxel masks) and leave it
+// in groups of 32.  A 32-voxel block b of the double brick = lanes [32 (b&1), 32 (b&1) + 32) of brick b >> 1.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+union H8 {
+    h8 v;
+    fp16x2 p[4];
+    _Float16 e[8];
+};
+constexpr int kQCap = 96;  // hit queue entries per wave (a group of 32 leaves as soon as it is full; a batch adds <= 64)
+constexpr int kSRow = 36;  // floats per channel row of the staged opacity * semantics (32 Gaussians + pad: conflict-free b128 reads)
+
+// three f16 terms of an fp64 value (33 bits): the value as a (hi, lo) pair of floats, then exact fp32 residuals
+__device__ __forceinline__ void split3(double t, _Float16 &a, _Float16 &b, _Float16 &c)
+{
+    float hi = (float)t;
+    asm volatile("" : "+v"(hi));  // keeps (half)(float)double from becoming a software double -> half conversion
+    const float lo = (float)(t - (double)hi);
+    a = (_Float16)hi;
+    float r = (hi - (float)a) + lo;
+    asm volatile("" : "+v"(r));
+    b = (_Float16)r;
+    c = (_Float16)(r - (float)b);
+}
+
+template <bool LABELS>
+__global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderArgs a)
+{
+    constexpr int kStage = 4 * 64 * kC;
+    constexpr int kMem = kStage > kListCap ? kStage : kListCap;
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kMem + 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_queue[4][5][kQCap];
+    __shared__ __attribute__((aligned(16))) float s_sem[4][(kC + 1) * kSRow];  // row kC stays zero (channels 18..31 of the operand)
+    uint32_t *s_lg = s_mem;
+    uint32_t *s_scan = s_mem + kMem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int logical = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    const int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
+    const int X0 = (s / a.nsy) * kSuper;
+    const int Y0 = (s % a.nsy) * kSuper + t * kTileY;
+    const bool tile_ok = logical < a.ntiles_total && X0 < a.H && Y0 < a.W;
+    const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nwords;
+
+    uint4 vf = make_uint4(0, 0, 0, 0);
+    if (a.verify_dense) {
+        const uint4 *vp = reinterpret_cast<const uint4 *>(a.verify_flags) + 4 * tid;
+        const uint4 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
+        vf = make_uint4(v0.x | v1.x | v2.x | v3.x, v0.y | v1.y | v2.y | v3.y, v0.z | v1.z | v2.z | v3.z,
+                        v0.w | v1.w | v2.w | v3.w);
+    }
+    unsigned long long word_next = (tile_ok && tid < a.nwords) ? bm[tid] : 0ull;
+    int nondense = 0;
+    // bit 0: point n is not in voxel n; bit 1: pts is not an exact affine lattice -- either way the arbitrary-points body
+    if (a.verify_dense) nondense = __syncthreads_or((vf.x | vf.y | vf.z | vf.w) != 0u);
+    if (blockIdx.x == 0 && tid == 0 && a.state) a.state[0] = nondense ? 1u : 0u;
+    if (nondense) {
+        general_body<GF_SPLAT_BASE, kExpComp, LABELS>(a);
+        return;
+    }
+    if (!tile_ok) return;
+
+#if GF_TIMELINE
+    if (a.timeline && tid == 0) {
+        a.timeline[4 * (size_t)blockIdx.x] = wall_clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        a.timeline[4 * (size_t)gridDim.x + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    const int n = lane & 31, h = lane >> 5;
+    uint32_t *q_id = s_queue[wave][0];
+    float *S = s_sem[wave];
+    for (int i = lane; i < (kC + 1) * kSRow; i += 64) S[i] = 0.f;
+    const int Xw = X0 + 4 * (wave & 1);
+
+    // lattice of the voxel centres (fp64): position of voxel index i along an axis = p0 + i * step
+    using cflt_t = const float __attribute__((address_space(4))) *;
+    cflt_t cp = (cflt_t)(uintptr_t)a.pts;
+    const double p0x = cp[0], p0y = cp[1], p0z = cp[2];
+    const double sx = a.H > 1 ? (double)cp[3 * (size_t)a.W * a.D] - p0x : 1.0;
+    const double sy = a.W > 1 ? (double)cp[3 * (size_t)a.D + 1] - p0y : 1.0;
+    const double sz = a.D > 1 ? (double)cp[3 + 2] - p0z : 1.0;
+
+    // phi of this lane's voxel in each of the four blocks (B operand of step 1): half 0 holds monomials
+    // (1, ux, uy, uz, ux^2), half 1 (uy^2, uz^2, ux uy, uy uz, ux uz); the other three K slots are zero
+    h8 phi[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float ux = (float)(2 * (b & 1) + (n >> 4)) - 1.5f, uy = (float)((n >> 2) & 3) - 1.5f,
+                    uz = (float)(4 * (b >> 1) + (n & 3)) - 3.5f;
+        const float m0[8] = {1.f, ux, uy, uz, ux * ux, 0.f, 0.f, 0.f};
+        const float m1[8] = {uy * uy, uz * uz, ux * uy, uy * uz, ux * uz, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) phi[b][j] = (_Float16)(h ? m1[j] : m0[j]);
+    }
+
+    // One-hot coordinates of the voxel (B operand of the box term): half 0 = [lx == 0..3], [ly == 0..3], half 1 = [z == 0..7].
+    // With theta' = -32768 on the coordinates a Gaussian's box excludes, theta' . phi' is 0 inside the box and <= -32768
+    // outside, where exp2 flushes to exactly 0: the box test rides on a fourth MFMA instead of two VALU per weight.
+    h8 hot[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int lx = 2 * (b & 1) + (n >> 4), ly = (n >> 2) & 3, zz = 4 * (b >> 1) + (n & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hot[b][j] = (_Float16)((h ? zz == j : (j < 4 ? lx == j : ly == j - 4)) ? 1.f : 0.f);
+    }
+
+    for (int zg = 0; zg * 16 < a.D; ++zg) {
+        const int Zw = zg * 16 + (wave >> 1) * 8;
+        f32x16 acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        const double Cx = p0x + ((double)Xw + 1.5) * sx, Cy = p0y + ((double)Y0 + 1.5) * sy, Cz = p0z + ((double)Zw + 3.5) * sz;
+
+        int list_len = 0, w_next = 0, wi = 0, grp = 0, ngrp = 0, total = 0, off = 0, qlen = 0;
+        unsigned long long hits = 0ull;
+        bool done = false;
+        while (!done) {
+            // ---- producer: identical to gf_splat_render_kernel
+            while (true) {
+                if (grp < ngrp) {
+                    int gb = 0, ge = total;
+                    bool mine = true;
+                    if (ngrp > 1) {
+                        gb = (int)s_scan[8 + grp];
+                        ge = grp == 31 ? total : (int)s_scan[9 + grp];
+                        mine = (tid >> 3) == grp;
+                    }
+                    const int nn = __builtin_amdgcn_readfirstlane(ge - gb);
+                    if (nn > 0) {
+                        if (list_len + nn > kListCap) break;
+                        if (mine) {
+                            int pos = list_len + off - gb;
+                            while (hits) {
+                                const int j = __builtin_ctzll(hits);
+                                hits &= hits - 1;
+                                s_lg[pos++] = (uint32_t)(wi * 64 + j);
+                            }
+                        }
+                        list_len += nn;
+                    }
+                    if (++grp == ngrp) __syncthreads();
+                    continue;
+                }
+                if (w_next >= a.nwords) {
+                    done = true;
+                    break;
+                }
+                wi = w_next + tid;
+                w_next += kBlock;
+                const unsigned long long word = word_next;
+                word_next = (w_next + tid) < a.nwords ? bm[w_next + tid] : 0ull;
+                hits = word;
+                const int cnt = __builtin_popcountll(hits);
+                const int incl = wave_inclusive_scan(cnt);
+                if (lane == 63) s_scan[wave] = (uint32_t)incl;
+                __syncthreads();
+                off = incl - cnt;
+                total = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int c = (int)s_scan[w];
+                    if (w < wave) off += c;
+                    total += c;
+                }
+                total = __builtin_amdgcn_readfirstlane(total);
+                grp = 0;
+                ngrp = total == 0 ? 0 : (total <= kListCap ? 1 : 32);
+                if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
+                if (ngrp != 1) __syncthreads();
+            }
+            __syncthreads();  // list complete
+#if GF_TIMELINE
+            if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+#endif
+            // ---- consume: hits of this wave's double brick -> queue -> groups of 32.  After the last batch of the last
+            // list the remainder leaves as a partial group (the loop runs once for an empty final list).
+            uint32_t eg_n = 0;
+            uint2 box_n = make_uint2(0, 0);
+            if (list_len > 0) {
+                eg_n = s_lg[min(lane, list_len - 1)];
+                box_n = a.boxes[eg_n];
+            }
+            for (int base = 0; base < list_len || (done && base == 0); base += 64) {
+                const int i = base + lane;
+                const uint32_t eg = eg_n;
+                const uint2 box = box_n;
+                if (list_len > 0) {
+                    eg_n = s_lg[min(i + 64, list_len - 1)];
+                    box_n = a.boxes[eg_n];
+                }
+                uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+                if (i < list_len) {
+                    const uint32_t blo = box.x, bhi = box.y;
+                    const unsigned long long mxx = mask_x(clamp04(ux(blo) - Xw), clamp04(ux(bhi) - Xw));
+                    const uint32_t my = mask_y32(clamp04(uy(blo) - Y0), clamp04(uy(bhi) - Y0));
+                    const uint32_t mzA = my & mask_z32(clamp04(uz(blo) - Zw), clamp04(uz(bhi) - Zw));
+                    const uint32_t mzB = my & mask_z32(clamp04(uz(blo) - Zw - 4), clamp04(uz(bhi) - Zw - 4));
+                    m0 = (uint32_t)mxx & mzA; m1 = (uint32_t)(mxx >> 32) & mzA;
+                    m2 = (uint32_t)mxx & mzB; m3 = (uint32_t)(mxx >> 32) & mzB;
+                }
+                const bool hit = (m0 | m1 | m2 | m3) != 0u;
+                const unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
+                if (hit) {
+                    const int pos = qlen + (int)mbcnt(todo);
+                    q_id[pos] = eg;
+                    q_id[kQCap + pos] = m0; q_id[2 * kQCap + pos] = m1; q_id[3 * kQCap + pos] = m2; q_id[4 * kQCap + pos] = m3;
+                }
+                qlen += __builtin_popcountll(todo);
+                const bool last = done && base + 64 >= list_len;
+                while (qlen >= 32 || (last && qlen > 0)) {
+                    const int qn = min(qlen, 32);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // ---- operands of the group: lane (g = n, h)
+                    const bool live = n < qn;
+                    const uint32_t id = q_id[live ? n : 0];
+                    const float4 *rp = reinterpret_cast<const float4 *>(a.records + (size_t)id * kRecDwords);
+                    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                    const float4 e0 = rp[3 + 3 * h], e1 = rp[4 + 3 * h], e2 = rp[h ? 7 : 5];
+                    // opacity * semantics -> S[channel][g]; half 0 holds channels 0..11, half 1 channels 12..17
+                    {
+                        const float opa = live ? r0.w : 0.f;
+                        const float v[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+                        if (h == 0) {
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) S[k * kSRow + n] = opa * v[k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) S[(12 + k) * kSRow + n] = opa * v[k];
+                        }
+                    }
+                    // theta (A operand of step 1), fp64
+                    H8 t1, t2, t3;
+                    {
+                        const double L = 1.4426950408889634074;
+                        const double ex = Cx - (double)r0.x, ey = Cy - (double)r0.y, ez = Cz - (double)r0.z;
+                        const double c0 = r1.x, c1 = r1.y, c2 = r1.z, c3 = r1.w, c4 = r2.x, c5 = r2.y;
+                        const double gx = c0 * ex + c3 * ey + c5 * ez, gy = c3 * ex + c1 * ey + c4 * ez, gz = c5 * ex + c4 * ey + c2 * ez;
+                        const double lo5[5] = {-0.5 * L * (ex * gx + ey * gy + ez * gz), -L * sx * gx, -L * sy * gy, -L * sz * gz,
+                                               -0.5 * L * sx * sx * c0};
+                        const double hi5[5] = {-0.5 * L * sy * sy * c1, -0.5 * L * sz * sz * c2, -L * sx * sy * c3, -L * sy * sz * c4,
+                                               -L * sx * sz * c5};
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) split3(live ? (h ? hi5[j] : lo5[j]) : 0.0, t1.e[j], t2.e[j], t3.e[j]);
+#pragma unroll
+                        for (int j = 5; j < 8; ++j) { t1.e[j] = (_Float16)0.f; t2.e[j] = (_Float16)0.f; t3.e[j] = (_Float16)0.f; }
+                    }
+                    // theta' (A operand of the box term): -32768 where the coordinate lies outside the Gaussian's box
+                    H8 tb;
+                    {
+                        const uint32_t blo = __float_as_uint(r2.z), bhi = __float_as_uint(r2.w);
+                        const int x0 = ux(blo) - Xw, x1 = ux(bhi) - Xw, y0 = uy(blo) - Y0, y1 = uy(bhi) - Y0;
+                        const int z0 = uz(blo) - Zw, z1 = uz(bhi) - Zw;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const bool in = h ? (j >= z0 && j < z1) : (j < 4 ? (j >= x0 && j < x1) : (j - 4 >= y0 && j - 4 < y1));
+                            tb.e[j] = (_Float16)((in && live) ? 0.f : -32768.f);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // S' (A operand of step 2): lane (channel = n, h); K half kh, slot j <-> Gaussian (j&3) + 8 (2 kh + (j>>2)) + 4 h
+                    H8 sh[2], sl[2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(S + min(n, kC) * kSRow + 8 * q + 4 * h);
+                        const fp16x2 ha = __builtin_amdgcn_cvt_pkrtz(v4.x, v4.y), hb = __builtin_amdgcn_cvt_pkrtz(v4.z, v4.w);
+                        const fp16x2 la = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)ha[0], -1.0f, v4.x), __builtin_fmaf((float)ha[1], -1.0f, v4.y));
+                        const fp16x2 lb = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)hb[0], -1.0f, v4.z), __builtin_fmaf((float)hb[1], -1.0f, v4.w));
+                        sh[q >> 1].p[2 * (q & 1)] = ha; sh[q >> 1].p[2 * (q & 1) + 1] = hb;
+                        sl[q >> 1].p[2 * (q & 1)] = la; sl[q >> 1].p[2 * (q & 1) + 1] = lb;
+                    }
+                    // ---- the four 32-voxel blocks, two at a time.  Issue order (the wave issues in order, the matrix pipe runs
+                    // beside the VALU): exponents of blocks 0,1 | exponents of 2,3 | exp + split of 0, 1 (VALU, while 2,3 are in
+                    // the matrix pipe) | accumulation of 0,1 | exp + split of 2, 3 (while 0,1 accumulate) | accumulation of 2,3
+                    // (drains under the next group's operand preparation).  Two independent chains alternate in every MFMA run.
+                    f32x16 d[4];
+                    H8 wh[4][2], wl[4][2];
+                    auto exponents = [&](int b0) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) d[b0 + k][r] = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) d[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t3.v, phi[b0 + k], d[b0 + k], 0, 0, 0);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) d[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t2.v, phi[b0 + k], d[b0 + k], 0, 0, 0);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) d[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t1.v, phi[b0 + k], d[b0 + k], 0, 0, 0);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) d[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tb.v, hot[b0 + k], d[b0 + k], 0, 0, 0);
+                    };
+                    auto weights = [&](int b) {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const float w0 = __builtin_amdgcn_exp2f(d[b][r]), w1 = __builtin_amdgcn_exp2f(d[b][r + 1]);
+                            const fp16x2 hi = __builtin_amdgcn_cvt_pkrtz(w0, w1);
+                            float r0, r1;  // exact residuals w - hi, the f16 halves read in place (v_fma_mix_f32)
+                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(w0));
+                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(w1));
+                            wh[b][r >> 3].p[(r & 7) >> 1] = hi;
+                            wl[b][r >> 3].p[(r & 7) >> 1] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+                        }
+                    };
+                    auto accumulate2 = [&](int b0) {
+#pragma unroll
+                        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[kh].v, wh[b0 + k][kh].v, acc[b0 + k], 0, 0, 0);
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wl[b0 + k][kh].v, acc[b0 + k], 0, 0, 0);
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wh[b0 + k][kh].v, acc[b0 + k], 0, 0, 0);
+                        }
+                    };
+                    exponents(0);
+                    exponents(2);
+                    weights(0);
+                    weights(1);
+                    accumulate2(0);
+                    weights(2);
+                    weights(3);
+                    accumulate2(2);
+                    // ---- the rest of the queue moves down
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int rest = qlen - qn;
+                    uint32_t mv[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) mv[k] = lane < rest ? q_id[k * kQCap + 32 + lane] : 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rest) {
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) q_id[k * kQCap + lane] = mv[k];
+                    }
+                    qlen = rest;
+                }
+            }
+            __syncthreads();  // every wave is done with the list
+            list_len = 0;
+        }
+#if GF_TIMELINE
+        if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x + 2] = wall_clock64();
+#endif
+        // ---- accumulators C[channel (r&3) + 8 (r>>2) + 4 h][voxel n of block b] -> rows [voxel-in-brick][18] in LDS,
+        // then the same 16-byte stores as gf_splat_render_kernel; lower brick (blocks 0, 1), then upper (2, 3)
+        float *stage = reinterpret_cast<float *>(s_mem) + wave * (64 * kC);
+        if (!LABELS || a.out_logits) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int Zb = Zw + 4 * half;
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = (r & 3) + 8 * (r >> 2) + 4 * h;  // registers 10..15 hold channels >= 18: never stored
+                        if (c < kC) stage[(32 * bb + n) * kC + c] = acc[2 * half + bb][r];
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (Zb < a.D) {
+                    if ((a.D & 3) == 0) {
+                        for (int i = lane; i < 16 * kC; i += 64) {
+                            const int run = i / kC, k = i - run * kC;
+                            const int cx = Xw + (run >> 2), cy = Y0 + (run & 3);
+                            if (cx < a.H && cy < a.W) {
+                                const size_t row0 = ((size_t)cx * a.W + cy) * a.D + Zb;
+                                const float4 val = *reinterpret_cast<const float4 *>(stage + i * 4);
+                                store_row4(a.out_logits + row0 * kC + k * 4, val);
+                            }
+                        }
+                    } else {
+                        for (int i = lane; i < 64 * kC; i += 64) {
+                            const int l = i / kC, ch = i - l * kC;
+                            const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zb + (l & 3);
+                            if (cx < a.H && cy < a.W && cz < a.D)
+                                a.out_logits[(((size_t)cx * a.W + cy) * a.D + cz) * kC + ch] = stage[i];
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if ((zg + 1) * 16 < a.D) word_next = tid < a.nwords ? bm[tid] : 0ull;
+#if GF_TIMELINE
+        if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x + 3] = wall_clock64();
+#endif
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 struct BoxVolArgs {
     const int *means_int;
@@ -902,6 +1336,16 @@ __global__ __launch_bounds__(256) void gf_box_volumes_kernel(BoxVolArgs a)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if (lane_id() == 0 && s) atomicAdd(a.num_rendered, s);
+}
+
+static void launch_render_mfma(const RenderArgs &r, hipStream_t stream)
+{
+    const int per_xcd = (r.ntiles_total + 7) / 8;
+    hipEvent_t ev0, ev1;
+    const bool prof = profile_slot(&ev0, &ev1);
+    if (prof) (void)hipEventRecord(ev0, stream);
+    hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
+    if (prof) (void)hipEventRecord(ev1, stream);
 }
 
 template <int VARIANT, int EXP, bool LABELS>
@@ -1010,13 +1454,15 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
 
     PrepArgs pa;
     pa.means3D = means3D; pa.means_int = means3D_int; pa.opacity = opacity; pa.semantics = semantics;
-    pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.records = ws.records; pa.boxes = ws.boxes;
+    pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.pts = pts; pa.records = ws.records; pa.boxes = ws.boxes;
     pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
     pa.nwords = ws.nwords; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
     const int prep_waves = P >= 65536 ? 4 : 1;
     pa.variant = variant; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = verify ? 1 : 0;
-    pa.prescale = exp_flavour(variant, flags) == kExpFast ? 1 : 0;
+    const bool mfma = (flags & GF_MFMA_SPLAT) && variant == GF_SPLAT_BASE && dense_candidate && !lab.labels && P > 0;
+    pa.prescale = (!mfma && exp_flavour(variant, flags) == kExpFast) ? 1 : 0;  // the matrix-core kernel scales in fp64 itself
     pa.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
+    pa.lattice = (mfma && verify) ? 1 : 0;
     const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
@@ -1037,7 +1483,9 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.tile_perm = g_tile_perm;
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
-    if (variant == GF_SPLAT_BASE)
+    if (mfma)
+        launch_render_mfma(ra, stream);
+    else if (variant == GF_SPLAT_BASE)
         launch_render_exp<GF_SPLAT_BASE>(flags, dense_candidate, ra, stream);
     else
         launch_render_exp<GF_SPLAT_PROB>(flags, dense_candidate, ra, stream);

@@ -58,6 +58,10 @@ extern "C" {
  * cancellation noise on ill-conditioned Gaussians, including the NaN of a determinant that rounds negative); this
  * flag trades that parity for the correctly rounded value.  Pass the same flag to forward and backward. */
 #define GF_PROB_EXACT_DET 64
+/* Base variant, dense points: render on the matrix cores (split-f16 MFMA, fp32 accumulate).  Needs pts
+ * to be an exact affine lattice of voxel centres (verified on the device with GF_PTS_AUTO; asserted by the caller with
+ * GF_PTS_ASSUME_DENSE).  Ignored by the prob variant, the label epilogue and arbitrary points. */
+#define GF_MFMA_SPLAT 128
 
 int gf_abi_version(void);
 const char *gf_last_error(void);

@@ -1,0 +1,122 @@
+"""The matrix-core render kernel (GF_MFMA_SPLAT: base variant, dense lattice, split-f16 MFMA with fp32 accumulation)
+through the C ABI: same bound as the default kernel against the CPU oracle / the reference's own kernels (1e-4 scaled),
+the device-side lattice check, and the fallbacks."""
+import numpy as np
+import pytest
+
+import oracle
+from gaussianformer_amd.synthetic import make_splat_inputs
+
+from util import assert_logits_close, hip_splat_forward, prep
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [
+    # config, P, H, W, D
+    ("nuscenes_gs25600_solid", 300, 24, 20, 16),
+    ("nuscenes_gs25600_solid", 257, 23, 21, 16),   # H, W not multiples of the tile
+    ("nuscenes_gs25600_solid", 200, 20, 20, 10),   # D not a multiple of 4: scalar row stores, upper brick partly outside
+    ("nuscenes_gs25600_solid", 200, 20, 20, 40),   # several z groups per tile
+    ("nuscenes_gs25600_solid", 90, 9, 7, 4),       # grid smaller than one double brick
+    ("nuscenes_gs144000", 1000, 40, 44, 16),
+    ("nuscenes_gs25600_solid", 0, 12, 12, 8),      # only the appended whole-grid Gaussian
+]
+
+
+def _oracle_logits(si, pi, mi, radii, cov6):
+    return oracle.splat_forward(si.variant, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D)["logits"]
+
+
+@pytest.mark.parametrize("config,P,H,W,D", SMALL)
+def test_mfma_forward_small(gpu, config, P, H, W, D):
+    from gaussianformer_amd import _lib
+    si = make_splat_inputs(config, seed=3, P=P, H=H, W=W, D=D)
+    pi, mi, radii, cov6 = prep(si)
+    ref = _oracle_logits(si, pi, mi, radii, cov6)
+    for flags in (_lib.GF_MFMA_SPLAT, _lib.GF_MFMA_SPLAT | _lib.GF_PTS_ASSUME_DENSE):
+        got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
+        assert_logits_close(got["logits"], ref, tol=1e-4)
+
+
+def test_mfma_membership_is_exact(gpu):
+    """Sigma^-1 = 0, opacity = semantics = 1: every covered voxel receives exactly 1 per covering Gaussian -- the box
+    term of the exponent (0 inside, <= -32768 outside) and the split-f16 accumulation are exact on these values."""
+    from gaussianformer_amd import _lib
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=6, P=2000, H=40, W=36, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    si.opacities[:] = 1.0
+    si.semantics[:] = 1.0
+    cov6 = np.zeros_like(cov6)
+    ref = _oracle_logits(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    assert np.array_equal(got["logits"], ref)
+
+
+def test_mfma_crowded_tile(gpu):
+    """Thousands of Gaussians in one supertile: list refills, queue carried across them, many groups per wave."""
+    from gaussianformer_amd import _lib
+    si = make_splat_inputs("nuscenes_gs144000", seed=9, P=6000, H=20, W=20, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    ref = _oracle_logits(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    assert_logits_close(got["logits"], ref, tol=1e-4)
+
+
+def test_mfma_inexact_lattice_falls_back(gpu):
+    """pts one ulp off the lattice in a few voxels (still inside their voxels): the device-side check must notice -- the
+    kernel evaluates its polynomial on the lattice, not on pts -- and the arbitrary-points body must produce the result
+    for the positions actually given.  Anisotropic but exact steps are a lattice and stay on the matrix cores."""
+    import torch
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import splat_forward
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=11, P=300, H=24, W=20, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    rng = np.random.default_rng(1)
+    pick = rng.choice(si.pts.shape[0], 50, replace=False)
+    si.pts[pick, 0] = np.nextafter(si.pts[pick, 0], np.float32(1e9))
+    ref = _oracle_logits(si, pi, mi, radii, cov6)          # the oracle reads pts: the perturbed positions
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
+    logits, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_MFMA_SPLAT)
+    assert int(state.view(torch.int32)[0]) == 1            # verdict: not usable as a dense lattice
+    assert_logits_close(logits.cpu().numpy(), ref, tol=1e-4)
+    # the thinnest Gaussians make one ulp visible: the result must be the one for the given positions, bit for bit the
+    # arbitrary-points kernel's
+    general, *_ = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_PTS_GENERAL | _lib.GF_COMP_EXP)
+    assert torch.equal(general, logits)
+
+
+@pytest.mark.parametrize("config", ["nuscenes_gs25600_solid", "nuscenes_gs144000"])
+def test_mfma_forward_full_size(gpu, config):
+    """BASELINE shapes: against the reference's own kernels when oracle/_ref is built, else the CPU oracle; linear in the
+    semantics; deterministic."""
+    from gaussianformer_amd import _lib
+    from oracle import ref as oref
+    si = make_splat_inputs(config, seed=0)
+    pi, mi, radii, cov6 = prep(si)
+    if oref.available():
+        want = oref.splat_forward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D)["logits"]
+    else:
+        want = _oracle_logits(si, pi, mi, radii, cov6)
+    got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    assert_logits_close(got["logits"], want, tol=1e-4)
+    again, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    assert np.array_equal(again["logits"], got["logits"])
+    si.semantics *= np.float32(2.0)
+    twice, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    # (not bit-exact like the fp32 kernel: the low f16 halves of small operands are subnormal, where a factor 2 rounds anew)
+    assert np.allclose(twice["logits"], np.float32(2.0) * got["logits"], rtol=2e-6, atol=1e-6)
+
+
+def test_mfma_flag_is_ignored_where_it_does_not_apply(gpu):
+    """prob variant and arbitrary points: the flag changes nothing."""
+    from gaussianformer_amd import _lib
+    si = make_splat_inputs("prob_gs6400", seed=3, P=120, H=24, W=20, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    a, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    b, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=4, P=150, H=20, W=24, D=16, dense_pts=False, N=5000)
+    pi, mi, radii, cov6 = prep(si)
+    a, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    b, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    assert np.array_equal(a["logits"], b["logits"])

@@ -10,11 +10,12 @@ from gaussianformer_amd.local_aggregate import SplatForwardPlan
 from gaussianformer_amd.synthetic import make_splat_inputs
 import oracle
 config = sys.argv[1] if len(sys.argv) > 1 else "nuscenes_gs25600_solid"
+extra_flags = _lib.GF_MFMA_SPLAT if "mfma" in sys.argv[2:] else 0
 dev = torch.device("cuda:0")
 si = make_splat_inputs(config, seed=0)
 pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size, si.scale_multiplier)
 t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
-plan = SplatForwardPlan(0, *t, si.H, si.W, si.D, flags=1)
+plan = SplatForwardPlan(0, *t, si.H, si.W, si.D, flags=1 | extra_flags)
 lib = _lib.load()
 for _ in range(5): plan.run()
 torch.cuda.synchronize()
