@@ -305,6 +305,26 @@ def main():
             return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
                     "note": "same K steps as replays of one captured HIP graph (prep + render)"}
 
+        def mfma():
+            # the opt-in matrix-core render kernel (GF_MFMA_SPLAT), same K steps one at a time
+            if wl.variant != _lib.GF_SPLAT_BASE:
+                return None
+            plan = SplatForwardPlan(wl.variant, *wl.tensors, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO | _lib.GF_MFMA_SPLAT)
+            ref_out = wl.plan.run(wl.stream).clone()
+            got = plan.run(wl.stream)
+            err = float(((got - ref_out).abs() / ref_out.abs().clamp(min=1.0)).max())
+            for _ in range(max(2, args.warmup // 2)):
+                plan.run(wl.stream)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(args.steps):
+                plan.run(wl.stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t4
+            return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
+                    "max_scaled_diff_vs_default_kernel": err,
+                    "note": "same K steps with GF_MFMA_SPLAT: exponent and accumulation on the matrix cores (split-f16 MFMA, fp32 accumulate)"}
+
         def frames():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_frame
@@ -317,6 +337,7 @@ def main():
 
         extra("two_stream", two_stream)
         extra("hip_graph", hip_graph)
+        extra("mfma_kernel", mfma)
         extra("frames_per_s", frames)
 
     if not args.no_extras and use_dist:

@@ -940,10 +940,12 @@ __device__ __forceinline__ void split3(double t, _Float16 &a, _Float16 &b, _Floa
 template <bool LABELS>
 __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderArgs a)
 {
-    constexpr int kStage = 4 * 64 * kC;
-    constexpr int kMem = kStage > kListCap ? kStage : kListCap;
+    // the output staging area is NOT aliased onto the list here (two workgroups per CU leave the LDS for it): a wave that
+    // has consumed the last list goes straight to its epilogue while the slower waves of the tile are still accumulating
+    constexpr int kMem = kListCap;
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kMem + 64];
-    __shared__ __attribute__((aligned(16))) uint32_t s_queue[4][5][kQCap];
+    __shared__ __attribute__((aligned(16))) float s_stage[4][64 * kC];
+    __shared__ __attribute__((aligned(16))) uint32_t s_queue[4][kQCap];
     __shared__ __attribute__((aligned(16))) float s_sem[4][(kC + 1) * kSRow];  // row kC stays zero (channels 18..31 of the operand)
     uint32_t *s_lg = s_mem;
     uint32_t *s_scan = s_mem + kMem;
@@ -986,7 +988,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     }
 #endif
     const int n = lane & 31, h = lane >> 5;
-    uint32_t *q_id = s_queue[wave][0];
+    uint32_t *q_id = s_queue[wave];
     float *S = s_sem[wave];
     for (int i = lane; i < (kC + 1) * kSRow; i += 64) S[i] = 0.f;
     const int Xw = X0 + 4 * (wave & 1);
@@ -1109,23 +1111,14 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     eg_n = s_lg[min(i + 64, list_len - 1)];
                     box_n = a.boxes[eg_n];
                 }
-                uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+                // a hit = the Gaussian's box meets this wave's double brick (the per-voxel box test rides on the MFMAs)
+                bool hit = false;
                 if (i < list_len) {
                     const uint32_t blo = box.x, bhi = box.y;
-                    const unsigned long long mxx = mask_x(clamp04(ux(blo) - Xw), clamp04(ux(bhi) - Xw));
-                    const uint32_t my = mask_y32(clamp04(uy(blo) - Y0), clamp04(uy(bhi) - Y0));
-                    const uint32_t mzA = my & mask_z32(clamp04(uz(blo) - Zw), clamp04(uz(bhi) - Zw));
-                    const uint32_t mzB = my & mask_z32(clamp04(uz(blo) - Zw - 4), clamp04(uz(bhi) - Zw - 4));
-                    m0 = (uint32_t)mxx & mzA; m1 = (uint32_t)(mxx >> 32) & mzA;
-                    m2 = (uint32_t)mxx & mzB; m3 = (uint32_t)(mxx >> 32) & mzB;
+                    hit = ux(blo) < Xw + 4 && ux(bhi) > Xw && uy(blo) < Y0 + 4 && uy(bhi) > Y0 && uz(blo) < Zw + 8 && uz(bhi) > Zw;
                 }
-                const bool hit = (m0 | m1 | m2 | m3) != 0u;
                 const unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
-                if (hit) {
-                    const int pos = qlen + (int)mbcnt(todo);
-                    q_id[pos] = eg;
-                    q_id[kQCap + pos] = m0; q_id[2 * kQCap + pos] = m1; q_id[3 * kQCap + pos] = m2; q_id[4 * kQCap + pos] = m3;
-                }
+                if (hit) q_id[qlen + (int)mbcnt(todo)] = eg;
                 qlen += __builtin_popcountll(todo);
                 const bool last = done && base + 64 >= list_len;
                 while (qlen >= 32 || (last && qlen > 0)) {
@@ -1154,15 +1147,20 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     H8 t1, t2, t3;
                     {
                         const double L = 1.4426950408889634074;
-                        const double ex = Cx - (double)r0.x, ey = Cy - (double)r0.y, ez = Cz - (double)r0.z;
                         const double c0 = r1.x, c1 = r1.y, c2 = r1.z, c3 = r1.w, c4 = r2.x, c5 = r2.y;
-                        const double gx = c0 * ex + c3 * ey + c5 * ez, gy = c3 * ex + c1 * ey + c4 * ez, gz = c5 * ex + c4 * ey + c2 * ez;
-                        const double lo5[5] = {-0.5 * L * (ex * gx + ey * gy + ez * gz), -L * sx * gx, -L * sy * gy, -L * sz * gz,
-                                               -0.5 * L * sx * sx * c0};
-                        const double hi5[5] = {-0.5 * L * sy * sy * c1, -0.5 * L * sz * sz * c2, -L * sx * sy * c3, -L * sy * sz * c4,
-                                               -L * sx * sz * c5};
+                        double th[5];
+                        if (h == 0) {  // constant and linear terms + xx: the ones that depend on the brick
+                            const double ex = Cx - (double)r0.x, ey = Cy - (double)r0.y, ez = Cz - (double)r0.z;
+                            const double gx = c0 * ex + c3 * ey + c5 * ez, gy = c3 * ex + c1 * ey + c4 * ez, gz = c5 * ex + c4 * ey + c2 * ez;
+                            th[0] = -0.5 * L * (ex * gx + ey * gy + ez * gz);
+                            th[1] = -L * sx * gx; th[2] = -L * sy * gy; th[3] = -L * sz * gz;
+                            th[4] = -0.5 * L * sx * sx * c0;
+                        } else {
+                            th[0] = -0.5 * L * sy * sy * c1; th[1] = -0.5 * L * sz * sz * c2;
+                            th[2] = -L * sx * sy * c3; th[3] = -L * sy * sz * c4; th[4] = -L * sx * sz * c5;
+                        }
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) split3(live ? (h ? hi5[j] : lo5[j]) : 0.0, t1.e[j], t2.e[j], t3.e[j]);
+                        for (int j = 0; j < 5; ++j) split3(live ? th[j] : 0.0, t1.e[j], t2.e[j], t3.e[j]);
 #pragma unroll
                         for (int j = 5; j < 8; ++j) { t1.e[j] = (_Float16)0.f; t2.e[j] = (_Float16)0.f; t3.e[j] = (_Float16)0.f; }
                     }
@@ -1246,19 +1244,14 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     const int rest = qlen - qn;
-                    uint32_t mv[5];
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) mv[k] = lane < rest ? q_id[k * kQCap + 32 + lane] : 0u;
+                    const uint32_t mv = lane < rest ? q_id[32 + lane] : 0u;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    if (lane < rest) {
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) q_id[k * kQCap + lane] = mv[k];
-                    }
+                    if (lane < rest) q_id[lane] = mv;
                     qlen = rest;
                 }
             }
-            __syncthreads();  // every wave is done with the list
+            if (!done) __syncthreads();  // every wave is done with the list before it is refilled
             list_len = 0;
         }
 #if GF_TIMELINE
@@ -1266,7 +1259,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 #endif
         // ---- accumulators C[channel (r&3) + 8 (r>>2) + 4 h][voxel n of block b] -> rows [voxel-in-brick][18] in LDS,
         // then the same 16-byte stores as gf_splat_render_kernel; lower brick (blocks 0, 1), then upper (2, 3)
-        float *stage = reinterpret_cast<float *>(s_mem) + wave * (64 * kC);
+        float *stage = s_stage[wave];
         if (!LABELS || a.out_logits) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -1304,8 +1297,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();
-        if ((zg + 1) * 16 < a.D) word_next = tid < a.nwords ? bm[tid] : 0ull;
+        if ((zg + 1) * 16 < a.D) {
+            __syncthreads();  // the next z group rebuilds the list
+            word_next = tid < a.nwords ? bm[tid] : 0ull;
+        }
 #if GF_TIMELINE
         if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x + 3] = wall_clock64();
 #endif
