@@ -248,9 +248,9 @@ class _LocalAggregate(torch.autograd.Function):
     """model/head/localagg/local_aggregate/__init__.py:18-106."""
 
     @staticmethod
-    def forward(ctx, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D, H, W, D):
+    def forward(ctx, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D, H, W, D, flags=_lib.GF_PTS_AUTO):
         logits, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, pts, points_int, means3D, means3D_int,
-                                               opacities, semantics, radii, cov3D, H, W, D)
+                                               opacities, semantics, radii, cov3D, H, W, D, flags=flags)
         ctx.dims = (H, W, D)
         ctx.save_for_backward(state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii)
         return logits
@@ -264,7 +264,7 @@ class _LocalAggregate(torch.autograd.Function):
         # grads for (means3D, opacities, semantics, cov3D) only -- :91-104.  The reference returns the opacity
         # gradient as [P] whatever the input's shape; a [P,1] opacity that requires grad would be rejected by
         # autograd there, so it is reshaped here.
-        return None, None, mg, None, og.view_as(opacities), sg, None, cg, None, None, None
+        return None, None, mg, None, og.view_as(opacities), sg, None, cg, None, None, None, None
 
 
 class _LocalAggregateProb(torch.autograd.Function):
@@ -358,10 +358,13 @@ class LocalAggregator(_AggregatorBase):
     (model/head/localagg/local_aggregate/__init__.py:108-161).  ``check_inputs`` (extra keyword, default on)
     keeps the reference's per-call range asserts -- evaluated on the device, one host read instead of eight;
     ``check_inputs=False`` makes the call fully asynchronous (boxes of out-of-grid centres are then clipped
-    the way ``getRect`` clips them)."""
+    the way ``getRect`` clips them).  ``matrix_cores=True`` (extra keyword, default off) renders the forward with the
+    split-f16 MFMA kernel (``GF_MFMA_SPLAT``: ~1e-5 from the reference instead of ~1e-6, needs voxel centres that are
+    exactly representable; the backward is unchanged)."""
 
-    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, inv_softmax=False, check_inputs=True):
+    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, inv_softmax=False, check_inputs=True, matrix_cores=False):
         super().__init__()
+        self.matrix_cores = matrix_cores
         self.scale_multiplier = scale_multiplier
         self.H = H
         self.W = W
@@ -373,7 +376,8 @@ class LocalAggregator(_AggregatorBase):
         self._pc_min_host = [float(v) for v in pc_min]
 
     def _splat(self, *args):
-        return _LocalAggregate.apply(*args, self.H, self.W, self.D)
+        flags = _lib.GF_PTS_AUTO | (_lib.GF_MFMA_SPLAT if self.matrix_cores else 0)
+        return _LocalAggregate.apply(*args, self.H, self.W, self.D, flags)
 
     def forward(self, pts, means3D, opacities, semantics, scales, cov3D):
         pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D = self._prepare(
@@ -381,8 +385,7 @@ class LocalAggregator(_AggregatorBase):
         radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
         self._raise_on_violation(radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]   # (xx, yy, zz, xy, yz, xz) of the 3x3, :143
-        logits = _LocalAggregate.apply(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
-                                       self.H, self.W, self.D)
+        logits = self._splat(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D)
         assert not self.inv_softmax, "inv_softmax=True is an `assert False` in the reference too (:158-161)"
         return logits
 

@@ -120,3 +120,46 @@ def test_mfma_flag_is_ignored_where_it_does_not_apply(gpu):
     a, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
     b, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
     assert np.array_equal(a["logits"], b["logits"])
+
+
+def test_mfma_random_shapes_sweep(gpu):
+    """Seeded sweep over grid shapes, Gaussian counts and scale ranges (thin and wide Gaussians, with and without the
+    whole-grid one): the matrix-core kernel within the bound of the default one everywhere."""
+    from gaussianformer_amd import _lib
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for it in range(10):
+        H, W, D = int(rng.integers(5, 45)), int(rng.integers(5, 45)), int(rng.choice([4, 8, 12, 16, 24]))
+        P = int(rng.integers(1, 1500))
+        config = "nuscenes_gs144000" if it % 3 == 0 else "nuscenes_gs25600_solid"
+        si = make_splat_inputs(config, seed=100 + it, P=P, H=H, W=W, D=D)
+        pi, mi, radii, cov6 = prep(si)
+        ref = _oracle_logits(si, pi, mi, radii, cov6)
+        got, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+        assert_logits_close(got["logits"], ref, what=f"sweep {it} ({config}, P={P}, {H}x{W}x{D})", tol=1e-4)
+        worst = max(worst, float((np.abs(got["logits"].astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))).max()))
+    assert worst <= 1e-4
+
+
+def test_mfma_module_keyword_and_autograd(gpu):
+    """``LocalAggregator(..., matrix_cores=True)``: forward on the matrix cores, the same backward; gradients against the
+    exact module on the same inputs."""
+    import torch
+    from gaussianformer_amd.local_aggregate import LocalAggregator
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=12, P=400, H=24, W=24, D=16)
+    mods = [LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size, matrix_cores=mc).to(gpu)
+            for mc in (False, True)]
+    outs, grads = [], []
+    for m in mods:
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)[None]
+        means, opa, sem, cov = (t(si.means3D).requires_grad_(True), t(si.opacities).requires_grad_(True),
+                                t(si.semantics).requires_grad_(True), t(si.cov3D).requires_grad_(True))
+        out = m(t(si.pts), means, opa, sem, t(si.scales), cov)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        out.backward(torch.randn(out.shape, generator=g).to(gpu))
+        outs.append(out.detach())
+        grads.append([x.grad.clone() for x in (means, opa, sem, cov)])
+    assert float(((outs[0] - outs[1]).abs() / outs[0].abs().clamp(min=1.0)).max()) <= 1e-4
+    assert not torch.equal(outs[0], outs[1])                       # it really is the other kernel
+    for a, b in zip(*grads):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(a.abs().max()))   # the backward does not depend on the forward kernel
