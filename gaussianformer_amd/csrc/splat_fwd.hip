@@ -51,6 +51,8 @@ struct PrepArgs {
     unsigned long long *bitmask;
     uint32_t *verify_flags;  // [kVerifyBlocks]: bit 0 = a point is not in its voxel, bit 1 = pts is not an exact affine lattice
     int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det, lattice;
+    uint32_t *tile_counters;  // null, or the eight per-XCD tile counters of the matrix-core render kernel ...
+    uint32_t tile_counter_init;  // ... and the value they start from (the workgroups per XCD: those tiles are taken)
 };
 
 constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u);
         return;
     }
+    if (a.tile_counters && blockIdx.x == 0 && threadIdx.x < 8) a.tile_counters[64 * threadIdx.x] = a.tile_counter_init;
     const int word = blockIdx.x * WAVES + wave;  // bitmask word of this wave
     const int g = word * 64 + lane;
     const bool valid = g < a.P;
@@ -347,6 +350,7 @@ struct RenderArgs {
     int label_mode, empty_label;
     float threshold;
     int raw_numerator;  // prob variant: logits = sum sem * prob, not divided by prob_sum (GF_PROB_NUMERATOR)
+    uint32_t *tile_counters;  // matrix-core kernel: next unclaimed tile of XCD x at [64 x] (one cache line each)
 };
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
@@ -953,12 +957,19 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int per_xcd = (int)(gridDim.x >> 3);
-    const int logical = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    const int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
-    const int X0 = (s / a.nsy) * kSuper;
-    const int Y0 = (s % a.nsy) * kSuper + t * kTileY;
-    const bool tile_ok = logical < a.ntiles_total && X0 < a.H && Y0 < a.W;
+    // Persistent workgroups: two per CU, each walks tiles of ITS XCD (workgroup b runs on XCD b % 8; consecutive logical
+    // tiles stay on one XCD so its L2 keeps their bitmask rows, boxes and records).  The first tile is the workgroup's slot,
+    // the following ones come from a per-XCD counter (zeroed by the prep kernel), claimed while the current tile's list is
+    // complete -- early enough to fetch the next tile's first bitmask words under the whole accumulation.
+    __shared__ int s_next;
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int per_xcd = (a.ntiles_total + 7) >> 3;  // logical tiles per XCD (the last XCD's tail may be short)
+    int local = (int)(blockIdx.x >> 3);
+    int logical = xcd * per_xcd + local;
+    int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
+    int X0 = (s / a.nsy) * kSuper;
+    int Y0 = (s % a.nsy) * kSuper + t * kTileY;
+    bool tile_ok = local < per_xcd && logical < a.ntiles_total && X0 < a.H && Y0 < a.W;
     const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nwords;
 
     uint4 vf = make_uint4(0, 0, 0, 0);
@@ -979,19 +990,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     }
     if (!tile_ok) return;
 
-#if GF_TIMELINE
-    if (a.timeline && tid == 0) {
-        a.timeline[4 * (size_t)blockIdx.x] = wall_clock64();
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
-        a.timeline[4 * (size_t)gridDim.x + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
-    }
-#endif
     const int n = lane & 31, h = lane >> 5;
     uint32_t *q_id = s_queue[wave];
     float *S = s_sem[wave];
     for (int i = lane; i < (kC + 1) * kSRow; i += 64) S[i] = 0.f;
-    const int Xw = X0 + 4 * (wave & 1);
 
     // lattice of the voxel centres (fp64): position of voxel index i along an axis = p0 + i * step
     using cflt_t = const float __attribute__((address_space(4))) *;
@@ -1025,8 +1027,22 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         for (int j = 0; j < 8; ++j) hot[b][j] = (_Float16)((h ? zz == j : (j < 4 ? lx == j : ly == j - 4)) ? 1.f : 0.f);
     }
 
+    const int nslots = per_xcd * 8;  // timeline slots (debug builds)
+    (void)nslots;
+    for (;;) {  // tiles of this workgroup
+    const int Xw = X0 + 4 * (wave & 1);
+    int next_local = per_xcd;  // "no more tiles" until the counter says otherwise
+#if GF_TIMELINE
+    if (a.timeline && tid == 0) {
+        a.timeline[4 * (size_t)logical] = wall_clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        a.timeline[4 * (size_t)nslots + logical] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     for (int zg = 0; zg * 16 < a.D; ++zg) {
         const int Zw = zg * 16 + (wave >> 1) * 8;
+        const bool last_zg = (zg + 1) * 16 >= a.D;
         f32x16 acc[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -1091,10 +1107,19 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
                 if (ngrp != 1) __syncthreads();
             }
-            __syncthreads();  // list complete
+            if (done && last_zg && tid == 0) s_next = (int)atomicAdd(a.tile_counters + 64 * xcd, 1u);
+            __syncthreads();  // list complete (and the next tile claimed)
 #if GF_TIMELINE
-            if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+            if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)logical + 1] = wall_clock64();
 #endif
+            if (done && last_zg) {
+                // first bitmask words of the next tile: in flight during the whole accumulation of this one
+                next_local = s_next;
+                const int nl = xcd * per_xcd + next_local;
+                const int ns = nl / kTilesPerSuper;
+                const bool nok = next_local < per_xcd && nl < a.ntiles_total;
+                word_next = (nok && tid < a.nwords) ? a.bitmask[(size_t)ns * a.nwords + tid] : 0ull;
+            }
             // ---- consume: hits of this wave's double brick -> queue -> groups of 32.  After the last batch of the last
             // list the remainder leaves as a partial group (the loop runs once for an empty final list).
             uint32_t eg_n = 0;
@@ -1189,57 +1214,48 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                         sh[q >> 1].p[2 * (q & 1)] = ha; sh[q >> 1].p[2 * (q & 1) + 1] = hb;
                         sl[q >> 1].p[2 * (q & 1)] = la; sl[q >> 1].p[2 * (q & 1) + 1] = lb;
                     }
-                    // ---- the four 32-voxel blocks, two at a time.  Issue order (the wave issues in order, the matrix pipe runs
-                    // beside the VALU): exponents of blocks 0,1 | exponents of 2,3 | exp + split of 0, 1 (VALU, while 2,3 are in
-                    // the matrix pipe) | accumulation of 0,1 | exp + split of 2, 3 (while 0,1 accumulate) | accumulation of 2,3
-                    // (drains under the next group's operand preparation).  Two independent chains alternate in every MFMA run.
-                    f32x16 d[4];
-                    H8 wh[4][2], wl[4][2];
-                    auto exponents = [&](int b0) {
+                    // ---- the four 32-voxel blocks, two at a time: exponents of a pair (two independent MFMA chains alternate), exp +
+                    // split of each (VALU), accumulation of the pair -- which drains in the matrix pipe under the next pair's
+                    // VALU work, the last one under the next group's operand preparation.
+                    auto pair = [&](int b0) {
+                        f32x16 d0, d1;
 #pragma unroll
-                        for (int k = 0; k < 2; ++k)
+                        for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t3.v, phi[b0], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t3.v, phi[b0 + 1], d1, 0, 0, 0);
+                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t2.v, phi[b0], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t2.v, phi[b0 + 1], d1, 0, 0, 0);
+                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t1.v, phi[b0], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t1.v, phi[b0 + 1], d1, 0, 0, 0);
+                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tb.v, hot[b0], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tb.v, hot[b0 + 1], d1, 0, 0, 0);
+                        H8 wh[2][2], wl[2][2];
+                        auto weights = [&](const f32x16 &d, int k) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) d[b0 + k][r] = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) d[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t3.v, phi[b0 + k], d[b0 + k], 0, 0, 0);
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) d[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t2.v, phi[b0 + k], d[b0 + k], 0, 0, 0);
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) d[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t1.v, phi[b0 + k], d[b0 + k], 0, 0, 0);
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) d[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tb.v, hot[b0 + k], d[b0 + k], 0, 0, 0);
-                    };
-                    auto weights = [&](int b) {
-#pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const float w0 = __builtin_amdgcn_exp2f(d[b][r]), w1 = __builtin_amdgcn_exp2f(d[b][r + 1]);
-                            const fp16x2 hi = __builtin_amdgcn_cvt_pkrtz(w0, w1);
-                            float r0, r1;  // exact residuals w - hi, the f16 halves read in place (v_fma_mix_f32)
-                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(w0));
-                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(w1));
-                            wh[b][r >> 3].p[(r & 7) >> 1] = hi;
-                            wl[b][r >> 3].p[(r & 7) >> 1] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-                        }
-                    };
-                    auto accumulate2 = [&](int b0) {
+                            for (int r = 0; r < 16; r += 2) {
+                                const float w0 = __builtin_amdgcn_exp2f(d[r]), w1 = __builtin_amdgcn_exp2f(d[r + 1]);
+                                const fp16x2 hi = __builtin_amdgcn_cvt_pkrtz(w0, w1);
+                                float r0, r1;  // exact residuals w - hi, the f16 halves read in place (v_fma_mix_f32)
+                                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(w0));
+                                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(w1));
+                                wh[k][r >> 3].p[(r & 7) >> 1] = hi;
+                                wl[k][r >> 3].p[(r & 7) >> 1] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+                            }
+                        };
+                        weights(d0, 0);
+                        weights(d1, 1);
 #pragma unroll
                         for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[kh].v, wh[b0 + k][kh].v, acc[b0 + k], 0, 0, 0);
+                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[kh].v, wh[k][kh].v, acc[b0 + k], 0, 0, 0);
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wl[b0 + k][kh].v, acc[b0 + k], 0, 0, 0);
+                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wl[k][kh].v, acc[b0 + k], 0, 0, 0);
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wh[b0 + k][kh].v, acc[b0 + k], 0, 0, 0);
+                            for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wh[k][kh].v, acc[b0 + k], 0, 0, 0);
                         }
                     };
-                    exponents(0);
-                    exponents(2);
-                    weights(0);
-                    weights(1);
-                    accumulate2(0);
-                    weights(2);
-                    weights(3);
-                    accumulate2(2);
+                    pair(0);
+                    pair(2);
                     // ---- the rest of the queue moves down
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -1255,7 +1271,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
             list_len = 0;
         }
 #if GF_TIMELINE
-        if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x + 2] = wall_clock64();
+        if (a.timeline && tid == 0) a.timeline[4 * (size_t)logical + 2] = wall_clock64();
 #endif
         // ---- accumulators C[channel (r&3) + 8 (r>>2) + 4 h][voxel n of block b] -> rows [voxel-in-brick][18] in LDS,
         // then the same 16-byte stores as gf_splat_render_kernel; lower brick (blocks 0, 1), then upper (2, 3)
@@ -1297,13 +1313,24 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if ((zg + 1) * 16 < a.D) {
+        if (!last_zg) {
             __syncthreads();  // the next z group rebuilds the list
             word_next = tid < a.nwords ? bm[tid] : 0ull;
         }
 #if GF_TIMELINE
-        if (a.timeline && tid == 0) a.timeline[4 * (size_t)blockIdx.x + 3] = wall_clock64();
+        if (a.timeline && tid == 0) a.timeline[4 * (size_t)logical + 3] = wall_clock64();
 #endif
+    }
+    // ---- next tile of this workgroup
+    local = next_local;
+    logical = xcd * per_xcd + local;
+    s = logical / kTilesPerSuper; t = logical % kTilesPerSuper;
+    X0 = (s / a.nsy) * kSuper;
+    Y0 = (s % a.nsy) * kSuper + t * kTileY;
+    if (!(local < per_xcd && logical < a.ntiles_total)) break;  // workgroup-uniform
+    bm = a.bitmask + (size_t)s * a.nwords;
+    __syncthreads();  // the slowest wave is done with the list and the scan scratch
+    if (!(X0 < a.H && Y0 < a.W)) { word_next = 0ull; }  // (cannot happen for logical < ntiles_total; keeps the list empty)
     }
 }
 
@@ -1333,13 +1360,25 @@ __global__ __launch_bounds__(256) void gf_box_volumes_kernel(BoxVolArgs a)
     if (lane_id() == 0 && s) atomicAdd(a.num_rendered, s);
 }
 
+// workgroups of the persistent matrix-core kernel: two per CU (252 VGPRs), a multiple of 8, at most one per tile slot
+static int mfma_grid(int ntiles_total)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    const int per_xcd = (ntiles_total + 7) / 8;
+    return 8 * std::min(per_xcd, std::max(1, 2 * cus / 8));
+}
+
 static void launch_render_mfma(const RenderArgs &r, hipStream_t stream)
 {
-    const int per_xcd = (r.ntiles_total + 7) / 8;
     hipEvent_t ev0, ev1;
     const bool prof = profile_slot(&ev0, &ev1);
     if (prof) (void)hipEventRecord(ev0, stream);
-    hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(per_xcd * 8), dim3(kBlock), 0, stream, r);
+    hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
     if (prof) (void)hipEventRecord(ev1, stream);
 }
 
@@ -1458,6 +1497,9 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.prescale = (!mfma && exp_flavour(variant, flags) == kExpFast) ? 1 : 0;  // the matrix-core kernel scales in fp64 itself
     pa.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
     pa.lattice = (mfma && verify) ? 1 : 0;
+    uint32_t *tile_counters = ws.flags + 4608;  // [64 x], x < 8: inside the 32 KB flag section, past the verdicts
+    pa.tile_counters = mfma ? tile_counters : nullptr;
+    pa.tile_counter_init = mfma ? (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8) : 0u;
     const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
@@ -1478,6 +1520,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.tile_perm = g_tile_perm;
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
+    ra.tile_counters = tile_counters;
     if (mfma)
         launch_render_mfma(ra, stream);
     else if (variant == GF_SPLAT_BASE)
