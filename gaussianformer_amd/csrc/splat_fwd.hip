@@ -948,7 +948,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     // has consumed the last list goes straight to its epilogue while the slower waves of the tile are still accumulating
     constexpr int kMem = kListCap;
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kMem + 64];
-    __shared__ __attribute__((aligned(16))) float s_stage[4][64 * kC];
+    __shared__ __attribute__((aligned(16))) float s_stage[4][2][64 * kC];  // per wave, per brick: no reuse inside a tile
     __shared__ __attribute__((aligned(16))) uint32_t s_queue[4][kQCap];
     __shared__ __attribute__((aligned(16))) float s_sem[4][(kC + 1) * kSRow];  // row kC stays zero (channels 18..31 of the operand)
     uint32_t *s_lg = s_mem;
@@ -1275,11 +1275,11 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 #endif
         // ---- accumulators C[channel (r&3) + 8 (r>>2) + 4 h][voxel n of block b] -> rows [voxel-in-brick][18] in LDS,
         // then the same 16-byte stores as gf_splat_render_kernel; lower brick (blocks 0, 1), then upper (2, 3)
-        float *stage = s_stage[wave];
         if (!LABELS || a.out_logits) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const int Zb = Zw + 4 * half;
+                float *stage = s_stage[wave][half];  // wave-private: only LDS ordering inside the wave is needed, the
+                const int Zb = Zw + 4 * half;        // global stores of the lower brick are not waited for
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                         const int c = (r & 3) + 8 * (r >> 2) + 4 * h;  // registers 10..15 hold channels >= 18: never stored
                         if (c < kC) stage[(32 * bb + n) * kC + c] = acc[2 * half + bb][r];
                     }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (Zb < a.D) {
                     if ((a.D & 3) == 0) {
@@ -1309,8 +1309,6 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                         }
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
             }
         }
         if (!last_zg) {
