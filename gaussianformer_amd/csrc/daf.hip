@@ -8,11 +8,14 @@
 //
 // Here one lane owns VEC (=4) consecutive channels of one sample point, so a point's 128
 // channels are 32 lanes x 16 B: every bilinear tap is one 512-B coalesced row read.  The
-// sampling location / visibility gate / tap geometry are shared by the point's lanes.  In
-// the backward pass grad_weights and grad_sampling_location are reduced across the
-// owning lanes with DPP-free butterfly shuffles and written by ONE lane with a plain
-// read-modify-write (each element has exactly one owner group), so only the scattered
-// grad_mc_ms_feat stream uses atomics.
+// sampling location / visibility gate / tap geometry are shared by the point's lanes.
+// Backward: grad_weights and grad_sampling_location are summed over the owning lanes (DPP
+// running sums in the nuScenes layout -- 8 lanes per group, 32 per point --, butterfly
+// shuffles otherwise) and STORED by one lane: every element has exactly one producer, so
+// the buffers must only be zero on entry.  grad_mc_ms_feat is accumulated pixel-major
+// (gf_daf_backward_sorted: taps bucketed by feature-map tile in two counting passes, then
+// one workgroup per tile adds its taps in a fixed order -- no float atomics, deterministic);
+// shapes the sort does not cover fall back to the reference's atomicAdd scatter.
 #include "gf_common.hpp"
 
 namespace gf {
