@@ -14,7 +14,8 @@
 // shuffles otherwise) and STORED by one lane: every element has exactly one producer, so
 // the buffers must only be zero on entry.  grad_mc_ms_feat is accumulated pixel-major
 // (gf_daf_backward_sorted: taps bucketed by feature-map tile in two counting passes, then
-// one workgroup per tile adds its taps in a fixed order -- no float atomics, deterministic);
+// one workgroup per tile adds its taps row by row in registers -- no float atomics; the order
+// of a row's taps follows integer LDS atomics, so the last bits may differ between runs);
 // shapes the sort does not cover fall back to the reference's atomicAdd scatter.
 #include "gf_common.hpp"
 
