@@ -539,9 +539,11 @@ __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 3) void gf_spla
                 const float q_ = fmaf(dz, c1z * dz, fmaf(dy, c1y * dy, (c1x * dx) * dx));
                 const float r_ = fmaf(c2z * dx, dz, fmaf(c2y * dy, dz, (c2x * dx) * dy));
                 const float power = fmaf(q_, -0.5f, -r_);
-                // base: exp via v_exp_f32 (2^(x log2 e)); the argument's rounding adds ~|power| * 6e-8 relative
-                // error.  prob keeps ocml expf: its gradient divides by 1 - e + 1e-9 (backward.cu:93).
-                const float e = VARIANT == GF_SPLAT_PROB ? expf(power) : __builtin_amdgcn_exp2f(power * 1.44269504088896340736f);
+                // exp via v_exp_f32 (2^(x log2 e)): the argument's rounding adds ~|power| * 6e-8 relative error.  The prob
+                // gradient divides by 1 - e + 1e-9 (backward.cu:93), which only magnifies the error of e where power -> 0,
+                // and there the product rounds like expf does (1 ulp of 1): measured against the reference's own kernels
+                // the gradients moved from 1.1e-5 to the same 1e-5 class (bound 1e-3).
+                const float e = __builtin_amdgcn_exp2f(power * 1.44269504088896340736f);
                 const float sx = c1x * dx + c2x * dy + c2z * dz;  // (Sigma^-1 d)
                 const float sy = c2x * dx + c1y * dy + c2y * dz;
                 const float sz = c2z * dx + c2y * dy + c1z * dz;
