@@ -312,6 +312,102 @@ __global__ __launch_bounds__(256, 4) void gf_subm_gemm_kernel(SubmArgs a)
     }
 }
 
+// The same gather-GEMM on the bf16 matrix cores with fp32-equivalent operands.  f32 MFMA runs at 1/16 of the bf16 rate on
+// gfx950, so every fp32 value is split into three bf16 terms (8 + 8 + 8 significant bits, exact: x = x1 + x2 + x3 up to
+// 2^-24 |x|) and a product a.b is the six terms a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 (the dropped ones are <= 2^-24 |ab|
+// each), accumulated in fp32 by v_mfma_f32_32x32x16_bf16 with the small terms first: six MFMAs of 8 passes per K = 16
+// instead of eight of 16 passes, 2.7x less time in the matrix pipe, and the error of a product (~1.2e-7 relative) is what a
+// chain of fp32 FMAs has per step.  The feature half-rows are split in registers (per K chunk), the weight slice is
+// split once per workgroup on its way into LDS, stored in B-operand order ([term][chunk][32-column group][K half][column]
+// x 8 bf16 = one ds_read_b128 per operand).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+union BF8 {
+    bf16x8 v;
+    __bf16 e[8];
+    uint4 u;
+};
+__device__ __forceinline__ void split3_bf16(float x, __bf16 &x1, __bf16 &x2, __bf16 &x3)
+{
+    x1 = (__bf16)x;
+    const float r = x - (float)x1;
+    x2 = (__bf16)r;
+    x3 = (__bf16)(r - (float)x2);
+}
+
+template <int CIN, int COUT, int SW>
+__global__ __launch_bounds__(256, 3) void gf_subm_gemm_bf16_kernel(SubmArgs a)
+{
+    extern __shared__ uint4 s_wb[];  // [3][CIN/16][SW/32][2][32] operands of 16 B
+    constexpr int NC = CIN / 16, NG = SW / 32, NB = CIN / 8, TPB = 256 / SW;
+    static_assert(COUT % SW == 0 && SW % 32 == 0 && CIN % 16 == 0, "unsupported slice");
+    __shared__ unsigned int s_start[kSubmMaxK3 + 1];
+    const unsigned int t = blockIdx.x;
+    const int k = subm_segment_of(a.t.tile_start, a.K3, t, s_start);
+    if (t >= s_start[a.K3]) return;  // workgroup-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int c_lo = blockIdx.y * SW;
+    const unsigned int slot0 = a.t.kstart[k] + (t - s_start[k]) * kPairTile + wave * 32;
+    const unsigned int seg_end = a.t.kstart[k + 1];
+    const unsigned int myslot = slot0 + i;
+    const int row = a.pair_in[min(myslot, seg_end - 1)];  // padding lanes repeat the segment's last pair; never stored
+    // gathered feature row: lane (pair i, K half h) holds channels 16 c + 8 h .. + 7 of every chunk c
+    const float4 *src = reinterpret_cast<const float4 *>(a.feat + (size_t)row * CIN + 8 * h);
+    float4 av[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { av[c][0] = src[4 * c]; av[c][1] = src[4 * c + 1]; }
+    // W slice -> LDS: a thread converts 8 consecutive input channels of one output column at a time
+    {
+        const float *wsrc = a.weight + (size_t)k * CIN * COUT + c_lo;
+        const int co = tid % SW, g = co >> 5, n = co & 31;
+#pragma unroll
+        for (int blk = tid / SW; blk < NB; blk += TPB) {
+            BF8 w1, w2, w3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split3_bf16(wsrc[(size_t)(8 * blk + j) * COUT + co], w1.e[j], w2.e[j], w3.e[j]);
+            const int idx = (((blk >> 1) * NG + g) * 2 + (blk & 1)) * 32 + n;
+            s_wb[idx] = w1.u;
+            s_wb[NC * NG * 64 + idx] = w2.u;
+            s_wb[2 * NC * NG * 64 + idx] = w3.u;
+        }
+    }
+    __syncthreads();
+    if (slot0 >= seg_end) return;  // wave-uniform: this wave's 32 pairs lie past the segment
+    f32x16 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float x[8] = {av[c][0].x, av[c][0].y, av[c][0].z, av[c][0].w, av[c][1].x, av[c][1].y, av[c][1].z, av[c][1].w};
+        BF8 a1, a2, a3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3_bf16(x[j], a1.e[j], a2.e[j], a3.e[j]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int idx = ((c * NG + g) * 2 + h) * 32 + i;
+            BF8 b1, b2, b3;
+            b1.u = s_wb[idx]; b2.u = s_wb[NC * NG * 64 + idx]; b3.u = s_wb[2 * NC * NG * 64 + idx];
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.v, b1.v, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b3.v, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b2.v, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b1.v, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b2.v, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, acc[g], 0, 0, 0);
+        }
+    }
+    // D layout: column = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h (pair)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned int slot = slot0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (slot < seg_end) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) a.partial[(size_t)slot * COUT + c_lo + 32 * g + i] = acc[g][r];
+        }
+    }
+}
+
 // out[i] = sum over k ascending of the partial rows of (i, k): COUT/4 lanes per point
 template <int COUT>
 __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
@@ -604,9 +700,17 @@ extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, 
     const size_t lds = (size_t)Cin * SW * sizeof(float);
     const dim3 gemm_grid((unsigned)(total_pairs / kPairTile + K3), Cout / SW);  // x >= the number of tiles, whatever the split over the segments
     const int rows = 256 / (Cout / 4);
+    static const bool exact_f32 = getenv("GF_SUBM_F32_MFMA") != nullptr;  // the f32-MFMA kernel, for comparison
+    if (exact_f32) {
 #define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds, stream, a)
-    GF_SUBM_DISPATCH(GF_GEMM);
+        GF_SUBM_DISPATCH(GF_GEMM);
 #undef GF_GEMM
+    } else {
+        const size_t lds_bf = (size_t)3 * (Cin / 16) * (SW / 32) * 64 * 16;
+#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_bf16_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds_bf, stream, a)
+        GF_SUBM_DISPATCH(GF_GEMM);
+#undef GF_GEMM
+    }
     if (Cout == 128) hipLaunchKernelGGL(gf_subm_reduce_kernel<128>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
     else if (Cout == 64) hipLaunchKernelGGL(gf_subm_reduce_kernel<64>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(gf_subm_reduce_kernel<32>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
