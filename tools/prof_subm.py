@@ -2,7 +2,7 @@
 import sys
 import torch
 sys.path.insert(0, ".")
-from gaussianformer_amd.sparse_conv import Rulebook, split_weight
+from gaussianformer_amd.sparse_conv import Rulebook
 dev = torch.device("cuda:0")
 A = int(sys.argv[1]) if len(sys.argv) > 1 else 25600
 xyz = torch.rand(A, 3, device=dev) * torch.tensor([160.0, 160.0, 16.0], device=dev)
@@ -13,6 +13,5 @@ go = torch.randn(A, 128, device=dev)
 for _ in range(5):
     rb = Rulebook(idx, 1, (160, 160, 16), 5)
     rb.apply(feat, w)
-    rb.apply(feat, w, split_weight(w, 5))
     rb.weight_grad(feat, go)
 torch.cuda.synchronize()
