@@ -43,9 +43,6 @@ SIGNATURES = {
     "gf_subm_rulebook_fill": (_i, [_i] * 6 + [_vp] * 4 + [_vp]),
     "gf_subm_rulebook_build": (_i, [_i] * 6 + [_vp, _vp, _sz, _vp, _vp, ctypes.c_longlong, _vp]),
     "gf_subm_conv_apply": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
-    "gf_subm_weight_split_bytes": (ctypes.c_size_t, [_i] * 3),
-    "gf_subm_weight_split": (_i, [_i] * 3 + [_vp] * 3),
-    "gf_subm_conv_apply_split": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
     "gf_subm_conv_weight_grad": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
     "gf_feature_maps_format": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "gf_head_labels": (_i, [ctypes.c_longlong, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),

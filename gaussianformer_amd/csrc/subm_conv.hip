@@ -56,7 +56,6 @@ struct SubmArgs {
     int N, batch, X, Y, Z, K, K3, Cin, Cout;
     long long cells;
     long long pair_capacity;  // > 0: the pair arrays hold this many entries; a larger rulebook raises total[1] bit 2 and stays empty
-    const uint4 *wsplit;      // null, or the weights as bf16 operand rows (gf_subm_weight_split)
 };
 
 constexpr unsigned long long kSubmOverCapacity = 4ull;  // bit of total[1]
@@ -335,27 +334,6 @@ __device__ __forceinline__ void split3_bf16(float x, __bf16 &x1, __bf16 &x2, __b
     x3 = (__bf16)(r - (float)x2);
 }
 
-// One thread converts 8 consecutive input channels of one output column of W[k] into the three bf16 operand rows:
-// the layout of a (k, slice) block of the table is the LDS layout of gf_subm_gemm_bf16_kernel.
-template <int CIN, int COUT, int SW>
-__global__ __launch_bounds__(256) void gf_subm_wsplit_kernel(const float *__restrict__ weight, uint4 *__restrict__ table, int K3)
-{
-    constexpr int NC = CIN / 16, NG = SW / 32, NB = CIN / 8, SL = COUT / SW;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (k, slice, blk, co)
-    if (e >= (long long)K3 * SL * NB * SW) return;
-    const int co = (int)(e % SW), blk = (int)((e / SW) % NB), sl = (int)((e / ((long long)SW * NB)) % SL), k = (int)(e / ((long long)SW * NB * SL));
-    const float *wsrc = weight + (size_t)k * CIN * COUT + sl * SW;
-    BF8 w1, w2, w3;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) split3_bf16(wsrc[(size_t)(8 * blk + j) * COUT + co], w1.e[j], w2.e[j], w3.e[j]);
-    const int g = co >> 5, n = co & 31;
-    const int idx = (((blk >> 1) * NG + g) * 2 + (blk & 1)) * 32 + n;
-    uint4 *dst = table + ((size_t)k * SL + sl) * (3 * NC * NG * 64);
-    dst[idx] = w1.u;
-    dst[NC * NG * 64 + idx] = w2.u;
-    dst[2 * NC * NG * 64 + idx] = w3.u;
-}
-
 template <int CIN, int COUT, int SW>
 __global__ __launch_bounds__(256, 3) void gf_subm_gemm_bf16_kernel(SubmArgs a)
 {
@@ -378,13 +356,8 @@ __global__ __launch_bounds__(256, 3) void gf_subm_gemm_bf16_kernel(SubmArgs a)
     float4 av[NC][2];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { av[c][0] = src[4 * c]; av[c][1] = src[4 * c + 1]; }
-    // W slice -> LDS: copied from the split table when the caller has one (a layer's weights are split once), else
-    // converted here, a thread taking 8 consecutive input channels of one output column at a time
-    if (a.wsplit) {
-        const uint4 *src4 = a.wsplit + ((size_t)k * (COUT / SW) + blockIdx.y) * (3 * NC * NG * 64);
-#pragma unroll
-        for (int e = tid; e < 3 * NC * NG * 64; e += 256) s_wb[e] = src4[e];  // 384 .. 3072 operands
-    } else {
+    // W slice -> LDS: a thread converts 8 consecutive input channels of one output column at a time
+    {
         const float *wsrc = a.weight + (size_t)k * CIN * COUT + c_lo;
         const int co = tid % SW, g = co >> 5, n = co & 31;
 #pragma unroll
@@ -708,57 +681,27 @@ extern "C" int gf_subm_rulebook_build(int N, int batch, int X, int Y, int Z, int
         else CALL(32, 32);                                            \
     } while (0)
 
-static size_t subm_wsplit_bytes(int K, int Cin, int Cout)
-{
-    const int SW = Cout >= 64 ? 64 : 32;
-    return (size_t)K * K * K * (Cout / SW) * 3 * (Cin / 16) * (SW / 32) * 64 * 16;
-}
-
-extern "C" size_t gf_subm_weight_split_bytes(int K, int Cin, int Cout)
-{
-    if (K < 1 || K > 7 || !(K & 1) || !gf::subm_channels_ok(Cin, Cout)) return 0;
-    return subm_wsplit_bytes(K, Cin, Cout);
-}
-
-extern "C" int gf_subm_weight_split(int K, int Cin, int Cout, const float *weight, void *split, void *stream_)
-{
-    using namespace gf;
-    hipStream_t stream = (hipStream_t)stream_;
-    GF_CHECK_ARG(K >= 1 && K <= 7 && (K & 1), "K must be odd and <= 7");
-    GF_CHECK_ARG(subm_channels_ok(Cin, Cout), "unsupported channels: Cin and Cout in {32, 64, 128}");
-    GF_CHECK_ARG(weight && split, "null pointer");
-    GF_CHECK_ARG(((uintptr_t)split & 15) == 0, "split table must be 16-byte aligned");
-    const int K3 = K * K * K, SW = Cout >= 64 ? 64 : 32;
-    const long long threads = (long long)K3 * (Cout / SW) * (Cin / 8) * SW;
-    const dim3 grid((unsigned)((threads + 255) / 256));
-#define GF_SPLIT(CI, CO) hipLaunchKernelGGL((gf_subm_wsplit_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), grid, dim3(256), 0, stream, weight, (uint4 *)split, K3)
-    GF_SUBM_DISPATCH(GF_SPLIT);
-#undef GF_SPLIT
-    GF_CHECK_LAUNCH();
-    return GF_OK;
-}
-
-static int subm_conv_apply_impl(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
-                                const float *features, const float *weight, const void *weight_split, const void *tables,
-                                const int *pair_in, float *partial, float *out, void *stream_)
+extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
+                                  const float *features, const float *weight, const void *tables, const int *pair_in,
+                                  float *partial, float *out, void *stream_)
 {
     using namespace gf;
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = subm_check(N, batch, X, Y, Z, K)) return rc;
     GF_CHECK_ARG(subm_channels_ok(Cin, Cout), "unsupported channels: Cin and Cout in {32, 64, 128}");
     if (N == 0) return GF_OK;
-    GF_CHECK_ARG(features && (weight || weight_split) && tables && pair_in && partial && out, "null pointer");
+    GF_CHECK_ARG(features && weight && tables && pair_in && partial && out, "null pointer");
     const int K3 = K * K * K;
     GF_CHECK_ARG(total_pairs >= 0 && total_pairs / kPairTile + K3 < (1ll << 31), "bad pair count");
     SubmArgs a = subm_args(N, batch, X, Y, Z, K, nullptr, const_cast<void *>(tables));
     a.Cin = Cin; a.Cout = Cout; a.feat = features; a.weight = weight; a.pair_in = const_cast<int *>(pair_in);
-    a.partial = partial; a.out = out; a.wsplit = (const uint4 *)weight_split;
+    a.partial = partial; a.out = out;
     const int SW = Cout >= 64 ? 64 : 32;  // output-channel slice per workgroup
     const size_t lds = (size_t)Cin * SW * sizeof(float);
     const dim3 gemm_grid((unsigned)(total_pairs / kPairTile + K3), Cout / SW);  // x >= the number of tiles, whatever the split over the segments
     const int rows = 256 / (Cout / 4);
     static const bool exact_f32 = getenv("GF_SUBM_F32_MFMA") != nullptr;  // the f32-MFMA kernel, for comparison
-    if (exact_f32 && weight) {
+    if (exact_f32) {
 #define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds, stream, a)
         GF_SUBM_DISPATCH(GF_GEMM);
 #undef GF_GEMM
@@ -773,24 +716,6 @@ static int subm_conv_apply_impl(int N, int batch, int X, int Y, int Z, int K, in
     else hipLaunchKernelGGL(gf_subm_reduce_kernel<32>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
     GF_CHECK_LAUNCH();
     return GF_OK;
-}
-
-extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
-                                  const float *features, const float *weight, const void *tables, const int *pair_in,
-                                  float *partial, float *out, void *stream)
-{
-    GF_CHECK_ARG(weight != nullptr, "null weight");
-    return subm_conv_apply_impl(N, batch, X, Y, Z, K, Cin, Cout, total_pairs, features, weight, nullptr, tables, pair_in,
-                                partial, out, stream);
-}
-
-extern "C" int gf_subm_conv_apply_split(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
-                                        const float *features, const void *weight_split, const void *tables,
-                                        const int *pair_in, float *partial, float *out, void *stream)
-{
-    GF_CHECK_ARG(weight_split != nullptr && ((uintptr_t)weight_split & 15) == 0, "null or misaligned split table");
-    return subm_conv_apply_impl(N, batch, X, Y, Z, K, Cin, Cout, total_pairs, features, nullptr, weight_split, tables, pair_in,
-                                partial, out, stream);
 }
 
 extern "C" int gf_subm_conv_weight_grad(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout,

@@ -83,9 +83,8 @@ class Rulebook:
                                 f"{total} neighbour pairs exceed the pair_capacity of {self.total}"))
         return total
 
-    def apply(self, features, weight, weight_split=None):
-        """``out[N, Cout]`` for ``features [N, Cin]`` and ``weight [K^3, Cin, Cout]`` (no autograd).  ``weight_split``
-        (from :func:`split_weight`) stands in for the per-workgroup conversion of the weights -- same result."""
+    def apply(self, features, weight):
+        """``out[N, Cout]`` for ``features [N, Cin]`` and ``weight [K^3, Cin, Cout]`` (no autograd)."""
         lib = _lib.load()
         features, weight = features.detach().to(f32).contiguous(), weight.detach().to(f32).contiguous()
         cin, cout = weight.shape[1], weight.shape[2]
@@ -93,13 +92,8 @@ class Rulebook:
         out = torch.empty(self.N, cout, dtype=f32, device=dev)
         partial = torch.empty(max(self.total, 1), cout, dtype=f32, device=dev)
         with torch.cuda.device(dev):
-            if weight_split is not None:
-                rc = lib.gf_subm_conv_apply_split(*self.dims, cin, cout, self.total, _lib.ptr(features), _lib.ptr(weight_split),
-                                                  _lib.ptr(self.tables), _lib.ptr(self.pair_in), _lib.ptr(partial), _lib.ptr(out),
-                                                  _lib.current_stream(dev))
-            else:
-                rc = lib.gf_subm_conv_apply(*self.dims, cin, cout, self.total, _lib.ptr(features), _lib.ptr(weight), _lib.ptr(self.tables),
-                                            _lib.ptr(self.pair_in), _lib.ptr(partial), _lib.ptr(out), _lib.current_stream(dev))
+            rc = lib.gf_subm_conv_apply(*self.dims, cin, cout, self.total, _lib.ptr(features), _lib.ptr(weight), _lib.ptr(self.tables),
+                                        _lib.ptr(self.pair_in), _lib.ptr(partial), _lib.ptr(out), _lib.current_stream(dev))
         _lib.check(rc, "gf_subm_conv_apply")
         return out
 
@@ -117,29 +111,12 @@ class Rulebook:
         return gw
 
 
-def split_weight(weight, kernel_size):
-    """The weights ``[K^3, Cin, Cout]`` as the bf16 operand table of ``gf_subm_conv_apply_split`` (uint8 tensor):
-    three bf16 terms per value in the matrix cores' B-operand order.  One launch; worth caching while the weights stand."""
-    _lib.require_gpu(weight)
-    lib = _lib.load()
-    w = weight.detach().to(f32).contiguous()
-    k = int(kernel_size)
-    nbytes = lib.gf_subm_weight_split_bytes(k, w.shape[1], w.shape[2])
-    if nbytes == 0:
-        raise RuntimeError(f"unsupported sparse-conv weight shape {tuple(w.shape)}")
-    table = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    with torch.cuda.device(w.device):
-        rc = lib.gf_subm_weight_split(k, w.shape[1], w.shape[2], _lib.ptr(w), _lib.ptr(table), _lib.current_stream(w.device))
-    _lib.check(rc, "gf_subm_weight_split")
-    return table
-
-
 class _SubMConv(Function):
     @staticmethod
-    def forward(ctx, features, weight, rulebook, weight_split=None):
+    def forward(ctx, features, weight, rulebook):
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, weight)
-        return rulebook.apply(features, weight, weight_split)
+        return rulebook.apply(features, weight)
 
     @staticmethod
     @once_differentiable
@@ -152,14 +129,13 @@ class _SubMConv(Function):
             g_feat = rb.apply(grad_out, weight.flip(0).transpose(1, 2))
         if ctx.needs_input_grad[1]:
             g_w = rb.weight_grad(features, grad_out)
-        return g_feat, g_w, None, None
+        return g_feat, g_w, None
 
 
 DUPLICATES = ("sum", "last")
 
 
-def subm_conv3d(features, indices, weight, batch_size, spatial_shape, kernel_size, rulebook=None, duplicates="sum",
-                weight_split=None):
+def subm_conv3d(features, indices, weight, batch_size, spatial_shape, kernel_size, rulebook=None, duplicates="sum"):
     """Functional submanifold convolution; ``indices`` int ``[N,4]`` = (batch, x, y, z),
     ``weight [K^3, Cin, Cout]`` (offsets in [K,K,K] order).  Returns ``[N, Cout]``.
 
@@ -174,7 +150,7 @@ def subm_conv3d(features, indices, weight, batch_size, spatial_shape, kernel_siz
     rb = rulebook if rulebook is not None else Rulebook(indices, batch_size, spatial_shape, kernel_size)
     if duplicates == "last":
         features = features * rb.representative_mask()
-    return _SubMConv.apply(features, weight, rb, weight_split)
+    return _SubMConv.apply(features, weight, rb)
 
 
 class SubMConv3d(nn.Module):
@@ -195,17 +171,9 @@ class SubMConv3d(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def _split_table(self):
-        """bf16 operand table of the current weights, rebuilt when they change (version counter / storage)."""
-        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
-        if getattr(self, "_split_key", None) != key:
-            self._split = split_weight(self.weight, self.kernel_size)
-            self._split_key = key
-        return self._split
-
     def forward(self, features, indices, batch_size, spatial_shape, rulebook=None):
         out = subm_conv3d(features, indices, self.weight, batch_size, spatial_shape, self.kernel_size, rulebook,
-                          duplicates=self.duplicates, weight_split=self._split_table())
+                          duplicates=self.duplicates)
         return out if self.bias is None else out + self.bias
 
 

@@ -253,11 +253,9 @@ int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const
  * advance (`pair_capacity` entries; partial f32 [pair_capacity, Cout]; pass pair_capacity as `total_pairs` below).  A
  * point set with more pairs than that leaves the rulebook EMPTY (apply returns zeros) and sets bit 2 of the refusal
  * word, which the caller reads whenever it next synchronises.
- * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  gf_subm_conv_apply multiplies on the bf16
- * matrix cores with fp32-equivalent operands (three bf16 terms per value, six partial products, fp32 accumulate: ~1e-7
- * relative per product; GF_SUBM_F32_MFMA=1 in the environment selects v_mfma_f32_32x32x2_f32, bitwise an fmaf chain);
- * the weight gradient runs on the f32 matrix cores.  Results are deterministic except the weight gradient of segments
- * longer than 512 pairs (float atomics between their chunks).
+ * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  Both products run on the f32 matrix
+ * cores (v_mfma_f32_32x32x2_f32: exact f32, an fmaf chain); results are deterministic except the weight gradient of
+ * segments longer than 512 pairs (float atomics between their chunks).
  */
 size_t gf_subm_tables_bytes(int N, int batch, int X, int Y, int Z, int K);
 int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
@@ -269,14 +267,6 @@ int gf_subm_rulebook_build(int N, int batch, int X, int Y, int Z, int K, const i
 int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
                        const float *features, const float *weight, const void *tables, const int *pair_in,
                        float *partial, float *out, void *stream);
-/* The weights of a layer as the bf16 operand rows gf_subm_conv_apply builds per workgroup (three bf16 terms per value,
- * B-operand order): split once per weight update with gf_subm_weight_split into gf_subm_weight_split_bytes(..) bytes
- * (16-byte aligned), then gf_subm_conv_apply_split takes the table in place of `weight` -- same result, bit for bit. */
-size_t gf_subm_weight_split_bytes(int K, int Cin, int Cout);
-int gf_subm_weight_split(int K, int Cin, int Cout, const float *weight, void *split, void *stream);
-int gf_subm_conv_apply_split(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
-                             const float *features, const void *weight_split, const void *tables, const int *pair_in,
-                             float *partial, float *out, void *stream);
 int gf_subm_conv_weight_grad(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
                              const float *features, const float *grad_out, const void *tables, const int *pair_in,
                              const int *pair_out, float *grad_weight, void *stream);

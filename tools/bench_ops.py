@@ -112,12 +112,6 @@ for A in (25600, 144000):
     sec = timed(lambda: rb.apply(feat_sc, w_sc), iters=10)
     report("subm_conv apply 5^3 128->128 (gather-GEMM + reduce)", f"A={A}", sec, 4 * (2 * rb.total * 128 + 125 * 128 * 128 + 2 * A * 128),
            {"pairs": rb.total, "TFLOPs": flops / sec / 1e12})
-    from gaussianformer_amd.sparse_conv import split_weight  # noqa: E402
-    sec_split = timed(lambda: split_weight(w_sc, 5), iters=10)
-    ws_sc = split_weight(w_sc, 5)
-    sec = timed(lambda: rb.apply(feat_sc, w_sc, ws_sc), iters=10)
-    report("subm_conv apply 5^3 128->128 with the cached weight-split table", f"A={A}", sec,
-           4 * (2 * rb.total * 128 + 125 * 128 * 128 + 2 * A * 128), {"pairs": rb.total, "TFLOPs": flops / sec / 1e12, "split_table_us": sec_split * 1e6})
     go_sc = torch.randn(A, 128, device=dev)
     sec = timed(lambda: rb.weight_grad(feat_sc, go_sc), iters=10)
     report("subm_conv weight gradient", f"A={A}", sec, 4 * (2 * rb.total * 128 + 125 * 128 * 128), {"pairs": rb.total, "TFLOPs": flops / sec / 1e12})
