@@ -15,9 +15,12 @@ into a full partial grid and the partial logits are summed with one RCCL all-red
 only runs data-parallel replicas (train.py:41-43, :86-91).
 
 Rank 0 prints ONE JSON line.  Next to ``value``, never instead of it:
-  N = 1  ``roofline`` (render kernel, hipEvents on the launch stream), ``cpu_baseline`` (C port of the reference kernels)
+  N = 1  ``roofline`` (render kernel, hipEvents on the launch stream in a separate loop after the headline's K steps;
+         ``op_frac`` = the whole op by the headline's own clock), ``cpu_baseline`` (C port of the reference kernels)
          and ``cpu_baseline_torch`` (vectorised PyTorch-CPU pair-list formulation), ``frames_per_s`` (one inference frame
-         of the whole hot path: 4 encoder blocks + head, tools/bench_frame.py), ``two_stream``, ``hip_graph``;
+         of the whole hot path: 4 encoder blocks + head, tools/bench_frame.py; eager and as one HIP graph), ``train_step``
+         (BASELINE config [2]: the native ops of a training step chained through autograd, tools/bench_step.py),
+         ``exact_fp32_kernel``, ``two_stream``, ``hip_graph``;
   N > 1  ``kernel_only`` (the same shards without the collective), ``gs144000`` (BASELINE config [4]: the 144 000-Gaussian
          set sharded N-way, with and without the all-reduce) and ``reduce_scatter_labels`` (reduce-scatter -> labels on the
          owned slab -> all-gather of labels).
@@ -36,7 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
-MIN_KERNEL_SAMPLES = 8
+KERNEL_SAMPLES = 16   # bracketed launches of the separate kernel-timing loop (>= 8)
 
 
 def headline_metric():
@@ -54,20 +57,22 @@ def algorithmic_bytes(P, N, C=18):
 
 def committed_traffic(config):
     """HBM bytes per launch from the committed PMC passes of this workload (profiles/traffic_*.json; FETCH_SIZE x2
-    correction applied there).  The counters cannot be read inside this process, so the figure is labelled with its
-    source; None if there is no pass for this config."""
+    correction applied there).  The counters cannot be read inside this process, so the figures are labelled with
+    their source.  Returns (render-kernel bytes, step bytes = prep + render kernels, note) or (None, None, None)."""
     import glob
     pattern = {"nuscenes_gs25600_solid": "traffic_r*.json", "nuscenes_gs144000": "traffic_gs144000_r*.json"}.get(config)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))) if pattern else []
     if not files:
-        return None, None
+        return None, None, None
     try:
         d = json.load(open(files[-1]))
-        return d.get("render_kernel_hbm_bytes_per_launch"), {
+        render, prep = d.get("render_kernel_hbm_bytes_per_launch"), d.get("prep_kernel_hbm_bytes_per_launch")
+        step = d.get("step_hbm_bytes", (render + prep) if (render is not None and prep is not None) else None)
+        return render, step, {
             "source": "committed rocprofv3 PMC pass " + os.path.relpath(files[-1], ROOT) + " (not measured in this run)",
-            "prep_kernel_hbm_bytes_per_launch": d.get("prep_kernel_hbm_bytes_per_launch")}
+            "render_kernel": d.get("render_kernel"), "prep_kernel_hbm_bytes_per_launch": prep}
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def cpu_baseline(si, pi, mi, radii, cov6, budget_s=10.0):
@@ -209,6 +214,14 @@ def main():
         def local(self, *_):
             return self.plan.run(self.stream)
 
+        def path(self):
+            """Which body rendered the last call (state block, word 1) and the device verdict bits (word 2)."""
+            w = self.plan.state_words()
+            names = {_lib.GF_PATH_EXACT_TILE: "gf_splat_render_kernel (exact-fp32 tile kernel)",
+                     _lib.GF_PATH_MATRIX_CORE: "gf_splat_render_mfma_kernel (split-f16 MFMA, fp32 accumulate)",
+                     _lib.GF_PATH_ARBITRARY: "arbitrary-points body (FALL-BACK: a device verdict failed)"}
+            return names.get(w[1], str(w[1])), w[2]
+
         def step(self):
             if not use_dist:
                 return self.plan.run(self.stream)
@@ -238,11 +251,8 @@ def main():
         wl.step()
     torch.cuda.synchronize()
 
-    # the dominant kernel is timed with hipEvents around sampled launches of the timed region (an event pair costs
-    # ~3 us of stream time; sampling keeps the region representative): at least MIN_KERNEL_SAMPLES of them
-    stride = max(1, args.steps // (2 * MIN_KERNEL_SAMPLES))
-    _lib.check(lib.gf_profile_stride(stride), "gf_profile_stride")
-    _lib.check(lib.gf_profile_enable(args.steps), "gf_profile_enable")
+    # ---- headline: exactly K steps, nothing else on the stream (no event records: a hipEvent pair costs ~3 us of
+    # stream time, which at --steps 20 used to bracket every timed launch)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -251,11 +261,19 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    buf = (ctypes.c_float * args.steps)()
-    n_ev = lib.gf_profile_read(buf, args.steps)
+
+    # ---- the dominant kernel, timed live in a SEPARATE loop after the headline: hipEvents around every launch of
+    # KERNEL_SAMPLES further steps of the same workload, on the stream the kernel is launched on
+    _lib.check(lib.gf_profile_stride(1), "gf_profile_stride")
+    _lib.check(lib.gf_profile_enable(KERNEL_SAMPLES), "gf_profile_enable")
+    for _ in range(KERNEL_SAMPLES):
+        wl.step()
+    torch.cuda.synchronize()
+    buf = (ctypes.c_float * KERNEL_SAMPLES)()
+    n_ev = lib.gf_profile_read(buf, KERNEL_SAMPLES)
     lib.gf_profile_enable(0)
-    lib.gf_profile_stride(1)
     kernel_ms = float(np.mean(buf[:n_ev])) if n_ev > 0 else None
+    kernel_name, verdict_bits = wl.path()
 
     extras = {}
 
@@ -305,14 +323,14 @@ def main():
             return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
                     "note": "same K steps as replays of one captured HIP graph (prep + render)"}
 
-        def mfma():
-            # the opt-in matrix-core render kernel (GF_MFMA_SPLAT), same K steps one at a time
+        def exact_kernel():
+            # the exact-fp32 VALU tile kernel (GF_EXACT_FP32: the default before the matrix-core kernel was), same K steps
             if wl.variant != _lib.GF_SPLAT_BASE:
                 return None
-            plan = SplatForwardPlan(wl.variant, *wl.tensors, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO | _lib.GF_MFMA_SPLAT)
+            plan = SplatForwardPlan(wl.variant, *wl.tensors, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO | _lib.GF_EXACT_FP32)
             ref_out = wl.plan.run(wl.stream).clone()
             got = plan.run(wl.stream)
-            err = float(((got - ref_out).abs() / ref_out.abs().clamp(min=1.0)).max())
+            err = float(((got - ref_out).abs() / got.abs().clamp(min=1.0)).max())
             for _ in range(max(2, args.warmup // 2)):
                 plan.run(wl.stream)
             torch.cuda.synchronize()
@@ -322,23 +340,33 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t4
             return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
-                    "max_scaled_diff_vs_default_kernel": err,
-                    "note": "same K steps with GF_MFMA_SPLAT: exponent and accumulation on the matrix cores (split-f16 MFMA, fp32 accumulate)"}
+                    "max_scaled_diff_of_the_default_kernel": err,
+                    "note": "same K steps with GF_EXACT_FP32: the exact-fp32 VALU tile kernel (2e-6 from the reference)"}
 
         def frames():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_frame
             out = {}
             for cfg, nf in (("nuscenes_gs25600_solid", 20), ("nuscenes_gs144000", 6)):
-                out[cfg] = bench_frame.run(cfg, frames=nf, warmup=2, device=str(dev))
+                out[cfg] = bench_frame.run(cfg, frames=nf, warmup=2, device=str(dev), graph=True)
             out["unit"] = "frames/s"
-            out["note"] = "one inference frame of the hot path per config (tools/bench_frame.py), single GPU, synthetic inputs in HBM"
+            out["note"] = ("one inference frame of the hot path per config (tools/bench_frame.py), single GPU, synthetic inputs in "
+                           "HBM; frames_per_s = eager launches, frames_per_s_graph = the same frame replayed as one captured HIP graph")
             return out
 
         extra("two_stream", two_stream)
         extra("hip_graph", hip_graph)
-        extra("mfma_kernel", mfma)
+        def train_step():
+            # BASELINE config [2]: the native ops of one training step chained through autograd (tools/bench_step.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_step
+            r = bench_step.run(anchors=25600, steps=5, warmup=2)
+            r["unit"] = "ms per step"
+            return r
+
+        extra("exact_fp32_kernel", exact_kernel)
         extra("frames_per_s", frames)
+        extra("train_step", train_step)
 
     if not args.no_extras and use_dist:
         def kernel_only():
@@ -395,11 +423,18 @@ def main():
         roofline = None
         if kernel_ms:
             achieved = abytes / (kernel_ms * 1e-3) / 1e9
-            traffic, traffic_note = committed_traffic(args.config) if single else (None, None)
+            traffic, traffic_step, traffic_note = committed_traffic(args.config) if single else (None, None, None)
+            op_achieved = abytes / (ms_per_step * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "kernel": "gf_splat_render_kernel", "kernel_us": kernel_ms * 1e3,
-                        "kernel_launches_timed": n_ev, "algorithmic_bytes": abytes}
+                        "kernel": kernel_name, "verdict_bits": verdict_bits, "kernel_us": kernel_ms * 1e3,
+                        "kernel_launches_timed": n_ev,
+                        "kernel_timing": f"hipEvents around each of {n_ev} launches of a separate loop run after the "
+                                         "headline's K steps (the headline loop records no events)",
+                        "algorithmic_bytes": abytes,
+                        # the whole op (prep + render launches) against the same roofline, by the headline's own clock
+                        "op_achieved": op_achieved, "op_frac": op_achieved / HBM_PEAK_GBS,
+                        "traffic_step": traffic_step}
             if traffic_note:
                 roofline["traffic_note"] = traffic_note
         out = {

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GF_LIB selects a development variant built by build.build(lib_name=...) (tools/ only)
 LIB_PATH = os.environ.get("GF_LIB") or os.path.join(_HERE, "csrc", "libgf_hip.so")
 
-GF_ABI_VERSION = 1
+GF_ABI_VERSION = 2
 GF_SPLAT_BASE, GF_SPLAT_PROB = 0, 1
 GF_NUM_CHANNELS = 18
 GF_LABELS_ARGMAX, GF_LABELS_PROB_THRESHOLD, GF_LABELS_PROB_GEOSEM = 0, 1, 2
@@ -21,6 +21,8 @@ GF_PTS_AUTO, GF_PTS_ASSUME_DENSE, GF_PTS_GENERAL, GF_FAST_EXP, GF_LIBM_EXP, GF_C
 GF_PROB_NUMERATOR = 32
 GF_PROB_EXACT_DET = 64
 GF_MFMA_SPLAT = 128
+GF_EXACT_FP32 = 256
+GF_PATH_EXACT_TILE, GF_PATH_MATRIX_CORE, GF_PATH_ARBITRARY = 0, 1, 2
 
 _vp, _i, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
 
@@ -50,8 +52,8 @@ SIGNATURES = {
     "gf_daf_prepare_backward": (_i, [_i] * 6 + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare": (_i, [_i] * 4 + [_vp, _f, _f, _i, _i] + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare_backward": (_i, [_i] * 2 + [_vp] * 5 + [_vp]),
-    "gf_key_points": (_i, [_i] * 4 + [_vp] * 4 + [_f] * 3 + [_vp, _vp]),
-    "gf_key_points_backward": (_i, [_i] * 4 + [_vp] * 4 + [_f] * 3 + [_vp] * 3 + [_vp]),
+    "gf_key_points": (_i, [_i] * 4 + [_vp] * 4 + [_f] * 3 + [_i, _vp, _vp]),
+    "gf_key_points_backward": (_i, [_i] * 4 + [_vp] * 4 + [_f] * 3 + [_i] + [_vp] * 3 + [_vp]),
     "gf_profile_enable": (_i, [_i]),
     "gf_profile_stride": (_i, [_i]),
     "gf_profile_read": (_i, [_vp, _i]),

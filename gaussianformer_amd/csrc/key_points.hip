@@ -21,6 +21,7 @@ struct KeyPointArgs {
     float pc_lo[3], pc_span[3];
     float scale_lo, scale_span, learned_scale;
     int n, anchor_dim, F, K;
+    int identity;  // bit 0: xyz_activation != "sigmoid" (centre columns used as they are, :79-80), bit 1: the same for the scale columns (:66-67)
 };
 
 constexpr float kSigmoidClamp = 9.21f;  // safe_sigmoid, model/utils/safe_ops.py:7-9
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(128) void gf_key_points_kernel(KeyPointArgs a)
     for (int k = 0; k < 10; ++k) raw[k] = row[k];
     float sg[6];  // activated centre (0..2) and scale (3..5) sigmoids
 #pragma unroll
-    for (int k = 0; k < 6; ++k) sg[k] = safe_sigmoid(raw[k]);
+    for (int k = 0; k < 6; ++k) sg[k] = (a.identity >> (k / 3)) & 1 ? raw[k] : safe_sigmoid(raw[k]);
     float gs[3], centre[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(128) void gf_key_points_kernel(KeyPointArgs a)
     float *ga = a.grad_anchor + (size_t)i * a.anchor_dim;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        ga[k] = g_centre[k] * a.pc_span[k] * safe_sigmoid_grad(raw[k], sg[k]);
-        ga[3 + k] = g_gs[k] * a.scale_span * safe_sigmoid_grad(raw[3 + k], sg[3 + k]);
+        ga[k] = g_centre[k] * a.pc_span[k] * ((a.identity & 1) ? 1.f : safe_sigmoid_grad(raw[k], sg[k]));
+        ga[3 + k] = g_gs[k] * a.scale_span * ((a.identity & 2) ? 1.f : safe_sigmoid_grad(raw[3 + k], sg[3 + k]));
     }
     const float w = q.w, x = q.x, y = q.y, z = q.z;
     const float gw = 2.f * (w * Dm[0][0] - z * Dm[0][1] + y * Dm[0][2] + z * Dm[1][0] + w * Dm[1][1] - x * Dm[1][2] - y * Dm[2][0] + x * Dm[2][1] + w * Dm[2][2]);
@@ -145,9 +146,9 @@ __global__ __launch_bounds__(128) void gf_key_points_kernel(KeyPointArgs a)
 }
 
 static int fill_args(KeyPointArgs &a, int n, int anchor_dim, int F, int K, const float *pc_range, float scale_lo, float scale_hi,
-                     float learned_scale)
+                     float learned_scale, int identity)
 {
-    a.n = n; a.anchor_dim = anchor_dim; a.F = F; a.K = K;
+    a.n = n; a.anchor_dim = anchor_dim; a.F = F; a.K = K; a.identity = identity;
     for (int k = 0; k < 3; ++k) { a.pc_lo[k] = pc_range[k]; a.pc_span[k] = pc_range[3 + k] - pc_range[k]; }
     a.scale_lo = scale_lo; a.scale_span = scale_hi - scale_lo; a.learned_scale = learned_scale;
     return 0;
@@ -156,16 +157,16 @@ static int fill_args(KeyPointArgs &a, int n, int anchor_dim, int F, int K, const
 }  // namespace gf
 
 extern "C" int gf_key_points(int n, int anchor_dim, int F, int K, const float *anchor, const float *learned, const float *fix_scale,
-                             const float *pc_range, float scale_lo, float scale_hi, float learnable_fixed_scale, float *key_points,
-                             void *stream_)
+                             const float *pc_range, float scale_lo, float scale_hi, float learnable_fixed_scale, int identity_activations,
+                             float *key_points, void *stream_)
 {
     using namespace gf;
-    GF_CHECK_ARG(n >= 0 && anchor_dim >= 10 && F >= 0 && F <= kMaxFix && K >= 0 && F + K > 0, "bad sizes");
+    GF_CHECK_ARG(n >= 0 && anchor_dim >= 10 && F >= 0 && F <= kMaxFix && K >= 0 && F + K > 0 && (identity_activations & ~3) == 0, "bad sizes");
     if (n == 0) return GF_OK;
     GF_CHECK_ARG(anchor && key_points && pc_range && (F == 0 || fix_scale) && (K == 0 || learned), "null pointer");
     KeyPointArgs a{};
     a.anchor = anchor; a.learned = learned; a.fix = fix_scale; a.key_points = key_points;
-    fill_args(a, n, anchor_dim, F, K, pc_range, scale_lo, scale_hi, learnable_fixed_scale);
+    fill_args(a, n, anchor_dim, F, K, pc_range, scale_lo, scale_hi, learnable_fixed_scale, identity_activations);
     hipLaunchKernelGGL(gf_key_points_kernel<false>, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream_, a);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -173,18 +174,18 @@ extern "C" int gf_key_points(int n, int anchor_dim, int F, int K, const float *a
 
 extern "C" int gf_key_points_backward(int n, int anchor_dim, int F, int K, const float *anchor, const float *learned,
                                       const float *fix_scale, const float *pc_range, float scale_lo, float scale_hi,
-                                      float learnable_fixed_scale, const float *grad_key_points, float *grad_anchor,
-                                      float *grad_learned, void *stream_)
+                                      float learnable_fixed_scale, int identity_activations, const float *grad_key_points,
+                                      float *grad_anchor, float *grad_learned, void *stream_)
 {
     using namespace gf;
-    GF_CHECK_ARG(n >= 0 && anchor_dim >= 10 && F >= 0 && F <= kMaxFix && K >= 0 && F + K > 0, "bad sizes");
+    GF_CHECK_ARG(n >= 0 && anchor_dim >= 10 && F >= 0 && F <= kMaxFix && K >= 0 && F + K > 0 && (identity_activations & ~3) == 0, "bad sizes");
     if (n == 0) return GF_OK;
     GF_CHECK_ARG(anchor && grad_key_points && grad_anchor && pc_range && (F == 0 || fix_scale) && (K == 0 || (learned && grad_learned)),
                  "null pointer");
     KeyPointArgs a{};
     a.anchor = anchor; a.learned = learned; a.fix = fix_scale; a.grad_kp = grad_key_points; a.grad_anchor = grad_anchor;
     a.grad_learned = grad_learned;
-    fill_args(a, n, anchor_dim, F, K, pc_range, scale_lo, scale_hi, learnable_fixed_scale);
+    fill_args(a, n, anchor_dim, F, K, pc_range, scale_lo, scale_hi, learnable_fixed_scale, identity_activations);
     hipLaunchKernelGGL(gf_key_points_kernel<true>, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream_, a);
     GF_CHECK_LAUNCH();
     return GF_OK;

@@ -419,8 +419,12 @@ __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
     const int i = blockIdx.x * ROWS + threadIdx.x / CG;
     const int lane = threadIdx.x & 63;
     const int gshift = lane & ~(CG - 1);  // first lane of this point's group inside the wave
-    const bool live = i < a.N && !(a.t.total[1] & kSubmOverCapacity);  // an over-capacity rulebook is empty: zeros
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // An over-capacity rulebook is empty.  Its output is NaN, not zero: a model that keeps running on a refused point set
+    // must not look healthy (Rulebook.check() names the cause; SparseConv3D polls it without blocking).
+    const bool over = (a.t.total[1] & kSubmOverCapacity) != 0;
+    const bool live = i < a.N && !over;
+    const float init = over ? __builtin_nanf("") : 0.f;
+    float4 acc = make_float4(init, init, init, init);
     const int *sf = a.t.slot_first + (size_t)(live ? i : 0) * a.K3;
     const unsigned short *cn = a.t.cnt + (size_t)(live ? i : 0) * a.K3;
     // the CG lanes of a point scan its K^3 counts together (most are zero), then walk the hits in
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
             }
         }
     }
-    if (i < a.N) reinterpret_cast<float4 *>(a.out + (size_t)i * COUT)[tc] = acc;  // zeros for an over-capacity rulebook
+    if (i < a.N) reinterpret_cast<float4 *>(a.out + (size_t)i * COUT)[tc] = acc;  // NaN for an over-capacity rulebook
 }
 
 // staging helpers of the weight gradient: thread tid owns float4 (tid + 256 u) of the 32 x C block, u < Q

@@ -20,17 +20,54 @@ _C18 = _lib.GF_NUM_CHANNELS
 class _Workspace:
     """Scratch reused across calls, one grow-only buffer per (device, stream): the kernels of a call run on torch's
     current stream, so two calls on different streams must not share records / bitmask / verdict words.  A buffer
-    is allocated while its stream is current, so the caching allocator frees it in that stream's order."""
+    is allocated while its stream is current, so the caching allocator frees it in that stream's order.  The cache is
+    bounded (least recently used of ``MAX_STREAMS`` entries goes): a process that keeps creating streams does not
+    accumulate a megabyte-plus per stream ever used, and a recycled stream handle meets at worst its own old buffer."""
+    MAX_STREAMS = 8
     _cache = {}
 
     @classmethod
     def get(cls, device, nbytes):
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-        buf = cls._cache.get(key)
+        buf = cls._cache.pop(key, None)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-            cls._cache[key] = buf
+        cls._cache[key] = buf              # most recently used last
+        while len(cls._cache) > cls.MAX_STREAMS:
+            cls._cache.pop(next(iter(cls._cache)))
         return buf
+
+
+_lattice_cache = {}
+
+
+def pts_is_exact_lattice(pts, H, W, D):
+    """Host-side twin of the device lattice verdict (``gf_splat_prep_kernel``): is ``pts [N,3]`` exactly
+    ``p0 + index * step`` per axis (fp64 comparison) in x-major / z-fastest order?  Evaluated once per tensor
+    (data pointer, version counter, shape) and cached -- the voxel grid of a model does not change between frames.
+    The modules use it to route grids whose centres are NOT exactly representable (e.g. a 0.4 m cell) to the
+    exact-fp32 kernel instead of letting the matrix-core kernel's device verdict send every frame to the slow
+    arbitrary-points body.  One host read on a cache miss."""
+    key = (pts.device.index, pts.data_ptr(), pts._version, tuple(pts.shape), H, W, D)
+    hit = _lattice_cache.get(key)
+    if hit is not None:
+        return hit
+    ok = False
+    if pts.dim() == 2 and pts.shape[0] == H * W * D and pts.shape[1] == 3:
+        g = pts.detach().reshape(H, W, D, 3).double()
+        p0 = g[0, 0, 0]
+        step = torch.stack([g[1, 0, 0, 0] - p0[0] if H > 1 else p0.new_ones(()),
+                            g[0, 1, 0, 1] - p0[1] if W > 1 else p0.new_ones(()),
+                            g[0, 0, 1, 2] - p0[2] if D > 1 else p0.new_ones(())])
+        ix = torch.arange(H, device=pts.device, dtype=torch.float64)[:, None, None]
+        iy = torch.arange(W, device=pts.device, dtype=torch.float64)[None, :, None]
+        iz = torch.arange(D, device=pts.device, dtype=torch.float64)[None, None, :]
+        ok = bool(((g[..., 0] == p0[0] + ix * step[0]) & (g[..., 1] == p0[1] + iy * step[1]) &
+                   (g[..., 2] == p0[2] + iz * step[2])).all().item())
+    if len(_lattice_cache) > 16:
+        _lattice_cache.clear()
+    _lattice_cache[key] = ok
+    return ok
 
 
 def _contig(t, dtype):
@@ -152,6 +189,10 @@ class SplatForwardPlan:
         if rc:
             _lib.check(rc, "gf_splat_forward")
         return self.logits
+
+    def state_words(self):
+        """(not-dense flag, GF_PATH_* of the body that rendered the last call, verdict bits) -- synchronises."""
+        return self.state[:12].view(torch.int32).tolist()
 
 
 class SplatForwardPipeline:
@@ -307,25 +348,25 @@ class _AggregatorBase(nn.Module):
         # model/head/localagg/local_aggregate/__init__.py:137-141
         points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
         means3D_int = ((means3D.detach() - self.pc_min) / self.grid_size).to(torch.int)
-        self._violations = None
+        violations = None
         if self.check_inputs:
             # the reference's range asserts (:138-140), evaluated on the device and read back ONCE per call by
-            # _raise_on_violation (the reference synchronises eight times here)
+            # _raise_on_violation (the reference synchronises eight times here).  Returned, not stored on the module:
+            # a module shared by several threads / streams stays re-entrant.
             hi = points_int.new_tensor([self.H, self.W, self.D])
-            self._violations = torch.stack([
+            violations = torch.stack([
                 (points_int < 0).any() | (points_int >= hi).any(),
                 (means3D_int < 0).any() | (means3D_int >= hi).any()])
-        return pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D
+        return pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D, violations
 
     _radii_mode = _lib.GF_RADII_SCALAR
 
-    def _raise_on_violation(self, radii):
+    def _raise_on_violation(self, violations, radii):
         """One host read for the three range conditions the reference asserts one by one
         (local_aggregate/__init__.py:138,140,142): same AssertionError, one synchronisation."""
         if not self.check_inputs:
             return
-        bad = torch.cat([self._violations, (radii < 1).any().reshape(1)]).tolist()
-        self._violations = None
+        bad = torch.cat([violations, (radii < 1).any().reshape(1)]).tolist()
         assert not bad[0], "points outside the voxel grid (points_int out of [0,H)x[0,W)x[0,D))"
         assert not bad[1], "Gaussian centres outside the voxel grid (means3D_int out of range)"
         assert not bad[2], "radii must be >= 1"
@@ -358,11 +399,16 @@ class LocalAggregator(_AggregatorBase):
     (model/head/localagg/local_aggregate/__init__.py:108-161).  ``check_inputs`` (extra keyword, default on)
     keeps the reference's per-call range asserts -- evaluated on the device, one host read instead of eight;
     ``check_inputs=False`` makes the call fully asynchronous (boxes of out-of-grid centres are then clipped
-    the way ``getRect`` clips them).  ``matrix_cores=True`` (extra keyword, default off) renders the forward with the
-    split-f16 MFMA kernel (``GF_MFMA_SPLAT``: ~1e-5 from the reference instead of ~1e-6, needs voxel centres that are
-    exactly representable; the backward is unchanged)."""
+    the way ``getRect`` clips them).
 
-    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, inv_softmax=False, check_inputs=True, matrix_cores=False):
+    ``matrix_cores`` (extra keyword) selects the forward kernel: ``None`` (default) = the library default, i.e. the
+    split-f16 MFMA kernel (``GF_MFMA_SPLAT``: ~2e-5 from the reference, tolerance 1e-4) whenever ``pts`` is the dense
+    grid of exactly representable voxel centres -- checked once per ``pts`` tensor on the host (``pts_is_exact_lattice``)
+    so that a grid that is not (e.g. a 0.4 m cell) goes straight to the exact-fp32 kernel -- ``True`` = request it
+    regardless of that check (the device verdict still guards every call), ``False`` = always the exact-fp32 kernel
+    (``GF_EXACT_FP32``: ~2e-6 from the reference).  The backward is the same exact-fp32 kernel in every case."""
+
+    def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, inv_softmax=False, check_inputs=True, matrix_cores=None):
         super().__init__()
         self.matrix_cores = matrix_cores
         self.scale_multiplier = scale_multiplier
@@ -375,15 +421,19 @@ class LocalAggregator(_AggregatorBase):
         self.check_inputs = check_inputs
         self._pc_min_host = [float(v) for v in pc_min]
 
-    def _splat(self, *args):
-        flags = _lib.GF_PTS_AUTO | (_lib.GF_MFMA_SPLAT if self.matrix_cores else 0)
-        return _LocalAggregate.apply(*args, self.H, self.W, self.D, flags)
+    def _splat(self, pts, *args):
+        if self.matrix_cores is None:
+            exact = pts.shape[0] == self.H * self.W * self.D and not pts_is_exact_lattice(pts, self.H, self.W, self.D)
+            flags = _lib.GF_PTS_AUTO | (_lib.GF_EXACT_FP32 if exact else 0)
+        else:
+            flags = _lib.GF_PTS_AUTO | (_lib.GF_MFMA_SPLAT if self.matrix_cores else _lib.GF_EXACT_FP32)
+        return _LocalAggregate.apply(pts, *args, self.H, self.W, self.D, flags)
 
     def forward(self, pts, means3D, opacities, semantics, scales, cov3D):
-        pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D = self._prepare(
+        pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D, violations = self._prepare(
             pts, means3D, opacities, semantics, scales, cov3D)
         radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
-        self._raise_on_violation(radii)
+        self._raise_on_violation(violations, radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]   # (xx, yy, zz, xy, yz, xz) of the 3x3, :143
         logits = self._splat(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D)
         assert not self.inv_softmax, "inv_softmax=True is an `assert False` in the reference too (:158-161)"
@@ -416,14 +466,14 @@ class LocalAggregatorProb(_AggregatorBase):
         return _LocalAggregateProb.apply(*args, self.H, self.W, self.D)
 
     def forward(self, pts, means3D, opas, semantics, scales, cov3D):
-        pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D = self._prepare(
+        pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D, violations = self._prepare(
             pts, means3D, opas, semantics, scales, cov3D)
         if self.per_axis_radii:
             radii = torch.ceil(scales * self.scale_multiplier / self.grid_size).to(torch.int)
         else:
             radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
         radii = radii.clamp(min=self.radii_min)
-        self._raise_on_violation(radii)
+        self._raise_on_violation(violations, radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
         return _LocalAggregateProb.apply(pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D,
                                          self.H, self.W, self.D)
@@ -433,14 +483,14 @@ class LocalAggregatorProb(_AggregatorBase):
         """Inference-only: ``(numerator [n,18], bin_logits [n], density [n], probability [n])`` with the
         un-normalised numerator (``GF_PROB_NUMERATOR``) -- what the shards of
         ``sharded.sharded_splat_forward_prob`` exchange before normalising."""
-        pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D = self._prepare(
+        pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D, violations = self._prepare(
             pts, means3D, opas, semantics, scales, cov3D)
         if self.per_axis_radii:
             radii = torch.ceil(scales * self.scale_multiplier / self.grid_size).to(torch.int)
         else:
             radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
         radii = radii.clamp(min=self.radii_min)
-        self._raise_on_violation(radii)
+        self._raise_on_violation(violations, radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
         numerator, bin_logits, density, probability, _ = splat_forward(
             _lib.GF_SPLAT_PROB, pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D,

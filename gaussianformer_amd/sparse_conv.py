@@ -20,8 +20,11 @@ class Rulebook:
 
     ``pair_capacity=None``: the pair count is read back once to size the pair arrays (spconv reads its pair counts
     the same way).  ``pair_capacity=n``: nothing is read back -- the arrays hold ``n`` pairs, a point set with more
-    pairs produces an empty rulebook (zero output) and a refusal flag that :meth:`check` raises on; call it at a
-    point where the stream is synchronised anyway."""
+    pairs produces an empty rulebook (NaN output: a refused point set must not look like a healthy zero) and a
+    refusal flag that :meth:`check` raises on; call it at a point where the stream is synchronised anyway, or use
+    :meth:`poll` (non-blocking: the status is copied to pinned host memory behind the build and read once that copy
+    has completed).  Note the memory side of a generous capacity: ``apply`` sizes its partial-row buffer
+    ``[pair_capacity, Cout]`` by it (32 KB per point at ``pairs_per_point=64``, Cout = 128)."""
 
     def __init__(self, indices, batch_size, spatial_shape, kernel_size, pair_capacity=None):
         _lib.require_gpu(indices)
@@ -45,6 +48,14 @@ class Rulebook:
                 rc = lib.gf_subm_rulebook_build(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes,
                                                 _lib.ptr(self.pair_in), _lib.ptr(self.pair_out), self.total, _lib.current_stream(dev))
                 _lib.check(rc, "gf_subm_rulebook_build")
+                # deferred check: status -> pinned host memory on the same stream, event behind the copy
+                # (not while a HIP graph is being captured: no host allocation there; check() still works after a replay)
+                self._status_event = None
+                if not torch.cuda.is_current_stream_capturing():
+                    self._host_status = torch.empty(2, dtype=torch.int64, pin_memory=True)
+                    self._host_status.copy_(self._status, non_blocking=True)
+                    self._status_event = torch.cuda.Event()
+                    self._status_event.record(torch.cuda.current_stream(dev))
                 return
             rc = lib.gf_subm_rulebook_count(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes,
                                             _lib.current_stream(dev))
@@ -77,11 +88,27 @@ class Rulebook:
         total, refused = self._status.tolist()
         self.checked = True
         if refused:
-            raise RuntimeError("sparse-conv rulebook refused: " +
-                               ("a cell holds more than 65535 points" if refused & 1 else
-                                "more than 2^31 - 1 neighbour pairs" if refused & 2 else
-                                f"{total} neighbour pairs exceed the pair_capacity of {self.total}"))
+            self._raise(total, refused)
         return total
+
+    def poll(self):
+        """Non-blocking :meth:`check` of a ``pair_capacity`` rulebook: ``None`` while the status copy is still in
+        flight, else the pair count -- raising like :meth:`check` if the point set was refused."""
+        if self.checked:
+            return self.total
+        if self._status_event is None or not self._status_event.query():
+            return None
+        total, refused = self._host_status.tolist()
+        self.checked = True
+        if refused:
+            self._raise(total, refused)
+        return total
+
+    def _raise(self, total, refused):
+        raise RuntimeError("sparse-conv rulebook refused: " +
+                           ("a cell holds more than 65535 points" if refused & 1 else
+                            "more than 2^31 - 1 neighbour pairs" if refused & 2 else
+                            f"{total} neighbour pairs exceed the pair_capacity of {self.total}"))
 
     def apply(self, features, weight):
         """``out[N, Cout]`` for ``features [N, Cin]`` and ``weight [K^3, Cin, Cout]`` (no autograd)."""
@@ -192,6 +219,7 @@ class SparseConv3D(nn.Module):
         # reports a point set that did not fit.  None = exact size, one host read per rulebook (like spconv).
         self.pairs_per_point = pairs_per_point
         self.last_rulebook = None
+        self._unchecked = []   # pair_capacity rulebooks whose status has not been seen yet (polled, never waited for)
         if use_multi_layer:
             self.layer = nn.ModuleList()
             for i in range(3):
@@ -227,7 +255,17 @@ class SparseConv3D(nn.Module):
         indices = self.voxel_indices(anchor)
         feats = instance_feature.flatten(0, 1)
         cap = None if self.pairs_per_point is None else int(self.pairs_per_point) * indices.shape[0]
+        # refusals of earlier calls surface here, without blocking: a refused rulebook already produced NaN features,
+        # this names the cause as soon as its status has reached the host
+        if self._unchecked and not torch.cuda.is_current_stream_capturing():
+            still = []
+            for old in self._unchecked:
+                if old.poll() is None:
+                    still.append(old)
+            self._unchecked = still[-8:]
         rb = self.last_rulebook = Rulebook(indices, bs, self._spatial, self.kernel_size, pair_capacity=cap)
+        if cap is not None and not rb.checked and rb._status_event is not None:
+            self._unchecked.append(rb)
         if isinstance(self.layer, SubMConv3d):
             out = self.layer(feats, indices, bs, self._spatial, rulebook=rb)
         else:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 1
+#define GF_ABI_VERSION 2
 
 /* error codes */
 #define GF_OK 0
@@ -58,10 +58,25 @@ extern "C" {
  * cancellation noise on ill-conditioned Gaussians, including the NaN of a determinant that rounds negative); this
  * flag trades that parity for the correctly rounded value.  Pass the same flag to forward and backward. */
 #define GF_PROB_EXACT_DET 64
-/* Base variant, dense points: render on the matrix cores (split-f16 MFMA, fp32 accumulate).  Needs pts
- * to be an exact affine lattice of voxel centres (verified on the device with GF_PTS_AUTO; asserted by the caller with
- * GF_PTS_ASSUME_DENSE).  Ignored by the prob variant, the label epilogue and arbitrary points. */
+/* Base variant, dense points: the forward renders on the matrix cores (split-f16 MFMA, fp32 accumulate; DESIGN.md
+ * §3.2b; measured 1.7e-5 / 3.1e-5 from the reference's own kernels at gs25600 / gs144000, tolerance 1e-4).  This is
+ * the DEFAULT whenever it applies: base variant, N == H*W*D without GF_PTS_GENERAL, no label epilogue, none of the
+ * three exp-flavour flags and no GF_EXACT_FP32.  It needs pts to be an exact affine lattice of voxel centres and
+ * quadratic-form coefficients inside the f16 range (|theta| < 3e4 by a per-Gaussian bound); with GF_PTS_AUTO both
+ * are verified on the device in the same launches and a call that fails either runs the arbitrary-points body
+ * instead (correct, ~7x slower; reported in the state block, see gf_splat_state_bytes) -- so callers whose voxel
+ * centres are not exactly representable (e.g. a 0.4 m cell) should pass GF_EXACT_FP32.  With GF_PTS_ASSUME_DENSE
+ * the caller asserts both conditions.  GF_MFMA_SPLAT requests this kernel explicitly (it overrides an exp-flavour
+ * flag); the prob variant, the label epilogue and arbitrary points ignore it. */
 #define GF_MFMA_SPLAT 128
+/* Forward on the exact-fp32 VALU tile kernel (2.3e-6 / 1.0e-6 from the reference; ascending-Gaussian summation order,
+ * bit-identical between the dense and the arbitrary-points bodies): the default until ABI version 1. */
+#define GF_EXACT_FP32 256
+
+/* values of word 1 of the state block after gf_splat_forward: which body rendered the call */
+#define GF_PATH_EXACT_TILE 0     /* exact-fp32 tile kernel (dense grid) */
+#define GF_PATH_MATRIX_CORE 1    /* split-f16 MFMA kernel (dense exact lattice) */
+#define GF_PATH_ARBITRARY 2      /* arbitrary-points body (pts not the dense grid, or a failed lattice / range verdict) */
 
 int gf_abi_version(void);
 const char *gf_last_error(void);
@@ -71,7 +86,12 @@ size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D);
 
 /* Bytes of the small per-call state block written by gf_splat_forward and read by
  * gf_splat_backward (replaces the geomBuffer/binningBuffer/imgBuffer triple the reference
- * saves in ctx: model/head/localagg/local_aggregate/__init__.py:52-62). */
+ * saves in ctx: model/head/localagg/local_aggregate/__init__.py:52-62).  uint32 words:
+ *   [0] 1 = pts is NOT the dense voxel-centre grid (the backward then builds voxel2pts), 0 = it is
+ *   [1] GF_PATH_* -- the body that rendered the forward (a GF_PATH_ARBITRARY on an N == H*W*D call is the slow
+ *       fall-back of a failed verdict: visible to the caller after its next synchronisation)
+ *   [2] verdict bits of the device-side checks: 1 = a point is not in its voxel, 2 = pts is not an exact affine
+ *       lattice, 4 = a Gaussian's quadratic-form coefficients may leave the f16 range (matrix-core kernel only) */
 size_t gf_splat_state_bytes(void);
 
 /*
@@ -332,17 +352,19 @@ int gf_daf_prepare_backward(int B, int A, int pts, int cams, int L, int G, const
  *   learned    f32 [n, K, 3]   raw output of learnable_fc (may be NULL when K == 0)
  *   fix_scale  f32 [F, 3]      device pointer, F <= 16
  *   pc_range   6 floats, HOST pointer
+ *   identity_activations  bit 0: xyz_activation is not "sigmoid" (the centre columns are used as they are, :79-80);
+ *                         bit 1: scale_activation is not "sigmoid" (:66-67).  0 = the reference configs.
  *   key_points f32 [n, F + K, 3]
  */
 int gf_key_points(int n, int anchor_dim, int F, int K, const float *anchor, const float *learned, const float *fix_scale,
-                  const float *pc_range, float scale_lo, float scale_hi, float learnable_fixed_scale, float *key_points,
-                  void *stream);
+                  const float *pc_range, float scale_lo, float scale_hi, float learnable_fixed_scale,
+                  int identity_activations, float *key_points, void *stream);
 
 /* Its gradient: grad_anchor [n, anchor_dim] (columns >= 10 are written as zero), grad_learned [n, K, 3]. */
 int gf_key_points_backward(int n, int anchor_dim, int F, int K, const float *anchor, const float *learned,
                            const float *fix_scale, const float *pc_range, float scale_lo, float scale_hi,
-                           float learnable_fixed_scale, const float *grad_key_points, float *grad_anchor,
-                           float *grad_learned, void *stream);
+                           float learnable_fixed_scale, int identity_activations, const float *grad_key_points,
+                           float *grad_anchor, float *grad_learned, void *stream);
 
 /* Time only every `every`-th dominant-kernel launch (default 1): the two event records cost a few
  * microseconds of stream time each, so sampling keeps the timed region close to the un-instrumented one. */

@@ -19,8 +19,9 @@ def safe_sigmoid(t):
 
 
 def key_points(anchor, instance_feature, fix_scale, learnable_fc_weight, learnable_fc_bias, pc_range, scale_range,
-               learnable_fixed_scale=1.0):
-    """SparseGaussian3DKeyPointsGenerator.forward (deformable_module.py:51-90) with the default sigmoid activations:
+               learnable_fixed_scale=1.0, xyz_activation="sigmoid", scale_activation="sigmoid"):
+    """SparseGaussian3DKeyPointsGenerator.forward (deformable_module.py:51-90); an activation other than "sigmoid"
+    leaves the columns as they are (:66-67, :79-80):
     ``[bs, A, 7 + k, 3]`` key points = Gaussian-frame offsets (fixed + learned) * scale, rotated by R(q)^T^T, plus the
     centre.  ``anchor [bs,A,>=10]`` is (xyz, scale, quaternion, ...) before activation.  Pinned through
     tests/golden/caller_dfa.npz (the sampling locations the reference caller handed to the op)."""
@@ -33,11 +34,16 @@ def key_points(anchor, instance_feature, fix_scale, learnable_fc_weight, learnab
         learned = safe_sigmoid(torch.nn.functional.linear(instance_feature, learnable_fc_weight, learnable_fc_bias)
                                .reshape(bs, A, k, 3)) - 0.5
         scale = torch.cat([scale, learned * learnable_fixed_scale], dim=-2)
-    gs = scale_range[0] + (scale_range[1] - scale_range[0]) * safe_sigmoid(anchor[..., None, 3:6])
+    gs = anchor[..., None, 3:6]
+    if scale_activation == "sigmoid":
+        gs = safe_sigmoid(gs)
+    gs = scale_range[0] + (scale_range[1] - scale_range[0]) * gs
     kp = scale * gs
     rot = rotation_matrix(anchor[..., 6:10]).transpose(-1, -2)           # :72-73
     kp = torch.matmul(rot[:, :, None], kp[..., None]).squeeze(-1)
-    xyz = safe_sigmoid(anchor[..., :3])
+    xyz = anchor[..., :3]
+    if xyz_activation == "sigmoid":
+        xyz = safe_sigmoid(xyz)
     lo = anchor.new_tensor(pc_range[:3])
     hi = anchor.new_tensor(pc_range[3:])
     return kp + (xyz * (hi - lo) + lo).unsqueeze(2)

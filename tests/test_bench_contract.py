@@ -46,9 +46,10 @@ def test_algorithmic_bytes_formula():
     # every op input read once + logits written once
     assert bench.algorithmic_bytes(25601, 640000) == 128 * 25601 + 24 * 640000 + 72 * 640000 == 64716928
     assert bench.algorithmic_bytes(144000, 640000) == 79872000
-    t, note = bench.committed_traffic("nuscenes_gs25600_solid")
+    t, step, note = bench.committed_traffic("nuscenes_gs25600_solid")
     assert t is None or (0.9 * 64716928 <= t <= 2 * 64716928 and "committed" in note["source"])
-    assert bench.committed_traffic("no_such_config") == (None, None)
+    assert step is None or step >= t        # the step's traffic = prep + render kernels
+    assert bench.committed_traffic("no_such_config") == (None, None, None)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert bench.headline_metric() == base["metric"].split(";")[0].strip()
 

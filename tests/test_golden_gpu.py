@@ -24,10 +24,12 @@ def test_splat_matches_reference_fixture(gpu, name):
                          semantics=d["semantics"], H=int(d["H"]), W=int(d["W"]), D=int(d["D"]))
     pi, mi, radii, cov6 = d["points_int"], d["means_int"], d["radii"], d["cov6"]
     prob = si.variant == "prob"
-    for flags in (0, _lib.GF_PTS_GENERAL):
+    # default flags (base variant on the dense grid: the matrix-core kernel, north_star's 1e-4 bound), the exact-fp32
+    # tile kernel and the arbitrary-points kernel (both 1e-5)
+    for flags, tol in ((0, 1e-5 if prob else 1e-4), (_lib.GF_EXACT_FP32, 1e-5), (_lib.GF_PTS_GENERAL, 1e-5)):
         got, t, state, fwd_t = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
         for k in (("logits", "bin_logits", "density", "probability") if prob else ("logits",)):
-            assert_logits_close(got[k], d[k], what=f"{name}: {k} vs reference fixture", tol=1e-5)
+            assert_logits_close(got[k], d[k], what=f"{name}: {k} vs reference fixture (flags {flags})", tol=tol)
         grads = hip_splat_backward(gpu, si, t, state, fwd_t, d["out_grad"], d["bin_grad"] if prob else None,
                                    d["density_grad"] if prob else None, flags=flags)
         for k, g in zip(("means3D_grad", "opacity_grad", "semantics_grad", "cov3D_grad"), grads):

@@ -128,7 +128,8 @@ def test_fused_label_epilogue_matches_separate_kernels(config, per_axis, dense):
     t = to_dev(dev, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
     prob = si.variant == "prob"
     variant = _lib.GF_SPLAT_PROB if prob else _lib.GF_SPLAT_BASE
-    logits, bl, de, pr, _ = splat_forward(variant, *t, si.H, si.W, si.D)
+    # the label epilogue lives in the exact-fp32 kernels: compare with the same kernels' separate forward
+    logits, bl, de, pr, _ = splat_forward(variant, *t, si.H, si.W, si.D, flags=_lib.GF_EXACT_FP32)
     for kw in ([dict()] if not prob else [dict(threshold=0.3), dict(combine_geosem=True)]):
         want = occupancy_labels(logits, bin_logits=bl, empty_label=17, **kw)
         got = splat_forward_labels(variant, *t, si.H, si.W, si.D, **kw)

@@ -47,6 +47,34 @@ def test_key_points_values_and_gradients(gpu, bs, A, D, K):
         assert torch.allclose(l.grad.cpu().double(), l64.grad, rtol=1e-4, atol=1e-4 * float(l64.grad.abs().max()))
 
 
+@pytest.mark.parametrize("xyz_act,scale_act", [("identity", "sigmoid"), ("sigmoid", "none"), ("identity", "identity")])
+def test_identity_activations(gpu, xyz_act, scale_act):
+    """xyz_activation / scale_activation other than "sigmoid" (deformable_module.py:27-28, :66-67, :79-80): the columns
+    are used as they are; values and gradients against fp64 autograd of the restatement, through the drop-in module."""
+    import torch
+    from oracle import daf_prepare_ref
+    from gaussianformer_amd.key_points import SparseGaussian3DKeyPointsGenerator
+    g = torch.Generator().manual_seed(7)
+    bs, A, D, K, E = 1, 257, 12, 2, 16
+    anchor = torch.randn(bs, A, D, generator=g)
+    anchor[..., :6] = torch.rand(bs, A, 6, generator=g)          # un-activated columns hold fractions of the ranges
+    feat = torch.randn(bs, A, E, generator=g)
+    pc_range, scale_range = [-50.0, -50.0, -5.0, 50.0, 50.0, 3.0], [0.08, 0.64]
+    gen = SparseGaussian3DKeyPointsGenerator(embed_dims=E, num_learnable_pts=K, fix_scale=FIX, pc_range=pc_range,
+                                             scale_range=scale_range, xyz_activation=xyz_act, scale_activation=scale_act).to(gpu)
+    w = torch.randn(bs, A, len(FIX) + K, 3, generator=g)
+    a64 = anchor.double().requires_grad_(True)
+    ref = daf_prepare_ref.key_points(a64, feat.double(), FIX, gen.learnable_fc.weight.detach().cpu().double(),
+                                     gen.learnable_fc.bias.detach().cpu().double(), pc_range, scale_range,
+                                     xyz_activation=xyz_act, scale_activation=scale_act)
+    (ref * w.double()).sum().backward()
+    a = anchor.to(gpu).requires_grad_(True)
+    out = gen(a, feat.to(gpu))
+    (out * w.to(gpu)).sum().backward()
+    assert torch.allclose(out.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=2e-5)
+    assert torch.allclose(a.grad.cpu().double(), a64.grad, rtol=1e-4, atol=1e-4 * float(a64.grad.abs().max()))
+
+
 def _restated(ref_mod, anchor, learned, pc_range, scale_range):
     """daf_prepare_ref.key_points with the learned offsets given directly (weight = identity on a flattened feature)."""
     import torch

@@ -101,6 +101,31 @@ def test_key_point_restatement_matches_the_reference_caller():
     assert np.allclose(loc, d["call_sampling_location"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("xyz_act,scale_act", [("sigmoid", "sigmoid"), ("identity", "sigmoid"), ("sigmoid", "none"),
+                                               ("identity", "identity")])
+def test_key_point_restatement_activations_vs_the_reference_generator(xyz_act, scale_act):
+    """The activation switches of the key-point generator (deformable_module.py:27-28, :66-67, :79-80): the
+    reference's own class, executed here, against the restatement that checks gf_key_points on the GPU."""
+    import torch
+    import ref_shim
+    from oracle import daf_prepare_ref
+    if not ref_shim.available():
+        pytest.skip("/root/reference absent (GPU box)")
+    ref_shim.load_reference()
+    fix = [[0, 0, 0], [0.45, 0, 0], [-0.45, 0, 0], [0, 0.45, 0], [0, -0.45, 0], [0, 0, 0.45], [0, 0, -0.45]]
+    pc_range, scale_range = [-50.0, -50.0, -5.0, 50.0, 50.0, 3.0], [0.08, 0.64]
+    gen = ref_shim.build_from_cfg(dict(type="SparseGaussian3DKeyPointsGenerator", embed_dims=16, num_learnable_pts=2,
+                                       fix_scale=fix, pc_range=pc_range, scale_range=scale_range,
+                                       xyz_activation=xyz_act, scale_activation=scale_act), ref_shim.MODELS).double()
+    g = torch.Generator().manual_seed(11)
+    anchor = torch.randn(2, 50, 12, generator=g, dtype=torch.float64)
+    feat = torch.randn(2, 50, 16, generator=g, dtype=torch.float64)
+    want = gen(anchor, feat)
+    got = daf_prepare_ref.key_points(anchor, feat, fix, gen.learnable_fc.weight.detach(), gen.learnable_fc.bias.detach(),
+                                     pc_range, scale_range, xyz_activation=xyz_act, scale_activation=scale_act)
+    assert torch.allclose(got, want.detach(), rtol=1e-12, atol=1e-12)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 def _head_modules(name, d, gpu):
     import local_aggregate, local_aggregate_prob, local_aggregate_prob_fast

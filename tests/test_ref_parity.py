@@ -165,11 +165,13 @@ def _hip_vs_ref(gpu, reflib, si, per_axis, seed, flags=0, logit_tol=1e-4):
 def test_hip_small_vs_reference(gpu, reflib, config, P, H, W, D, per_axis):
     si = make_splat_inputs(config, seed=47, P=P, H=H, W=W, D=D)
     prob = si.variant == "prob"
-    rf, rgrads, grads, _ = _hip_vs_ref(gpu, reflib, si, per_axis, 48, logit_tol=1e-3 if prob else 1e-4)
+    # north_star's bounds for every variant: fp32 outputs within 1e-4, gradients within 1e-3 of the tensor's maximum
+    # (base variant, default flags: the matrix-core kernel renders the forward)
+    rf, rgrads, grads, _ = _hip_vs_ref(gpu, reflib, si, per_axis, 48, logit_tol=1e-4)
     for name, a, b in zip(GRAD_NAMES, grads, rgrads):
         if prob and not np.isfinite(b).all():
             continue
-        assert_grad_close(a, b, what=f"HIP {name} vs reference", rtol=2e-2 if prob else 1e-3)
+        assert_grad_close(a, b, what=f"HIP {name} vs reference", rtol=1e-3)
 
 
 def test_hip_arbitrary_points_vs_reference(gpu, reflib):
@@ -242,7 +244,12 @@ def test_hip_prob_full_size_vs_reference(gpu, reflib, per_axis):
         a, b = got[k][finite], rf[k][finite]
         err = np.abs(a.astype(np.float64) - b) / np.maximum(1.0, np.abs(b))
         print(f"   {k}: max scaled err {err.max():.3e}")
-        assert err.max() <= 1e-3, (k, err.max())
+        assert err.max() <= 1e-4, (k, err.max())
+        # Where the reference is not finite the HIP path is not finite either, element for element: the default
+        # reproduces the reference's fp32 determinant (gf_common.hpp: prob_det32), NaN of a negative rounding included;
+        # GF_PROB_EXACT_DET is the flag that removes them (tested below).
+        fin_ref = np.isfinite(rf[k])
+        assert np.array_equal(np.isfinite(got[k]), fin_ref), (k, int((np.isfinite(got[k]) != fin_ref).sum()))
     grads = hip_splat_backward(gpu, si, t, state, fwd_t, g, gb, gd)
     for name, a, b in zip(GRAD_NAMES, grads, rgrads):
         ok = np.isfinite(b)
@@ -251,7 +258,17 @@ def test_hip_prob_full_size_vs_reference(gpu, reflib, per_axis):
         scale = max(np.abs(b[ok]).max(), 1e-6)
         err = np.abs(a[ok].astype(np.float64) - b[ok]).max() / scale
         print(f"   {name}: max err / max|ref| {err:.3e} ({(~ok).sum()} non-finite reference rows)")
-        assert np.isfinite(a[ok]).all() and err <= 2e-2, (name, err)
+        assert np.isfinite(a[ok]).all() and err <= 1e-3, (name, err)
+    if not per_axis:
+        # the fp64 determinant (GF_PROB_EXACT_DET) leaves no non-finite voxel and agrees with the reference wherever
+        # the reference is finite and its own determinant is not dominated by cancellation noise (loose bound)
+        from gaussianformer_amd import _lib
+        exact, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_PROB_EXACT_DET)
+        for k in ("logits", "bin_logits", "density", "probability"):
+            assert np.isfinite(exact[k]).all(), k
+        for k in ("bin_logits", "density"):     # independent of the determinant
+            e = np.abs(exact[k][finite].astype(np.float64) - rf[k][finite]) / np.maximum(1.0, np.abs(rf[k][finite]))
+            assert e.max() <= 1e-4, (k, e.max())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -283,12 +300,16 @@ def test_daf_hip_vs_reference_gs25600(gpu, reflib):
         assert_grad_close(a, b, what=f"HIP {name} vs reference")
 
 
-def test_daf_hip_vs_reference_gs144000_forward(gpu, reflib):
-    """1 296 000 sample points (nuscenes_gs144000), forward."""
+def test_daf_hip_vs_reference_gs144000(gpu, reflib):
+    """1 296 000 sample points (nuscenes_gs144000), forward and backward."""
     d = make_daf_inputs(num_pts=1296000, seed=63)
     want = reflib.daf_forward(**d)
-    out, _ = _daf_hip(gpu, d)
+    g = np.random.default_rng(64).standard_normal(want.shape).astype(np.float32)
+    out, grads = _daf_hip(gpu, d, g)
     assert_logits_close(out, want, what="HIP daf output vs reference (gs144000)")
+    gr = reflib.daf_backward(d["mc_ms_feat"], d["spatial_shape"], d["scale_start_index"], d["sampling_location"], d["weights"], g)
+    for name, a, b in zip(("grad_mc_ms_feat", "grad_sampling_location", "grad_weights"), grads, gr):
+        assert_grad_close(a, b, what=f"HIP {name} vs reference (gs144000)")
 
 
 def test_daf_hip_small_vs_reference(gpu, reflib):

@@ -231,15 +231,21 @@ def test_forward_full_size(gpu, config):
     si2 = make_splat_inputs(config, seed=0)
     si2.semantics *= np.float32(2.0)
     got2, *_ = hip_splat_forward(gpu, si2, pi, mi, radii, cov6)
-    # power-of-two scaling is exact in fp32 except where a product lands in the denormal range
-    assert np.allclose(got2["logits"], np.float32(2.0) * got["logits"], rtol=0, atol=1e-35)
-    # deterministic: same bits on a second run, and the arbitrary-points kernel (same ascending
-    # Gaussian order per voxel) reproduces the dense kernel bit for bit
+    # (default flags = the matrix-core kernel: its f16 operand split is linear up to the last bit of the lo term)
+    assert np.allclose(got2["logits"], np.float32(2.0) * got["logits"], rtol=2e-6, atol=1e-6)
+    # deterministic: same bits on a second run
     from gaussianformer_amd import _lib
     again, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
     assert np.array_equal(again["logits"], got["logits"])
+    # the exact-fp32 tile kernel: power-of-two scaling is exact in fp32 except where a product lands in the denormal
+    # range, and the arbitrary-points kernel (same ascending Gaussian order per voxel) reproduces it bit for bit
+    exact, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_EXACT_FP32)
+    _check_fwd(exact, ref, si.variant)
+    exact2, *_ = hip_splat_forward(gpu, si2, pi, mi, radii, cov6, flags=_lib.GF_EXACT_FP32)
+    assert np.allclose(exact2["logits"], np.float32(2.0) * exact["logits"], rtol=0, atol=1e-35)
     general, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_PTS_GENERAL)
-    assert np.array_equal(general["logits"], got["logits"])
+    assert np.array_equal(general["logits"], exact["logits"])
+    assert_logits_close(got["logits"], exact["logits"], what="matrix-core vs exact-fp32 kernel", tol=1e-4)
 
 
 @pytest.mark.parametrize("config", ["nuscenes_gs25600_solid", "nuscenes_gs144000"])
@@ -255,12 +261,12 @@ def test_backward_full_size(gpu, config):
         assert_grad_close(a, b, what=name)
 
 
-@pytest.mark.parametrize("mode", ["default", "libm", "comp"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "libm", "comp"])
 def test_exp_modes(gpu, mode):
-    """The three exp() flavours (include/gf_hip.h) all meet the logits tolerance; default is the
-    log2(e)-prescaled v_exp_f32."""
+    """The three exp() flavours of the exact-fp32 kernels (include/gf_hip.h) all meet the logits tolerance;
+    GF_EXACT_FP32 alone is the log2(e)-prescaled v_exp_f32 (GF_FAST_EXP)."""
     from gaussianformer_amd import _lib
-    flags = {"default": 0, "libm": _lib.GF_LIBM_EXP, "comp": _lib.GF_COMP_EXP}[mode]
+    flags = {"exact": _lib.GF_EXACT_FP32, "fast": _lib.GF_FAST_EXP, "libm": _lib.GF_LIBM_EXP, "comp": _lib.GF_COMP_EXP}[mode]
     for config in ("nuscenes_gs25600_solid", "nuscenes_gs144000"):
         si = make_splat_inputs(config, seed=17, P=3000, H=48, W=40, D=16)
         pi, mi, radii, cov6 = prep(si)

@@ -218,7 +218,8 @@ def test_subm_conv_crowded_cells():
 
 def test_subm_conv_without_host_read():
     """gf_subm_rulebook_build: pair arrays sized in advance, no count read back.  Same output and gradients as the exact
-    rulebook when the pairs fit; an EMPTY rulebook (zero output) and a refusal that check() raises when they do not."""
+    rulebook when the pairs fit; an EMPTY rulebook (NaN output: loud, not a silent zero) and a refusal that check() raises
+    -- and that SparseConv3D reports by itself on a later call, without blocking -- when they do not."""
     from gaussianformer_amd.sparse_conv import Rulebook, SparseConv3D, subm_conv3d
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(11)
@@ -241,7 +242,7 @@ def test_subm_conv_without_host_read():
     small = Rulebook(idx, batch, shape, K, pair_capacity=exact.total - 1)
     out = subm_conv3d(feat, idx, weight, batch, shape, K, rulebook=small)
     torch.cuda.synchronize()
-    assert float(out.abs().max()) == 0.0
+    assert bool(torch.isnan(out).all())
     with pytest.raises(RuntimeError, match="pair_capacity"):
         small.check()
     # module keyword
@@ -253,6 +254,14 @@ def test_subm_conv_without_host_read():
     ya, yb = m(x, anchor), ref(x, anchor)
     assert torch.allclose(ya, yb, rtol=1e-5, atol=1e-5 * float(yb.abs().max()))
     assert m.last_rulebook.check() == ref.last_rulebook.total
+    # a module whose capacity is too small: NaN out, and the refusal surfaces from a LATER forward (deferred, non-blocking
+    # poll of the status copied to pinned memory) -- at the latest after a synchronisation
+    tight = SparseConv3D(128, 128, [0.0, 0.0, 0.0, 30.0, 30.0, 8.0], [0.5, 0.5, 0.5], pairs_per_point=1).to(dev)
+    y = tight(x, anchor)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(y).all())
+    with pytest.raises(RuntimeError, match="pair_capacity"):
+        tight(x, anchor)
 
 
 def _representative_reference(feat, idx, weight, batch, shape, K):

@@ -204,7 +204,7 @@ class Frame(nn.Module):
                 m.last_rulebook.check()
 
 
-def run(config="nuscenes_gs25600_solid", frames=10, warmup=3, device="cuda:0"):
+def run(config="nuscenes_gs25600_solid", frames=10, warmup=3, device="cuda:0", graph=False):
     from gaussianformer_amd.synthetic import DAF_LEVELS, voxel_centres
     if not torch.cuda.is_available():
         raise RuntimeError("bench_frame.py needs an MI355X")
@@ -227,12 +227,41 @@ def run(config="nuscenes_gs25600_solid", frames=10, warmup=3, device="cuda:0"):
     dt = (time.perf_counter() - t0) / frames
     model.check()
     hist = torch.bincount(labels, minlength=18).tolist()
-    return {"config": config, "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "frames": frames, "anchors": A,
-            "sample_points_per_block": A * (len(FIX_SCALE) + 2), "voxels": int(labels.numel()),
-            "labels_used": int(sum(1 for h in hist if h)),
-            "scope": "inference frame: feature_maps_format once, 4 encoder blocks (spconv / deformable / ffn / norm / refine in the "
-                     "reference's order), fused Gaussian pre-processing, splat, occupancy labels; image backbone excluded; "
-                     "FFN / LayerNorm / refine / anchor encoder / weights_fc (applied to the anchor and camera parts separately) are torch stand-ins with random weights"}
+    out = {"config": config, "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "frames": frames, "anchors": A,
+           "sample_points_per_block": A * (len(FIX_SCALE) + 2), "voxels": int(labels.numel()),
+           "labels_used": int(sum(1 for h in hist if h)),
+           "scope": "inference frame: feature_maps_format once, 4 encoder blocks (spconv / deformable / ffn / norm / refine in the "
+                    "reference's order), fused Gaussian pre-processing, splat, occupancy labels; image backbone excluded; "
+                    "FFN / LayerNorm / refine / anchor encoder / weights_fc (applied to the anchor and camera parts separately) are torch stand-ins with random weights"}
+    if graph:
+        # the same frame as ONE captured HIP graph: nothing in it synchronises (rulebooks are built without the host
+        # read, the splat's range asserts are off) and every native op launches on torch's current stream
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                model(anchor, feat, maps, pm, wh, pts)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                g_labels = model(anchor, feat, maps, pm, wh, pts)
+            for _ in range(max(1, warmup)):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            dtg = (time.perf_counter() - t0) / frames
+            model.check()
+            out["frames_per_s_graph"] = 1.0 / dtg
+            out["ms_per_frame_graph"] = dtg * 1e3
+            out["graph_labels_equal_eager"] = bool(torch.equal(g_labels, labels))
+        except Exception as exc:   # capture support is an extra; never lose the eager figure
+            out["frames_per_s_graph"] = None
+            out["graph_error"] = f"{type(exc).__name__}: {exc}"[:300]
+    return out
 
 
 if __name__ == "__main__":
@@ -240,6 +269,7 @@ if __name__ == "__main__":
     ap.add_argument("--configs", nargs="*", default=list(FRAME_CONFIGS))
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="also replay the frame as one captured HIP graph")
     args = ap.parse_args()
     for c in args.configs:
-        print(json.dumps(run(c, args.frames, args.warmup)), flush=True)
+        print(json.dumps(run(c, args.frames, args.warmup, graph=args.graph)), flush=True)
