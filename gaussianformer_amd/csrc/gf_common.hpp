@@ -21,8 +21,6 @@ constexpr int kRecDwords = 32;       // packed per-Gaussian record, 128 B
 constexpr int kRecMean = 0, kRecOpa = 3, kRecCov = 4, kRecLo = 10, kRecHi = 11, kRecSem = 12,
               kRecKdet = 30;
 
-// schedule words of the matrix-core forward inside the flags section (see gf_splat_prep_kernel)
-constexpr int kSchedBase = 5120, kSchedMagic = 0, kSchedDirty = 1, kSchedDone = 2;
 
 // packed voxel coordinate: x | y<<11 | z<<22   (H,W <= 2047, D <= 1023)
 __host__ __device__ __forceinline__ uint32_t pack3(int x, int y, int z)
@@ -35,8 +33,7 @@ __host__ __device__ __forceinline__ int uz(uint32_t p) { return (int)(p >> 22); 
 
 // workspace carve-up (all sections 256-B aligned)
 struct SplatWorkspace {
-    uint32_t *flags;        // [8192] [64..4160) = dense-grid verdicts, [4608 + 64 x] = tile counter of XCD x,
-                            //        [5120..5123) = schedule words of the matrix-core forward (kSched*)
+    uint32_t *flags;        // [8192] [64..4160) = dense-grid verdicts, [4608 + 64 x] = tile counter of XCD x
     float *records;         // [P][32]
     uint2 *boxes;           // [P]  (lo, hi) packed
     unsigned long long *bitmask;  // [nsuper][nwords]
@@ -48,7 +45,6 @@ struct SplatWorkspace {
     int *seg;               // [P][8] backward: (index, volume, box lo[3], box hi[3]) of the Gaussian at each sorted position
     uint32_t *sort_hist;    // [64][ceil(P/256)] + [64] backward: per-(cell, block) counts -> offsets, cell totals
     float *dotlg;           // [N]  prob backward: sum_c dL/dlogits[n][c] * logits[n][c]
-    uint32_t *tile_cost;    // [nsuper] matrix-core forward: Gaussians binned to each supertile (longest-first tile order)
     int nwords, nsx, nsy, nsuper;
     size_t total_bytes;
 };
@@ -76,7 +72,6 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.seg = (int *)(p + off); off += align256((size_t)P * 32);
     ws.sort_hist = (uint32_t *)(p + off); off += align256(((size_t)64 * ((P + 255) / 256) + 64) * 4);
     ws.dotlg = (float *)(p + off); off += align256((size_t)(N > 0 ? N : 0) * 4);
-    ws.tile_cost = (uint32_t *)(p + off); off += align256((size_t)ws.nsuper * 4);
     ws.total_bytes = off;
     return ws;
 }

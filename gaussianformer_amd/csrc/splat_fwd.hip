@@ -53,9 +53,6 @@ struct PrepArgs {
     int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det, lattice;
     uint32_t *tile_counters;  // null, or the eight per-XCD tile counters of the matrix-core render kernel ...
     uint32_t tile_counter_init;  // ... and the value they start from (the workgroups per XCD: those tiles are taken)
-    uint32_t *tile_cost;      // null, or [nsuper]: Gaussians binned to each supertile, summed here with integer atomics
-    uint32_t *sched;          // schedule words of the matrix-core forward (kSchedMagic / kSchedDirty / kSchedDone)
-    uint32_t sched_magic;     // what kSchedMagic holds once this workspace has served this problem shape
 };
 
 constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
@@ -167,15 +164,6 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         return;
     }
     if (a.tile_counters && blockIdx.x == 0 && threadIdx.x < 8) a.tile_counters[64 * threadIdx.x] = a.tile_counter_init;
-    // Longest-first tile order of the matrix-core kernel: this launch sums, per supertile, the Gaussians binned to it
-    // (tile_cost, integer atomics: order-independent); the render launch ranks its XCD's tiles by that count and its LAST
-    // workgroup to exit zeroes the counts again for the next call.  A workspace that has not served this shape before
-    // (magic mismatch) holds garbage counts: that call is marked dirty and keeps the plain tile order.
-    if (a.sched && blockIdx.x == 0 && threadIdx.x == 0 && a.sched[kSchedMagic] != a.sched_magic) {
-        a.sched[kSchedMagic] = a.sched_magic;
-        a.sched[kSchedDirty] = 1u;
-        a.sched[kSchedDone] = 0u;
-    }
     const int word = blockIdx.x * WAVES + wave;  // bitmask word of this wave
     const int g = word * 64 + lane;
     const bool valid = g < a.P;
@@ -355,7 +343,6 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             if ((int)blockIdx.x * WAVES + w < a.nwords) {
                 const unsigned long long bits = s_bits[i];
                 a.bitmask[(size_t)(s0 + si) * a.nwords + blockIdx.x * WAVES + w] = bits;
-                if (a.tile_cost && bits) atomicAdd(a.tile_cost + s0 + si, (uint32_t)__builtin_popcountll(bits));
             }
         }
     }
@@ -383,9 +370,6 @@ struct RenderArgs {
     float threshold;
     int raw_numerator;  // prob variant: logits = sum sem * prob, not divided by prob_sum (GF_PROB_NUMERATOR)
     uint32_t *tile_counters;  // matrix-core kernel: next unclaimed tile of XCD x at [64 x] (one cache line each)
-    uint32_t *tile_cost;      // matrix-core kernel: [nsuper] Gaussians binned to each supertile (prep launch)
-    uint32_t *sched;          // matrix-core kernel: schedule words (kSched*)
-    int nsuper;
 };
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
@@ -968,7 +952,6 @@ union H8 {
     fp16x2 p[4];
     _Float16 e[8];
 };
-constexpr int kLptMax = 512;  // tiles per XCD up to which the matrix-core kernel ranks them (longest first)
 constexpr int kQCap = 96;  // hit queue entries per wave (a group of 32 leaves as soon as it is full; a batch adds <= 64)
 constexpr int kSRow = 36;  // floats per channel row of the staged opacity * semantics (32 Gaussians + pad: conflict-free b128 reads)
 
@@ -1006,8 +989,6 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     // the following ones come from a per-XCD counter (zeroed by the prep kernel), claimed while the current tile's list is
     // complete -- early enough to fetch the next tile's first bitmask words under the whole accumulation.
     __shared__ int s_next;
-    __shared__ uint32_t s_key[kLptMax];   // longest-first order: sort keys, then ...
-    __shared__ uint16_t s_perm[kLptMax];  // ... position in the order -> tile of this XCD
     const int xcd = (int)(blockIdx.x & 7u);
     const int per_xcd = (a.ntiles_total + 7) >> 3;  // logical tiles per XCD (the last XCD's tail may be short)
 
@@ -1018,30 +999,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         vf = make_uint4(v0.x | v1.x | v2.x | v3.x, v0.y | v1.y | v2.y | v3.y, v0.z | v1.z | v2.z | v3.z,
                         v0.w | v1.w | v2.w | v3.w);
     }
-    // Longest-first tile order.  Every workgroup of an XCD ranks that XCD's tiles by the number of Gaussians the prep
-    // launch binned to their supertile (descending, ties by index: the same permutation in every workgroup, no
-    // communication): position k of the order goes to the k-th claim -- the first `gridDim.x / 8` positions are the
-    // workgroups' own slots, the following ones come off the per-XCD counter -- so the heaviest tiles start first and
-    // the tail of the launch is made of the lightest ones.  (Results do not depend on the order: a tile is computed
-    // by exactly one workgroup from its own inputs.)
-    const bool lpt = a.tile_cost != nullptr && per_xcd <= kLptMax && a.sched[kSchedDirty] == 0u;
-    if (lpt) {
-        for (int i = tid; i < per_xcd; i += kBlock) {
-            const int lg = xcd * per_xcd + i;
-            const uint32_t c = lg < a.ntiles_total ? min(a.tile_cost[lg / kTilesPerSuper], 0x3FFFFFu) + 1u : 0u;
-            s_key[i] = (c << 9) | (uint32_t)(kLptMax - 1 - i);  // distinct keys: larger = earlier
-        }
-        __syncthreads();
-        for (int i = tid; i < per_xcd; i += kBlock) {
-            const uint32_t mine = s_key[i];
-            int rank = 0;
-            for (int j = 0; j < per_xcd; ++j) rank += s_key[j] > mine ? 1 : 0;
-            s_perm[rank] = (uint16_t)i;
-        }
-        __syncthreads();
-    }
     int local = (int)(blockIdx.x >> 3);
-    if (lpt && local < per_xcd) local = s_perm[local];
     int logical = xcd * per_xcd + local;
     int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
     int X0 = (s / a.nsy) * kSuper;
@@ -1070,31 +1028,11 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     } else if (blockIdx.x == 0 && tid == 0 && a.state) {
         a.state[2] = 0u;
     }
-    // Every workgroup leaves through finish(): the last one to arrive zeroes the supertile counts for the next call
-    // (nobody reads them any more: each workgroup ranked its tiles before its first claim) and clears the dirty mark.
-    __shared__ int s_last;
-    auto finish = [&]() {
-        if (a.tile_cost == nullptr) return;
-        __syncthreads();
-        if (tid == 0) s_last = atomicAdd(a.sched + kSchedDone, 1u) == gridDim.x - 1u ? 1 : 0;
-        __syncthreads();
-        if (s_last) {
-            for (int i = tid; i < a.nsuper; i += kBlock) a.tile_cost[i] = 0u;
-            if (tid == 0) {
-                a.sched[kSchedDone] = 0u;
-                a.sched[kSchedDirty] = 0u;
-            }
-        }
-    };
     if (nondense) {
         general_body<GF_SPLAT_BASE, kExpComp, LABELS>(a);
-        finish();
         return;
     }
-    if (!tile_ok) {
-        finish();
-        return;
-    }
+    if (!tile_ok) return;
 
     const int n = lane & 31, h = lane >> 5;
     uint32_t *q_id = s_queue[wave];
@@ -1220,7 +1158,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 #endif
             if (done && last_zg) {
                 // first bitmask words of the next tile: in flight during the whole accumulation of this one
-                next_local = s_next < per_xcd ? (lpt ? (int)s_perm[s_next] : s_next) : per_xcd;
+                next_local = s_next;
                 const int nl = xcd * per_xcd + next_local;
                 const int ns = nl / kTilesPerSuper;
                 const bool nok = next_local < per_xcd && nl < a.ntiles_total;
@@ -1431,12 +1369,11 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     s = logical / kTilesPerSuper; t = logical % kTilesPerSuper;
     X0 = (s / a.nsy) * kSuper;
     Y0 = (s % a.nsy) * kSuper + t * kTileY;
-    if (!(local < per_xcd && logical < a.ntiles_total)) break;  // workgroup-uniform (in longest-first order the short XCD's missing tiles sort last)
+    if (!(local < per_xcd && logical < a.ntiles_total)) break;  // workgroup-uniform
     bm = a.bitmask + (size_t)s * a.nwords;
     __syncthreads();  // the slowest wave is done with the list and the scan scratch
     if (!(X0 < a.H && Y0 < a.W)) { word_next = 0ull; }  // (cannot happen for logical < ntiles_total; keeps the list empty)
     }
-    finish();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1608,9 +1545,6 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     uint32_t *tile_counters = ws.flags + 4608;  // [64 x], x < 8: inside the 32 KB flag section, past the verdicts
     pa.tile_counters = mfma ? tile_counters : nullptr;
     pa.tile_counter_init = mfma ? (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8) : 0u;
-    pa.tile_cost = mfma ? ws.tile_cost : nullptr;
-    pa.sched = mfma ? ws.flags + kSchedBase : nullptr;
-    pa.sched_magic = (uint32_t)(0x9e3779b9u * (uint32_t)P + 0x85ebca6bu * (uint32_t)H + 0xc2b2ae35u * (uint32_t)W + 0x27d4eb2fu * (uint32_t)D) | 1u;
     const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
@@ -1632,9 +1566,6 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
     ra.tile_counters = tile_counters;
-    ra.tile_cost = mfma ? ws.tile_cost : nullptr;
-    ra.sched = ws.flags + kSchedBase;
-    ra.nsuper = ws.nsuper;
     if (mfma)
         launch_render_mfma(ra, stream);
     else if (variant == GF_SPLAT_BASE)

@@ -77,12 +77,38 @@ def test_mfma_inexact_lattice_falls_back(gpu):
     ref = _oracle_logits(si, pi, mi, radii, cov6)          # the oracle reads pts: the perturbed positions
     t = [torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
     logits, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_MFMA_SPLAT)
-    assert int(state.view(torch.int32)[0]) == 1            # verdict: not usable as a dense lattice
+    # state block: the points ARE in their voxels (word 0 = 0, the backward keeps its dense path), the call was rendered
+    # by the arbitrary-points body (word 1) because the lattice verdict (bit 1 of word 2) failed
+    assert state.view(torch.int32)[:3].tolist() == [0, _lib.GF_PATH_ARBITRARY, 2]
     assert_logits_close(logits.cpu().numpy(), ref, tol=1e-4)
     # the thinnest Gaussians make one ulp visible: the result must be the one for the given positions, bit for bit the
     # arbitrary-points kernel's
     general, *_ = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_PTS_GENERAL | _lib.GF_COMP_EXP)
     assert torch.equal(general, logits)
+
+
+def test_mfma_coefficient_range_verdict(gpu):
+    """A Gaussian whose exponent coefficients would leave the f16 range of the matrix-core kernel's operands (thin AND
+    far-reaching: scale 0.004 m with a radius of 12 voxels) trips the prep launch's range verdict: the call is rendered
+    by the arbitrary-points body (finite, within tolerance of the oracle) and the state block says so."""
+    import torch
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import splat_forward
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=13, P=200, H=24, W=24, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    cov6[5] = (np.float32(1.0 / 0.004 ** 2), np.float32(1.0), np.float32(1.0), 0, 0, 0)   # (xx, yy, zz, xy, yz, xz)
+    radii[5] = 12
+    ref = _oracle_logits(si, pi, mi, radii, cov6)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
+    logits, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D)
+    assert state.view(torch.int32)[:3].tolist() == [0, _lib.GF_PATH_ARBITRARY, 4]
+    assert bool(torch.isfinite(logits).all())
+    assert_logits_close(logits.cpu().numpy(), ref, tol=1e-4)
+    # with an ordinary covariance in its place the same call stays on the matrix cores
+    cov6[5] = cov6[6]
+    t[7] = torch.from_numpy(cov6).to(gpu)
+    _, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D)
+    assert state.view(torch.int32)[:3].tolist() == [0, _lib.GF_PATH_MATRIX_CORE, 0]
 
 
 @pytest.mark.parametrize("config", ["nuscenes_gs25600_solid", "nuscenes_gs144000"])

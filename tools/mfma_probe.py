@@ -1,4 +1,4 @@
-"""Development probe (GPU box): the matrix-core render kernel (GF_MFMA_SPLAT) against the default kernel and oracle/_ref.
+"""Development probe (GPU box): the matrix-core render kernel (the default) against the exact-fp32 tile kernel and oracle/_ref.
 python tools/mfma_probe.py [config ...]"""
 import os
 import sys
@@ -22,10 +22,11 @@ for config in configs:
     pi, mi, radii, cov6 = prep(si)
     t = to_dev(dev, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
     outs = {}
-    for name, flags in (("default", 0), ("mfma", _lib.GF_MFMA_SPLAT)):
+    for name, flags in (("exact", _lib.GF_EXACT_FP32), ("mfma", 0)):
         plan = SplatForwardPlan(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=flags)
         outs[name] = plan.run().clone()
         torch.cuda.synchronize()
+        print(f"{config} {name}: state words {plan.state_words()}", flush=True)
         for _ in range(20):
             plan.run()
         torch.cuda.synchronize()
@@ -34,9 +35,9 @@ for config in configs:
             plan.run()
         torch.cuda.synchronize()
         print(f"{config} {name}: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per step", flush=True)
-    a, b = outs["default"].double(), outs["mfma"].double()
+    a, b = outs["exact"].double(), outs["mfma"].double()
     err = ((a - b).abs() / a.abs().clamp(min=1.0)).max().item()
-    print(f"{config}: mfma vs default max scaled err {err:.3e}; finite {bool(torch.isfinite(outs['mfma']).all())}")
+    print(f"{config}: mfma vs exact max scaled err {err:.3e}; finite {bool(torch.isfinite(outs['mfma']).all())}")
     try:
         from oracle import ref
         if ref.available() or os.path.isdir(os.path.join(ROOT, "oracle", "_ref")):

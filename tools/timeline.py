@@ -1,16 +1,21 @@
-"""Debug: per-workgroup timeline of the render kernel (start / list built / consumed / stored)."""
+"""Debug: per-workgroup timeline of the render kernel (start / list built / consumed / stored).
+python tools/timeline.py [config] [exact]   -- default: the matrix-core kernel; "exact": the exact-fp32 tile kernel"""
 import ctypes, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 import os
 from gaussianformer_amd import build as _b
-os.environ["GF_LIB"] = _b.build(extra_flags=("-DGF_TIMELINE=1",), lib_name="libgf_hip_timeline.so")
+_tl = os.path.join(_b.CSRC, "libgf_hip_timeline.so")
+_deps = [os.path.join(_b.CSRC, f) for f in _b.SOURCES + _b.HEADERS]
+if not os.path.exists(_tl) or any(os.path.getmtime(d) > os.path.getmtime(_tl) for d in _deps if os.path.exists(d)):
+    _b.build(extra_flags=("-DGF_TIMELINE=1",), lib_name="libgf_hip_timeline.so")   # prebuilt in-tree copies travel with gpurun
+os.environ["GF_LIB"] = _tl
 from gaussianformer_amd import _lib
 from gaussianformer_amd.local_aggregate import SplatForwardPlan
 from gaussianformer_amd.synthetic import make_splat_inputs
 import oracle
 config = sys.argv[1] if len(sys.argv) > 1 else "nuscenes_gs25600_solid"
-extra_flags = _lib.GF_MFMA_SPLAT if "mfma" in sys.argv[2:] else 0
+extra_flags = _lib.GF_EXACT_FP32 if "exact" in sys.argv[2:] else 0   # default = the matrix-core kernel
 dev = torch.device("cuda:0")
 si = make_splat_inputs(config, seed=0)
 pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size, si.scale_multiplier)
