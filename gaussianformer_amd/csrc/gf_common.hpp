@@ -36,7 +36,7 @@ struct SplatWorkspace {
     uint32_t *flags;        // [8192] [64..4160) = dense-grid verdicts, [4608 + 64 x] = tile counter of XCD x
     float *records;         // [P][32]
     uint2 *boxes;           // [P]  (lo, hi) packed
-    unsigned long long *bitmask;  // [nsuper][nwords]
+    unsigned long long *bitmask;  // [nsuper][nrow]: rows of nwords words, padded to an even count (16-byte aligned rows)
     int *voxel2pts;         // [V]   (backward, general pts only)
     uint32_t *vols;         // [P]  backward: box volumes
     uint32_t *bsum;         // [ceil(P/256)] backward: volume sums per 256 Gaussians (sorted order)
@@ -45,7 +45,7 @@ struct SplatWorkspace {
     int *seg;               // [P][8] backward: (index, volume, box lo[3], box hi[3]) of the Gaussian at each sorted position
     uint32_t *sort_hist;    // [64][ceil(P/256)] + [64] backward: per-(cell, block) counts -> offsets, cell totals
     float *dotlg;           // [N]  prob backward: sum_c dL/dlogits[n][c] * logits[n][c]
-    int nwords, nsx, nsy, nsuper;
+    int nwords, nrow, nsx, nsy, nsuper;
     size_t total_bytes;
 };
 
@@ -55,6 +55,7 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
 {
     SplatWorkspace ws;
     ws.nwords = (P + 63) / 64;
+    ws.nrow = (ws.nwords + 1) & ~1;
     ws.nsx = (H + kSuper - 1) / kSuper;
     ws.nsy = (W + kSuper - 1) / kSuper;
     ws.nsuper = ws.nsx * ws.nsy;
@@ -63,7 +64,7 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.flags = (uint32_t *)(p + off); off += 32768;
     ws.records = (float *)(p + off); off += align256((size_t)P * kRecDwords * 4);
     ws.boxes = (uint2 *)(p + off); off += align256((size_t)P * 8);
-    ws.bitmask = (unsigned long long *)(p + off); off += align256((size_t)ws.nsuper * ws.nwords * 8);
+    ws.bitmask = (unsigned long long *)(p + off); off += align256((size_t)ws.nsuper * ws.nrow * 8);
     ws.voxel2pts = (int *)(p + off); off += align256((size_t)H * W * D * 4);
     ws.vols = (uint32_t *)(p + off); off += align256((size_t)P * 4);
     ws.bsum = (uint32_t *)(p + off); off += align256((size_t)((P + 255) / 256) * 4);

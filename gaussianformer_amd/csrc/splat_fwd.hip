@@ -50,7 +50,7 @@ struct PrepArgs {
     uint2 *boxes;
     unsigned long long *bitmask;
     uint32_t *verify_flags;  // [kVerifyBlocks]: bit 0 = a point is not in its voxel, bit 1 = pts is not an exact affine lattice
-    int P, N, H, W, D, nwords, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det, lattice;
+    int P, N, H, W, D, nwords, nrow, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det, lattice;
     uint32_t *tile_counters;  // null, or the eight per-XCD tile counters of the matrix-core render kernel ...
     uint32_t tile_counter_init;  // ... and the value they start from (the workgroups per XCD: those tiles are taken)
 };
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             const int si = i / WAVES, w = i - si * WAVES;
             if ((int)blockIdx.x * WAVES + w < a.nwords) {
                 const unsigned long long bits = s_bits[i];
-                a.bitmask[(size_t)(s0 + si) * a.nwords + blockIdx.x * WAVES + w] = bits;
+                a.bitmask[(size_t)(s0 + si) * a.nrow + blockIdx.x * WAVES + w] = bits;
             }
         }
     }
@@ -363,7 +363,7 @@ struct RenderArgs {
     uint32_t *state;
     unsigned long long *timeline;  // debug: 4 timestamps per workgroup (null = off)
     const int *tile_perm;          // debug (GF_TIMELINE builds): workgroup -> logical tile, for scheduling experiments
-    int P, N, nwords, H, W, D, nsx, nsy, ntiles_total, verify_dense;
+    int P, N, nwords, nrow, H, W, D, nsx, nsy, ntiles_total, verify_dense;
     // optional head epilogue (gf_splat_forward_labels): labels straight from the accumulators
     long long *out_labels;  // null = off
     int label_mode, empty_label;
@@ -574,7 +574,7 @@ __device__ __forceinline__ void general_body(const RenderArgs &a)
         A.bin = 1.f; A.dens = 0.f; A.psum = 0.f;
         if (X >= 0 && X < a.H && Y >= 0 && Y < a.W && Z >= 0 && Z < a.D) {
             const int s = (X / kSuper) * a.nsy + (Y / kSuper);
-            const unsigned long long *__restrict__ bm = a.bitmask + (size_t)s * a.nwords;
+            const unsigned long long *__restrict__ bm = a.bitmask + (size_t)s * a.nrow;
             for (int w = 0; w < a.nwords; ++w) {
                 unsigned long long word = bm[w];
                 while (word) {
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
     const int X0 = (s / a.nsy) * kSuper;
     const int Y0 = (s % a.nsy) * kSuper + t * kTileY;
     const bool tile_ok = logical < a.ntiles_total && X0 < a.H && Y0 < a.W;
-    const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nwords;
+    const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nrow;
 
     // issue the first loads before the verdict barrier: verdicts, first bitmask word
     uint4 vf = make_uint4(0, 0, 0, 0);
@@ -952,6 +952,7 @@ union H8 {
     fp16x2 p[4];
     _Float16 e[8];
 };
+constexpr int kRowWords = 3072;  // bitmask row length up to which the matrix-core kernel's producer stages the whole row in LDS (P <= 196 608)
 constexpr int kQCap = 96;  // hit queue entries per wave (a group of 32 leaves as soon as it is full; a batch adds <= 64)
 constexpr int kSRow = 36;  // floats per channel row of the staged opacity * semantics (32 Gaussians + pad: conflict-free b128 reads)
 
@@ -1005,9 +1006,8 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     int X0 = (s / a.nsy) * kSuper;
     int Y0 = (s % a.nsy) * kSuper + t * kTileY;
     bool tile_ok = local < per_xcd && logical < a.ntiles_total && X0 < a.H && Y0 < a.W;
-    const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nwords;
+    const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nrow;
 
-    unsigned long long word_next = (tile_ok && tid < a.nwords) ? bm[tid] : 0ull;
     // verdicts of the prep launch: bit 0 = a point is not in its voxel, bit 1 = pts is not an exact affine lattice,
     // bit 2 = a Gaussian's coefficients may leave the f16 range -- any of them sends the call to the arbitrary-points body
     int verdict = 0;
@@ -1074,6 +1074,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     const int nslots = per_xcd * 8;  // timeline slots (debug builds)
     (void)nslots;
     for (;;) {  // tiles of this workgroup
+#if GF_TIMELINE
+    unsigned long long tacc[4] = {0, 0, 0, 0};
+    const unsigned long long ttile0 = __builtin_amdgcn_s_memtime();
+#endif
     const int Xw = X0 + 4 * (wave & 1);
     int next_local = per_xcd;  // "no more tiles" until the counter says otherwise
 #if GF_TIMELINE
@@ -1088,18 +1092,87 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         const int Zw = zg * 16 + (wave >> 1) * 8;
         const bool last_zg = (zg + 1) * 16 >= a.D;
         f32x16 acc[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
         const double Cx = p0x + ((double)Xw + 1.5) * sx, Cy = p0y + ((double)Y0 + 1.5) * sy, Cz = p0z + ((double)Zw + 3.5) * sz;
 
         int list_len = 0, w_next = 0, wi = 0, grp = 0, ngrp = 0, total = 0, off = 0, qlen = 0;
         unsigned long long hits = 0ull;
         bool done = false;
-        while (!done) {
-            // ---- producer: identical to gf_splat_render_kernel
-            while (true) {
+        // The next tile is claimed NOW (one returning device-scope atomic, ~1-2 us): its answer is first looked at when this
+        // tile's list is complete, so the round trip runs under the producer instead of in front of the accumulation.
+        uint32_t claimed = 0u;
+        // Scope: the counter of XCD x is only touched by the workgroups with blockIdx % 8 == x, which run on that XCD, so a
+        // workgroup-scope RMW -- performed in the XCD's own L2, no trip to the memory side -- is enough.  Should the
+        // placement ever differ, two L2s hand out the same index and a tile is computed twice (same values): never skipped.
+        if (last_zg && tid == 0)
+            claimed = __hip_atomic_fetch_add(a.tile_counters + 64 * xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // The producer is a short chain of dependent steps (scan, barrier, LDS): at equal priority it queues behind the
+        // other workgroup's accumulation on every SIMD; raised, it costs that workgroup a few hundred issue slots.
+        __builtin_amdgcn_s_setprio(3);
+        // ---- producer, fast path.  The whole bitmask row of the supertile comes into LDS by LDS-DMA (global_load_lds: 1 KB
+        // per wave instruction, no data registers, every piece in flight at once: ONE memory round trip where the chunked
+        // producer made one per kBlock words); the row occupies the output staging area, idle until the epilogue (the
+        // barrier that closes a tile orders it behind the previous epilogue's reads).  Then, in rolled loops (a handful of
+        // registers): per chunk of kBlock words one popcount scan, ONE barrier, and every thread knows where its hits go --
+        // list position = hits of earlier chunks + of earlier threads of its chunk, i.e. ascending Gaussian index.
+        // Rows that do not fit the staging area, or with more hits than the list holds, take the chunked producer below.
+        const int nchunks = (a.nwords + kBlock - 1) / kBlock;
+        unsigned long long *s_row = reinterpret_cast<unsigned long long *>(&s_stage[0][0][0]);      // [kRowWords]
+        uint16_t *s_excl = reinterpret_cast<uint16_t *>(s_row + kRowWords);                          // [kRowWords]
+        uint32_t *s_tot = reinterpret_cast<uint32_t *>(s_excl + kRowWords);                          // [kRowWords / kBlock][4]
+        bool fast = a.nwords <= kRowWords;
+        if (fast) {
+            // piece i = words [2 * 64 i, 2 * 64 (i + 1)): lane L moves 16 bytes = words 128 i + 2 L, 128 i + 2 L + 1 (rows are
+            // padded to an even word count; the tail of the last piece re-reads the row's last pair and is never looked at)
+            const int npieces = (a.nwords + 127) >> 7;
+            for (int i = wave; i < npieces; i += 4) {
+                const int w0 = min(128 * i + 2 * lane, a.nrow - 2);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bm + w0),
+                                                 (__attribute__((address_space(3))) void *)(s_row + 128 * i), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int c = 0; c < nchunks; ++c) {
+                const int w = c * kBlock + tid;
+                const unsigned long long bits = w < a.nwords ? s_row[w] : 0ull;
+                const int cnt = __builtin_popcountll(bits);
+                const int incl = wave_inclusive_scan(cnt);
+                if (lane == 63) s_tot[4 * c + wave] = (uint32_t)incl;
+                if (w < a.nwords) s_excl[w] = (uint16_t)(incl - cnt);   // < 64 * 64: hits of earlier lanes of this wave
+            }
+            __syncthreads();
+            int base = 0;
+            for (int c = 0; c < nchunks; ++c) {
+                const uint4 t4 = *reinterpret_cast<const uint4 *>(s_tot + 4 * c);   // the four wave totals of chunk c
+                const int w = c * kBlock + tid;
+                const int chunk_total = (int)(t4.x + t4.y + t4.z + t4.w);
+                if (base + chunk_total <= kListCap && w < a.nwords) {
+                    unsigned long long h = s_row[w];
+                    int pos = base + (int)s_excl[w] + (wave > 0 ? (int)t4.x : 0) + (wave > 1 ? (int)t4.y : 0) + (wave > 2 ? (int)t4.z : 0);
+                    const uint32_t id0 = (uint32_t)w * 64u;
+                    while (h) {
+                        const int j = __builtin_ctzll(h);
+                        h &= h - 1;
+                        s_lg[pos++] = id0 + (uint32_t)j;
+                    }
+                }
+                base += chunk_total;
+            }
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base <= kListCap) {
+                list_len = base;
+                done = true;
+            } else {
+                fast = false;        // too many hits for one list: start over chunk by chunk (what was written is overwritten)
+                __syncthreads();     // s_scan / the staging area are reused
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        while (true) {
+            // ---- producer, chunk by chunk (as in gf_splat_render_kernel): only for rows the fast path declined
+            while (!fast) {
                 if (grp < ngrp) {
                     int gb = 0, ge = total;
                     bool mine = true;
@@ -1130,9 +1203,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 }
                 wi = w_next + tid;
                 w_next += kBlock;
-                const unsigned long long word = word_next;
-                word_next = (w_next + tid) < a.nwords ? bm[w_next + tid] : 0ull;
-                hits = word;
+                hits = wi < a.nwords ? bm[wi] : 0ull;
                 const int cnt = __builtin_popcountll(hits);
                 const int incl = wave_inclusive_scan(cnt);
                 if (lane == 63) s_scan[wave] = (uint32_t)incl;
@@ -1151,19 +1222,13 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
                 if (ngrp != 1) __syncthreads();
             }
-            if (done && last_zg && tid == 0) s_next = (int)atomicAdd(a.tile_counters + 64 * xcd, 1u);
+            if (done && last_zg && tid == 0) s_next = (int)claimed;
             __syncthreads();  // list complete (and the next tile claimed)
+            __builtin_amdgcn_s_setprio(0);
 #if GF_TIMELINE
             if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)logical + 1] = wall_clock64();
 #endif
-            if (done && last_zg) {
-                // first bitmask words of the next tile: in flight during the whole accumulation of this one
-                next_local = s_next;
-                const int nl = xcd * per_xcd + next_local;
-                const int ns = nl / kTilesPerSuper;
-                const bool nok = next_local < per_xcd && nl < a.ntiles_total;
-                word_next = (nok && tid < a.nwords) ? a.bitmask[(size_t)ns * a.nwords + tid] : 0ull;
-            }
+            if (done && last_zg) next_local = s_next;
             // ---- consume: hits of this wave's double brick -> queue -> groups of 32.  After the last batch of the last
             // list the remainder leaves as a partial group (the loop runs once for an empty final list).
             uint32_t eg_n = 0;
@@ -1194,12 +1259,19 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     const int qn = min(qlen, 32);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+#if GF_TIMELINE
+                    const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
+#endif
                     // ---- operands of the group: lane (g = n, h)
                     const bool live = n < qn;
                     const uint32_t id = q_id[live ? n : 0];
                     const float4 *rp = reinterpret_cast<const float4 *>(a.records + (size_t)id * kRecDwords);
                     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
                     const float4 e0 = rp[3 + 3 * h], e1 = rp[4 + 3 * h], e2 = rp[h ? 7 : 5];
+#if GF_TIMELINE
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long tg1 = __builtin_amdgcn_s_memtime();
+#endif
                     // opacity * semantics -> S[channel][g]; half 0 holds channels 0..11, half 1 channels 12..17
                     {
                         const float opa = live ? r0.w : 0.f;
@@ -1258,6 +1330,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                         sh[q >> 1].p[2 * (q & 1)] = ha; sh[q >> 1].p[2 * (q & 1) + 1] = hb;
                         sl[q >> 1].p[2 * (q & 1)] = la; sl[q >> 1].p[2 * (q & 1) + 1] = lb;
                     }
+#if GF_TIMELINE
+                    asm volatile("" :: "v"(sh[0].v), "v"(sh[1].v), "v"(sl[0].v), "v"(sl[1].v), "v"(t1.v), "v"(t2.v), "v"(t3.v), "v"(tb.v));
+                    const unsigned long long tg2 = __builtin_amdgcn_s_memtime();
+#endif
                     // ---- the four 32-voxel blocks, two at a time: exponents of a pair (two independent MFMA chains alternate), exp +
                     // split of each (VALU), accumulation of the pair -- which drains in the matrix pipe under the next pair's
                     // VALU work, the last one under the next group's operand preparation.
@@ -1300,6 +1376,11 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     };
                     pair(0);
                     pair(2);
+#if GF_TIMELINE
+                    asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+                    const unsigned long long tg3 = __builtin_amdgcn_s_memtime();
+                    tacc[0] += tg1 - tg0; tacc[1] += tg2 - tg1; tacc[2] += tg3 - tg2; tacc[3] += 1;
+#endif
                     // ---- the rest of the queue moves down
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -1311,7 +1392,9 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     qlen = rest;
                 }
             }
-            if (!done) __syncthreads();  // every wave is done with the list before it is refilled
+            if (done) break;
+            __syncthreads();  // every wave is done with the list before it is refilled
+            __builtin_amdgcn_s_setprio(3);
             list_len = 0;
         }
 #if GF_TIMELINE
@@ -1357,12 +1440,17 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         }
         if (!last_zg) {
             __syncthreads();  // the next z group rebuilds the list
-            word_next = tid < a.nwords ? bm[tid] : 0ull;
         }
 #if GF_TIMELINE
         if (a.timeline && tid == 0) a.timeline[4 * (size_t)logical + 3] = wall_clock64();
 #endif
     }
+#if GF_TIMELINE
+    if (a.timeline && lane == 0) {
+        unsigned long long *dst = a.timeline + 5 * (size_t)nslots + ((size_t)logical * 4 + wave) * 6;
+        dst[0] = tacc[0]; dst[1] = tacc[1]; dst[2] = tacc[2]; dst[3] = tacc[3]; dst[4] = __builtin_amdgcn_s_memtime() - ttile0;
+    }
+#endif
     // ---- next tile of this workgroup
     local = next_local;
     logical = xcd * per_xcd + local;
@@ -1370,9 +1458,8 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     X0 = (s / a.nsy) * kSuper;
     Y0 = (s % a.nsy) * kSuper + t * kTileY;
     if (!(local < per_xcd && logical < a.ntiles_total)) break;  // workgroup-uniform
-    bm = a.bitmask + (size_t)s * a.nwords;
+    bm = a.bitmask + (size_t)s * a.nrow;
     __syncthreads();  // the slowest wave is done with the list and the scan scratch
-    if (!(X0 < a.H && Y0 < a.W)) { word_next = 0ull; }  // (cannot happen for logical < ntiles_total; keeps the list empty)
     }
 }
 
@@ -1532,7 +1619,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.means3D = means3D; pa.means_int = means3D_int; pa.opacity = opacity; pa.semantics = semantics;
     pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.pts = pts; pa.records = ws.records; pa.boxes = ws.boxes;
     pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
-    pa.nwords = ws.nwords; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
+    pa.nwords = ws.nwords; pa.nrow = ws.nrow; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
     const int prep_waves = P >= 65536 ? 4 : 1;
     pa.variant = variant; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = verify ? 1 : 0;
     // matrix-core kernel: the default wherever it applies (include/gf_hip.h, GF_MFMA_SPLAT / GF_EXACT_FP32)
@@ -1558,7 +1645,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     RenderArgs ra;
     ra.pts = pts; ra.points_int = points_int; ra.records = ws.records; ra.boxes = ws.boxes; ra.bitmask = ws.bitmask;
     ra.out_logits = out_logits; ra.out_bin = out_bin_logits; ra.out_density = out_density; ra.out_prob = out_probability;
-    ra.verify_flags = ws.flags + 64; ra.state = (uint32_t *)state; ra.P = P; ra.N = N; ra.nwords = ws.nwords;
+    ra.verify_flags = ws.flags + 64; ra.state = (uint32_t *)state; ra.P = P; ra.N = N; ra.nwords = ws.nwords; ra.nrow = ws.nrow;
     ra.H = H; ra.W = W; ra.D = D; ra.nsx = ws.nsx; ra.nsy = ws.nsy; ra.ntiles_total = ws.nsuper * kTilesPerSuper;
     ra.verify_dense = verify ? 1 : 0;
     ra.timeline = g_timeline;

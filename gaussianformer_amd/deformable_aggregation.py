@@ -73,6 +73,9 @@ def deformable_aggregation_backward(mc_ms_feat, spatial_shape, scale_start_index
     _lib.check(rc, "gf_daf_backward")
 
 
+_shape_tensors = {}   # (device, pyramid shapes) -> (spatial_shape, scale_start_index) int64 tensors
+
+
 def _format_call(levels, table, inverse):
     """gf_feature_maps_format on contiguous fp32 CUDA tensors: levels [bs,cams,C,h,w], table [bs,cams,num_feat,C]."""
     import ctypes
@@ -153,10 +156,15 @@ class DeformableAggregationFunction(Function):
             else:
                 flat = [f.reshape(bs, num_cams, f.shape[2], -1) for f in feature_maps]
                 col_feats = torch.cat(flat, dim=-1).permute(0, 1, 3, 2)
+            # the two index tensors depend on the pyramid's shape only: built once per (device, shapes) -- two
+            # host-to-device copies less per call, and nothing left in the call that a HIP-graph capture refuses
             dev = col_feats.device
-            return [col_feats,
-                    torch.tensor(shapes, dtype=torch.int64, device=dev),
-                    torch.tensor(starts, dtype=torch.int64, device=dev)]
+            key = (dev.type, dev.index, tuple(shapes))
+            cached = _shape_tensors.get(key)
+            if cached is None:
+                cached = _shape_tensors[key] = (torch.tensor(shapes, dtype=torch.int64, device=dev),
+                                                torch.tensor(starts, dtype=torch.int64, device=dev))
+            return [col_feats, cached[0], cached[1]]
         spatial_shape = feature_maps[1].int()
         sizes = (spatial_shape[:, 0] * spatial_shape[:, 1]).tolist()
         maps = feature_maps[0].permute(0, 1, 3, 2)

@@ -152,12 +152,19 @@ class Frame(nn.Module):
             if isinstance(m, SparseConv3D):
                 nn.init.normal_(m.layer.weight, std=0.01)
         self.aggregator = LocalAggregator(3, 200, 200, 16, PC_RANGE[:3], 0.5, check_inputs=False)
+        # constants as buffers (no host-to-device copy inside the frame: the frame can be captured as a HIP graph)
+        self.register_buffer("pc_lo", torch.tensor(PC_RANGE[:3]), persistent=False)
+        self.register_buffer("pc_span", torch.tensor(PC_RANGE[3:]) - torch.tensor(PC_RANGE[:3]), persistent=False)
+        e = torch.zeros(1, 1, 18); e[..., 17] = 10.0
+        self.register_buffer("empty_sem", e, persistent=False)
+        self.register_buffer("empty_mean", torch.tensor([[[0.0, 0.0, -1.0]]]), persistent=False)
+        self.register_buffer("empty_scale", torch.tensor([[[100.0, 100.0, 8.0]]]), persistent=False)
+        self.register_buffer("empty_rot", torch.tensor([[[1.0, 0.0, 0.0, 0.0]]]), persistent=False)
 
     def gaussians(self, anchor):
         c = self.cfg
-        r = anchor.new_tensor(PC_RANGE)
         # keep the centres strictly inside the grid (the head asserts it in the reference)
-        means = (0.001 + 0.998 * _sig(anchor[..., :3])) * (r[3:] - r[:3]) + r[:3]
+        means = (0.001 + 0.998 * _sig(anchor[..., :3])) * self.pc_span + self.pc_lo
         lo, hi = c["scale_range"]
         scales = lo + (hi - lo) * _sig(anchor[..., 3:6])
         rots = F.normalize(anchor[..., 6:10], dim=-1)
@@ -169,11 +176,10 @@ class Frame(nn.Module):
         sem = anchor[..., k:]
         if c["with_empty"]:   # gaussian_head.py:90-102
             sem = torch.cat([F.softplus(sem), torch.zeros_like(sem[..., :1])], dim=-1)
-            e = sem.new_zeros(1, 1, 18); e[..., 17] = 10.0
-            means = torch.cat([means, means.new_tensor([[[0.0, 0.0, -1.0]]])], dim=1)
-            scales = torch.cat([scales, scales.new_tensor([[[100.0, 100.0, 8.0]]])], dim=1)
-            rots = torch.cat([rots, rots.new_tensor([[[1.0, 0.0, 0.0, 0.0]]])], dim=1)
-            sem = torch.cat([sem, e], dim=1)
+            means = torch.cat([means, self.empty_mean], dim=1)
+            scales = torch.cat([scales, self.empty_scale], dim=1)
+            rots = torch.cat([rots, self.empty_rot], dim=1)
+            sem = torch.cat([sem, self.empty_sem], dim=1)
             opa = torch.cat([opa, opa.new_ones(1, 1, 1)], dim=1)
         return means, scales, rots, opa, sem
 

@@ -25,16 +25,18 @@ lib = _lib.load()
 for _ in range(5): plan.run()
 torch.cuda.synchronize()
 nb = 1256
-tl = torch.zeros(nb * 5, dtype=torch.int64, device=dev)
+tl = torch.zeros(nb * 5 + nb * 24, dtype=torch.int64, device=dev)
 lib.gf_debug_set_timeline.argtypes = [ctypes.c_void_p]
 lib.gf_debug_set_timeline(tl.data_ptr())
 plan.run(); torch.cuda.synchronize()
 lib.gf_debug_set_timeline(None)
 raw = tl.cpu().numpy()
-ids = raw[4 * nb:]
+ids = raw[4 * nb:5 * nb]
+extra = raw[5 * nb:].reshape(nb, 4, 6).astype(np.float64)   # per (tile, wave): cycles waiting for records, operand prep, blocks, groups, tile total
 T = raw[:4 * nb].reshape(nb, 4).astype(np.float64)
 valid = T[:, 0] > 0
 ids = ids[valid]
+extra = extra[valid]
 T = T[T[:, 0] > 0]
 t0 = T[:, 0].min()
 T = (T - t0) / 100.0  # 100 MHz -> us
@@ -43,6 +45,13 @@ np.savez("gpurun_out/timeline_blocks_%s.npz" % config, block=np.nonzero(valid)[0
 print("blocks", len(T), "kernel span us", T[:, 3].max())
 for name, col in (("start", 0), ("list built", 1), ("consumed", 2), ("end", 3)):
     v = T[:, col]; print(f"{name:12s} min {v.min():7.2f} p50 {np.median(v):7.2f} p90 {np.percentile(v,90):7.2f} max {v.max():7.2f}")
+g = extra[..., 3]
+if g.sum() > 0:
+    tot = extra[..., :3].sum(axis=(0, 1)); ng = g.sum()
+    print("matrix-core kernel, per group of 32 hits (shader cycles incl. ~4 s_memtime reads): records wait %.0f  operand prep %.0f  blocks (exp + MFMA issue) %.0f  | groups %.0f, per (tile, wave) %.2f" %
+          (tot[0] / ng, tot[1] / ng, tot[2] / ng, ng, ng / max((g > 0).sum(), 1)))
+    tt = extra[..., 4][g > 0]
+    print("   tile time per wave (cycles): mean %.0f;  in-group share %.2f" % (tt.mean(), extra[..., :3].sum() / tt.sum()))
 d_prod = T[:, 1] - T[:, 0]; d_cons = T[:, 2] - T[:, 1]; d_epi = T[:, 3] - T[:, 2]
 for name, v in (("produce", d_prod), ("consume", d_cons), ("epilogue", d_epi), ("total", T[:, 3] - T[:, 0])):
     print(f"dur {name:9s} mean {v.mean():7.2f} p50 {np.median(v):7.2f} p90 {np.percentile(v,90):7.2f} max {v.max():7.2f}")
