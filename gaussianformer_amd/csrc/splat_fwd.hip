@@ -31,6 +31,9 @@
 
 #include "gf_common.hpp"
 
+#ifndef GF_EXPERIMENT
+#define GF_EXPERIMENT 0  // development only (tools/gpu): 1 no output stores, 2 every hit reads record 0, 3 no fp64 theta, 4 no blocks, 5 no producer
+#endif
 #ifndef GF_TIMELINE
 #define GF_TIMELINE 0  // -DGF_TIMELINE=1: per-workgroup timestamps of the render kernel (tools/timeline.py)
 #endif
@@ -1034,6 +1037,12 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     }
     if (!tile_ok) return;
 
+#if GF_EXPERIMENT == 6
+    for (int d = 0; d < (int)((blockIdx.x >> 3) & 3u); ++d) __builtin_amdgcn_s_sleep(45);   // staggered start (~1.2 us steps)
+#endif
+#if GF_EXPERIMENT == 7
+    for (int d = 0; d < (int)((blockIdx.x >> 3) & 7u); ++d) __builtin_amdgcn_s_sleep(45);
+#endif
     const int n = lane & 31, h = lane >> 5;
     uint32_t *q_id = s_queue[wave];
     float *S = s_sem[wave];
@@ -1075,7 +1084,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     (void)nslots;
     for (;;) {  // tiles of this workgroup
 #if GF_TIMELINE
-    unsigned long long tacc[4] = {0, 0, 0, 0};
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tstore = 0;
     const unsigned long long ttile0 = __builtin_amdgcn_s_memtime();
 #endif
     const int Xw = X0 + 4 * (wave & 1);
@@ -1265,7 +1274,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     // ---- operands of the group: lane (g = n, h)
                     const bool live = n < qn;
                     const uint32_t id = q_id[live ? n : 0];
-                    const float4 *rp = reinterpret_cast<const float4 *>(a.records + (size_t)id * kRecDwords);
+                    const float4 *rp = reinterpret_cast<const float4 *>(a.records + (size_t)(GF_EXPERIMENT == 2 ? 0u : id) * kRecDwords);
                     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
                     const float4 e0 = rp[3 + 3 * h], e1 = rp[4 + 3 * h], e2 = rp[h ? 7 : 5];
 #if GF_TIMELINE
@@ -1290,7 +1299,9 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                         const double L = 1.4426950408889634074;
                         const double c0 = r1.x, c1 = r1.y, c2 = r1.z, c3 = r1.w, c4 = r2.x, c5 = r2.y;
                         double th[5];
-                        if (h == 0) {  // constant and linear terms + xx: the ones that depend on the brick
+                        if (GF_EXPERIMENT == 3) {
+                            th[0] = th[1] = th[2] = th[3] = th[4] = (double)r1.x;
+                        } else if (h == 0) {  // constant and linear terms + xx: the ones that depend on the brick
                             const double ex = Cx - (double)r0.x, ey = Cy - (double)r0.y, ez = Cz - (double)r0.z;
                             const double gx = c0 * ex + c3 * ey + c5 * ez, gy = c3 * ex + c1 * ey + c4 * ez, gz = c5 * ex + c4 * ey + c2 * ez;
                             th[0] = -0.5 * L * (ex * gx + ey * gy + ez * gz);
@@ -1374,8 +1385,12 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                             for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wh[k][kh].v, acc[b0 + k], 0, 0, 0);
                         }
                     };
-                    pair(0);
-                    pair(2);
+                    if (GF_EXPERIMENT != 4) {
+                        pair(0);
+                        pair(2);
+                    } else {
+                        asm volatile("" :: "v"(t1.v), "v"(t2.v), "v"(t3.v), "v"(tb.v), "v"(sh[0].v), "v"(sh[1].v), "v"(sl[0].v), "v"(sl[1].v));
+                    }
 #if GF_TIMELINE
                     asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
                     const unsigned long long tg3 = __builtin_amdgcn_s_memtime();
@@ -1400,44 +1415,35 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 #if GF_TIMELINE
         if (a.timeline && tid == 0) a.timeline[4 * (size_t)logical + 2] = wall_clock64();
 #endif
-        // ---- accumulators C[channel (r&3) + 8 (r>>2) + 4 h][voxel n of block b] -> rows [voxel-in-brick][18] in LDS,
-        // then the same 16-byte stores as gf_splat_render_kernel; lower brick (blocks 0, 1), then upper (2, 3)
-        if (!LABELS || a.out_logits) {
+        // ---- accumulators C[channel (r&3) + 8 (r>>2) + 4 h][voxel n of block b] -> out_logits, straight from the registers:
+        // lane (n, h) holds, for its voxel, channels 4h..4h+3 (r = 0..3), 8+4h..11+4h (r = 4..7) and -- h = 0 only -- 16, 17
+        // (r = 8, 9), so a block leaves as two 16-byte stores per lane (lanes n and n + 32 write adjacent pieces of one
+        // 72-byte row) and one 8-byte store of the lower half-wave.  (The version that transposed the rows through LDS
+        // into 16-byte stores over 288-byte runs spent 80 dependent LDS operations per wave here: 9.5 of 45 us.)
+        struct __attribute__((packed, aligned(4))) Out4 { float x, y, z, w; };
+        struct __attribute__((packed, aligned(4))) Out2 { float x, y; };
+        if (GF_EXPERIMENT == 1) {
+            asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+        } else if (!LABELS || a.out_logits) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float *stage = s_stage[wave][half];  // wave-private: only LDS ordering inside the wave is needed, the
-                const int Zb = Zw + 4 * half;        // global stores of the lower brick are not waited for
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int c = (r & 3) + 8 * (r >> 2) + 4 * h;  // registers 10..15 hold channels >= 18: never stored
-                        if (c < kC) stage[(32 * bb + n) * kC + c] = acc[2 * half + bb][r];
-                    }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (Zb < a.D) {
-                    if ((a.D & 3) == 0) {
-                        for (int i = lane; i < 16 * kC; i += 64) {
-                            const int run = i / kC, k = i - run * kC;
-                            const int cx = Xw + (run >> 2), cy = Y0 + (run & 3);
-                            if (cx < a.H && cy < a.W) {
-                                const size_t row0 = ((size_t)cx * a.W + cy) * a.D + Zb;
-                                const float4 val = *reinterpret_cast<const float4 *>(stage + i * 4);
-                                store_row4(a.out_logits + row0 * kC + k * 4, val);
-                            }
-                        }
-                    } else {
-                        for (int i = lane; i < 64 * kC; i += 64) {
-                            const int l = i / kC, ch = i - l * kC;
-                            const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zb + (l & 3);
-                            if (cx < a.H && cy < a.W && cz < a.D)
-                                a.out_logits[(((size_t)cx * a.W + cy) * a.D + cz) * kC + ch] = stage[i];
-                        }
-                    }
+            for (int b = 0; b < 4; ++b) {
+                const int cx = Xw + 2 * (b & 1) + (n >> 4), cy = Y0 + ((n >> 2) & 3), cz = Zw + 4 * (b >> 1) + (n & 3);
+                if (cx < a.H && cy < a.W && cz < a.D) {
+                    float *row = a.out_logits + (((size_t)cx * a.W + cy) * a.D + cz) * kC;
+                    *reinterpret_cast<Out4 *>(row + 4 * h) = Out4{acc[b][0], acc[b][1], acc[b][2], acc[b][3]};
+                    *reinterpret_cast<Out4 *>(row + 8 + 4 * h) = Out4{acc[b][4], acc[b][5], acc[b][6], acc[b][7]};
+                    if (h == 0) *reinterpret_cast<Out2 *>(row + 16) = Out2{acc[b][8], acc[b][9]};
                 }
             }
         }
+#if GF_TIMELINE
+        {   // how long do the output stores of this wave take to be acknowledged?  (debug attribution only)
+            const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tacc[3] += 0;
+            tstore += __builtin_amdgcn_s_memtime() - ts0;
+        }
+#endif
         if (!last_zg) {
             __syncthreads();  // the next z group rebuilds the list
         }
@@ -1448,7 +1454,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 #if GF_TIMELINE
     if (a.timeline && lane == 0) {
         unsigned long long *dst = a.timeline + 5 * (size_t)nslots + ((size_t)logical * 4 + wave) * 6;
-        dst[0] = tacc[0]; dst[1] = tacc[1]; dst[2] = tacc[2]; dst[3] = tacc[3]; dst[4] = __builtin_amdgcn_s_memtime() - ttile0;
+        dst[0] = tacc[0]; dst[1] = tacc[1]; dst[2] = tacc[2]; dst[3] = tacc[3]; dst[4] = __builtin_amdgcn_s_memtime() - ttile0; dst[5] = tstore;
     }
 #endif
     // ---- next tile of this workgroup

@@ -51,7 +51,7 @@ if g.sum() > 0:
     print("matrix-core kernel, per group of 32 hits (shader cycles incl. ~4 s_memtime reads): records wait %.0f  operand prep %.0f  blocks (exp + MFMA issue) %.0f  | groups %.0f, per (tile, wave) %.2f" %
           (tot[0] / ng, tot[1] / ng, tot[2] / ng, ng, ng / max((g > 0).sum(), 1)))
     tt = extra[..., 4][g > 0]
-    print("   tile time per wave (cycles): mean %.0f;  in-group share %.2f" % (tt.mean(), extra[..., :3].sum() / tt.sum()))
+    print("   tile time per wave (cycles): mean %.0f;  in-group share %.2f;  wait for the output stores to be acknowledged: mean %.0f" % (tt.mean(), extra[..., :3].sum() / tt.sum(), extra[..., 5][g > 0].mean()))
 d_prod = T[:, 1] - T[:, 0]; d_cons = T[:, 2] - T[:, 1]; d_epi = T[:, 3] - T[:, 2]
 for name, v in (("produce", d_prod), ("consume", d_cons), ("epilogue", d_epi), ("total", T[:, 3] - T[:, 0])):
     print(f"dur {name:9s} mean {v.mean():7.2f} p50 {np.median(v):7.2f} p90 {np.percentile(v,90):7.2f} max {v.max():7.2f}")
