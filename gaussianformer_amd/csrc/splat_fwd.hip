@@ -956,7 +956,7 @@ union H8 {
     _Float16 e[8];
 };
 constexpr int kRowWords = 3072;  // bitmask row length up to which the matrix-core kernel's producer stages the whole row in LDS (P <= 196 608)
-constexpr int kQCap = 96;  // hit queue entries per wave (a group of 32 leaves as soon as it is full; a batch adds <= 64)
+constexpr int kQCap = 128;  // hit queue entries per wave, a ring (power of two): <= 63 waiting + a batch of <= 64
 constexpr int kSRow = 36;  // floats per channel row of the staged opacity * semantics (32 Gaussians + pad: conflict-free b128 reads)
 
 // three f16 terms of an fp64 value (33 bits): the value as a (hi, lo) pair of floats, then exact fp32 residuals
@@ -1082,6 +1082,22 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 
     const int nslots = per_xcd * 8;  // timeline slots (debug builds)
     (void)nslots;
+    // the wave's record slot: six pieces of 1 KB (lane-linear, as LDS-DMA writes them) at the start of its part of the staging area
+    float4 *slot = reinterpret_cast<float4 *>(&s_stage[wave][0][0]);
+    auto request_records_at = [&](int qh, int start, int count) {
+        const uint32_t id = GF_EXPERIMENT == 2 ? 0u : q_id[(qh + start + (n < count ? n : 0)) & (kQCap - 1)];
+        const char *rec = reinterpret_cast<const char *>(a.records + (size_t)id * kRecDwords);
+        const int o3 = (3 + 3 * h) * 16, o4 = (4 + 3 * h) * 16, o5 = (h ? 7 : 5) * 16;
+        char *dst = reinterpret_cast<char *>(slot);
+        using gptr = const __attribute__((address_space(1))) void *;
+        using lptr = __attribute__((address_space(3))) void *;
+        __builtin_amdgcn_global_load_lds((gptr)(rec), (lptr)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + 16), (lptr)(dst + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + 32), (lptr)(dst + 2048), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o3), (lptr)(dst + 3072), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o4), (lptr)(dst + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o5), (lptr)(dst + 5120), 16, 0, 0);
+    };
     for (;;) {  // tiles of this workgroup
 #if GF_TIMELINE
     unsigned long long tacc[4] = {0, 0, 0, 0}, tstore = 0;
@@ -1103,7 +1119,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         f32x16 acc[4];
         const double Cx = p0x + ((double)Xw + 1.5) * sx, Cy = p0y + ((double)Y0 + 1.5) * sy, Cz = p0z + ((double)Zw + 3.5) * sz;
 
-        int list_len = 0, w_next = 0, wi = 0, grp = 0, ngrp = 0, total = 0, off = 0, qlen = 0;
+        int list_len = 0, w_next = 0, wi = 0, grp = 0, ngrp = 0, total = 0, off = 0, qlen = 0, qhead = 0, npend = 0;
         unsigned long long hits = 0ull;
         bool done = false;
         // The next tile is claimed NOW (one returning device-scope atomic, ~1-2 us): its answer is first looked at when this
@@ -1261,24 +1277,38 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     hit = ux(blo) < Xw + 4 && ux(bhi) > Xw && uy(blo) < Y0 + 4 && uy(bhi) > Y0 && uz(blo) < Zw + 8 && uz(bhi) > Zw;
                 }
                 const unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
-                if (hit) q_id[qlen + (int)mbcnt(todo)] = eg;
+                if (hit) q_id[(qhead + qlen + (int)mbcnt(todo)) & (kQCap - 1)] = eg;
                 qlen += __builtin_popcountll(todo);
                 const bool last = done && base + 64 >= list_len;
-                while (qlen >= 32 || (last && qlen > 0)) {
-                    const int qn = min(qlen, 32);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                // Groups of 32 hits leave the queue through a one-deep pipeline: the six 16-byte record pieces each lane needs
+                // come by LDS-DMA into the wave's slot of the (otherwise idle) staging area, requested one group AHEAD -- the
+                // request for group k + 1 goes out as soon as group k's pieces have been read into registers, and travels
+                // under group k's operand preparation and its blocks.  (Loading them where they were used left ~1400 cycles
+                // of exposed latency per group: 4.7 of 45 us with every hit reading one L2-hot record instead.)
+                while (true) {
+                    if (npend == 0) {
+                        if (!(qlen >= 32 || (last && qlen > 0))) break;
+                        npend = min(qlen, 32);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        request_records_at(qhead, 0, npend);
+                    }
+                    const int avail = qlen - npend;
+                    if (!(avail >= 32 || last)) break;   // the successor is requested before this group is worked on
+                    const int qn = npend;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pending group's pieces have landed in the slot
 #if GF_TIMELINE
                     const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
 #endif
                     // ---- operands of the group: lane (g = n, h)
                     const bool live = n < qn;
-                    const uint32_t id = q_id[live ? n : 0];
-                    const float4 *rp = reinterpret_cast<const float4 *>(a.records + (size_t)(GF_EXPERIMENT == 2 ? 0u : id) * kRecDwords);
-                    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-                    const float4 e0 = rp[3 + 3 * h], e1 = rp[4 + 3 * h], e2 = rp[h ? 7 : 5];
+                    const float4 r0 = slot[lane], r1 = slot[64 + lane], r2 = slot[128 + lane];
+                    const float4 e0 = slot[192 + lane], e1 = slot[256 + lane], e2 = slot[320 + lane];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // every lane has its pieces: the slot is free again
+                    __builtin_amdgcn_wave_barrier();
+                    const int nnext = min(avail, 32);
+                    if (nnext > 0) request_records_at(qhead, qn, nnext);
 #if GF_TIMELINE
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned long long tg1 = __builtin_amdgcn_s_memtime();
 #endif
                     // opacity * semantics -> S[channel][g]; half 0 holds channels 0..11, half 1 channels 12..17
@@ -1396,15 +1426,9 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     const unsigned long long tg3 = __builtin_amdgcn_s_memtime();
                     tacc[0] += tg1 - tg0; tacc[1] += tg2 - tg1; tacc[2] += tg3 - tg2; tacc[3] += 1;
 #endif
-                    // ---- the rest of the queue moves down
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const int rest = qlen - qn;
-                    const uint32_t mv = lane < rest ? q_id[32 + lane] : 0u;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < rest) q_id[lane] = mv;
-                    qlen = rest;
+                    qhead = (qhead + qn) & (kQCap - 1);
+                    qlen -= qn;
+                    npend = nnext;
                 }
             }
             if (done) break;
@@ -1430,9 +1454,17 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 const int cx = Xw + 2 * (b & 1) + (n >> 4), cy = Y0 + ((n >> 2) & 3), cz = Zw + 4 * (b >> 1) + (n & 3);
                 if (cx < a.H && cy < a.W && cz < a.D) {
                     float *row = a.out_logits + (((size_t)cx * a.W + cy) * a.D + cz) * kC;
+#if 1  // non-temporal: the logits are written once and not read again by this kernel (52.5 -> 50.8 us per step at gs25600)
+                    typedef float nt4 __attribute__((ext_vector_type(4), aligned(4)));
+                    typedef float nt2 __attribute__((ext_vector_type(2), aligned(4)));
+                    __builtin_nontemporal_store((nt4){acc[b][0], acc[b][1], acc[b][2], acc[b][3]}, reinterpret_cast<nt4 *>(row + 4 * h));
+                    __builtin_nontemporal_store((nt4){acc[b][4], acc[b][5], acc[b][6], acc[b][7]}, reinterpret_cast<nt4 *>(row + 8 + 4 * h));
+                    if (h == 0) __builtin_nontemporal_store((nt2){acc[b][8], acc[b][9]}, reinterpret_cast<nt2 *>(row + 16));
+#else
                     *reinterpret_cast<Out4 *>(row + 4 * h) = Out4{acc[b][0], acc[b][1], acc[b][2], acc[b][3]};
                     *reinterpret_cast<Out4 *>(row + 8 + 4 * h) = Out4{acc[b][4], acc[b][5], acc[b][6], acc[b][7]};
                     if (h == 0) *reinterpret_cast<Out2 *>(row + 16) = Out2{acc[b][8], acc[b][9]};
+#endif
                 }
             }
         }
