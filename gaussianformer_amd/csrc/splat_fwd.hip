@@ -956,6 +956,7 @@ union H8 {
     _Float16 e[8];
 };
 constexpr int kRowWords = 3072;  // bitmask row length up to which the matrix-core kernel's producer stages the whole row in LDS (P <= 196 608)
+constexpr int kListCapM = 2304;  // tile list entries of the matrix-core kernel: ids (4 B) + packed boxes (8 B) in LDS
 constexpr int kQCap = 128;  // hit queue entries per wave, a ring (power of two): <= 63 waiting + a batch of <= 64
 constexpr int kSRow = 36;  // floats per channel row of the staged opacity * semantics (32 Gaussians + pad: conflict-free b128 reads)
 
@@ -977,7 +978,8 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 {
     // the output staging area is NOT aliased onto the list here (two workgroups per CU leave the LDS for it): a wave that
     // has consumed the last list goes straight to its epilogue while the slower waves of the tile are still accumulating
-    constexpr int kMem = kListCap;
+    constexpr int kMem = kListCapM;
+    __shared__ uint32_t s_blo[kListCapM], s_bhi[kListCapM];   // packed box (lo, hi) of every list entry, by LDS-DMA
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kMem + 64];
     __shared__ __attribute__((aligned(16))) float s_stage[4][2][64 * kC];  // per wave, per brick: no reuse inside a tile
     __shared__ __attribute__((aligned(16))) uint32_t s_queue[4][kQCap];
@@ -1170,7 +1172,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 const uint4 t4 = *reinterpret_cast<const uint4 *>(s_tot + 4 * c);   // the four wave totals of chunk c
                 const int w = c * kBlock + tid;
                 const int chunk_total = (int)(t4.x + t4.y + t4.z + t4.w);
-                if (base + chunk_total <= kListCap && w < a.nwords) {
+                if (base + chunk_total <= kListCapM && w < a.nwords) {
                     unsigned long long h = s_row[w];
                     int pos = base + (int)s_excl[w] + (wave > 0 ? (int)t4.x : 0) + (wave > 1 ? (int)t4.y : 0) + (wave > 2 ? (int)t4.z : 0);
                     const uint32_t id0 = (uint32_t)w * 64u;
@@ -1183,7 +1185,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 base += chunk_total;
             }
             base = __builtin_amdgcn_readfirstlane(base);
-            if (base <= kListCap) {
+            if (base <= kListCapM) {
                 list_len = base;
                 done = true;
             } else {
@@ -1208,7 +1210,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     }
                     const int nn = __builtin_amdgcn_readfirstlane(ge - gb);
                     if (nn > 0) {
-                        if (list_len + nn > kListCap) break;
+                        if (list_len + nn > kListCapM) break;
                         if (mine) {
                             int pos = list_len + off - gb;
                             while (hits) {
@@ -1243,7 +1245,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 }
                 total = __builtin_amdgcn_readfirstlane(total);
                 grp = 0;
-                ngrp = total == 0 ? 0 : (total <= kListCap ? 1 : 32);
+                ngrp = total == 0 ? 0 : (total <= kListCapM ? 1 : 32);
                 if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
                 if (ngrp != 1) __syncthreads();
             }
@@ -1254,22 +1256,25 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
             if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)logical + 1] = wall_clock64();
 #endif
             if (done && last_zg) next_local = s_next;
+            // The packed boxes of the list's Gaussians come into LDS by LDS-DMA (two 4-byte pieces per entry, gathered by id):
+            // the waves then filter the list against their double brick without a single global load, and the only VMEM
+            // traffic of the accumulation are the record requests -- no `s_waitcnt vmcnt(0)` of a box load drains them.
+            for (int b0 = wave * 64; b0 < list_len; b0 += kBlock) {
+                const uint32_t id = s_lg[min(b0 + lane, list_len - 1)];
+                using gptr = const __attribute__((address_space(1))) void *;
+                using lptr = __attribute__((address_space(3))) void *;
+                __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0), 4, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             // ---- consume: hits of this wave's double brick -> queue -> groups of 32.  After the last batch of the last
             // list the remainder leaves as a partial group (the loop runs once for an empty final list).
-            uint32_t eg_n = 0;
-            uint2 box_n = make_uint2(0, 0);
-            if (list_len > 0) {
-                eg_n = s_lg[min(lane, list_len - 1)];
-                box_n = a.boxes[eg_n];
-            }
             for (int base = 0; base < list_len || (done && base == 0); base += 64) {
                 const int i = base + lane;
-                const uint32_t eg = eg_n;
-                const uint2 box = box_n;
-                if (list_len > 0) {
-                    eg_n = s_lg[min(i + 64, list_len - 1)];
-                    box_n = a.boxes[eg_n];
-                }
+                const int ic = min(i, max(list_len - 1, 0));
+                const uint32_t eg = s_lg[ic];
+                const uint2 box = make_uint2(s_blo[ic], s_bhi[ic]);
                 // a hit = the Gaussian's box meets this wave's double brick (the per-voxel box test rides on the MFMAs)
                 bool hit = false;
                 if (i < list_len) {
@@ -1449,33 +1454,33 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         if (GF_EXPERIMENT == 1) {
             asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
         } else if (!LABELS || a.out_logits) {
+            // All four row addresses first, each in registers of its own, then the stores back to back: hipcc makes a store's
+            // address and data registers wait for the store to COMPLETE (vmcnt) before they are written again, so addresses
+            // computed block by block in the same registers put a full write round trip between the blocks.
+            typedef __attribute__((address_space(1))) float gfloat;   // global address space: keeps the stores global_store (not flat)
+            gfloat *rows[4];
+            bool inside[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int cx = Xw + 2 * (b & 1) + (n >> 4), cy = Y0 + ((n >> 2) & 3), cz = Zw + 4 * (b >> 1) + (n & 3);
-                if (cx < a.H && cy < a.W && cz < a.D) {
-                    float *row = a.out_logits + (((size_t)cx * a.W + cy) * a.D + cz) * kC;
-#if 1  // non-temporal: the logits are written once and not read again by this kernel (52.5 -> 50.8 us per step at gs25600)
-                    typedef float nt4 __attribute__((ext_vector_type(4), aligned(4)));
-                    typedef float nt2 __attribute__((ext_vector_type(2), aligned(4)));
-                    __builtin_nontemporal_store((nt4){acc[b][0], acc[b][1], acc[b][2], acc[b][3]}, reinterpret_cast<nt4 *>(row + 4 * h));
-                    __builtin_nontemporal_store((nt4){acc[b][4], acc[b][5], acc[b][6], acc[b][7]}, reinterpret_cast<nt4 *>(row + 8 + 4 * h));
-                    if (h == 0) __builtin_nontemporal_store((nt2){acc[b][8], acc[b][9]}, reinterpret_cast<nt2 *>(row + 16));
-#else
-                    *reinterpret_cast<Out4 *>(row + 4 * h) = Out4{acc[b][0], acc[b][1], acc[b][2], acc[b][3]};
-                    *reinterpret_cast<Out4 *>(row + 8 + 4 * h) = Out4{acc[b][4], acc[b][5], acc[b][6], acc[b][7]};
-                    if (h == 0) *reinterpret_cast<Out2 *>(row + 16) = Out2{acc[b][8], acc[b][9]};
-#endif
+                inside[b] = cx < a.H && cy < a.W && cz < a.D;
+                rows[b] = (gfloat *)a.out_logits + (((size_t)(inside[b] ? cx : 0) * a.W + (inside[b] ? cy : 0)) * a.D + (inside[b] ? cz : 0)) * kC;
+            }
+            asm volatile("" : "+v"(rows[0]), "+v"(rows[1]), "+v"(rows[2]), "+v"(rows[3]));
+            typedef float nt4v __attribute__((ext_vector_type(4), aligned(4)));
+            typedef float nt2v __attribute__((ext_vector_type(2), aligned(4)));
+            typedef __attribute__((address_space(1))) nt4v nt4;
+            typedef __attribute__((address_space(1))) nt2v nt2;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (inside[b]) {
+                    // non-temporal: the logits are written once and not read again by this kernel (52.5 -> 50.8 us per step at gs25600)
+                    __builtin_nontemporal_store((nt4v){acc[b][0], acc[b][1], acc[b][2], acc[b][3]}, (nt4 *)(rows[b] + 4 * h));
+                    __builtin_nontemporal_store((nt4v){acc[b][4], acc[b][5], acc[b][6], acc[b][7]}, (nt4 *)(rows[b] + 8 + 4 * h));
+                    if (h == 0) __builtin_nontemporal_store((nt2v){acc[b][8], acc[b][9]}, (nt2 *)(rows[b] + 16));
                 }
             }
         }
-#if GF_TIMELINE
-        {   // how long do the output stores of this wave take to be acknowledged?  (debug attribution only)
-            const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tacc[3] += 0;
-            tstore += __builtin_amdgcn_s_memtime() - ts0;
-        }
-#endif
         if (!last_zg) {
             __syncthreads();  // the next z group rebuilds the list
         }
