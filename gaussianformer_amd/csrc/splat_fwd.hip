@@ -1130,8 +1130,12 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         // Scope: the counter of XCD x is only touched by the workgroups with blockIdx % 8 == x, which run on that XCD, so a
         // workgroup-scope RMW -- performed in the XCD's own L2, no trip to the memory side -- is enough.  Should the
         // placement ever differ, two L2s hand out the same index and a tile is computed twice (same values): never skipped.
-        if (last_zg && tid == 0)
-            claimed = __hip_atomic_fetch_add(a.tile_counters + 64 * xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (Inline asm: hipcc waits for a returning atomic at the end of the divergent block that issued it; written this way
+        // its round trip runs under the row's LDS-DMA and both are waited for by the one s_waitcnt below.)
+        if (last_zg && tid == 0) {
+            uint32_t *ctr = a.tile_counters + 64 * xcd;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+        }
         // The producer is a short chain of dependent steps (scan, barrier, LDS): at equal priority it queues behind the
         // other workgroup's accumulation on every SIMD; raised, it costs that workgroup a few hundred issue slots.
         __builtin_amdgcn_s_setprio(3);
@@ -1249,7 +1253,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
                 if (ngrp != 1) __syncthreads();
             }
-            if (done && last_zg && tid == 0) s_next = (int)claimed;
+            if (done && last_zg && tid == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) :: "memory");   // (long since back: waited for with the row)
+                s_next = (int)claimed;
+            }
             __syncthreads();  // list complete (and the next tile claimed)
             __builtin_amdgcn_s_setprio(0);
 #if GF_TIMELINE
@@ -1502,7 +1509,9 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     Y0 = (s % a.nsy) * kSuper + t * kTileY;
     if (!(local < per_xcd && logical < a.ntiles_total)) break;  // workgroup-uniform
     bm = a.bitmask + (size_t)s * a.nrow;
-    __syncthreads();  // the slowest wave is done with the list and the scan scratch
+    // the slowest wave is done with the list and the scan scratch.  LDS ordering only: a full __syncthreads() also waits
+    // (vmcnt) for the output stores just issued to be acknowledged
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
