@@ -31,9 +31,6 @@
 
 #include "gf_common.hpp"
 
-#ifndef GF_EXPERIMENT
-#define GF_EXPERIMENT 0  // development only (tools/gpu): 1 no output stores, 2 every hit reads record 0, 3 no fp64 theta, 4 no blocks, 5 no producer
-#endif
 #ifndef GF_TIMELINE
 #define GF_TIMELINE 0  // -DGF_TIMELINE=1: per-workgroup timestamps of the render kernel (tools/timeline.py)
 #endif
@@ -1039,12 +1036,6 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     }
     if (!tile_ok) return;
 
-#if GF_EXPERIMENT == 6
-    for (int d = 0; d < (int)((blockIdx.x >> 3) & 3u); ++d) __builtin_amdgcn_s_sleep(45);   // staggered start (~1.2 us steps)
-#endif
-#if GF_EXPERIMENT == 7
-    for (int d = 0; d < (int)((blockIdx.x >> 3) & 7u); ++d) __builtin_amdgcn_s_sleep(45);
-#endif
     const int n = lane & 31, h = lane >> 5;
     uint32_t *q_id = s_queue[wave];
     float *S = s_sem[wave];
@@ -1087,7 +1078,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     // the wave's record slot: six pieces of 1 KB (lane-linear, as LDS-DMA writes them) at the start of its part of the staging area
     float4 *slot = reinterpret_cast<float4 *>(&s_stage[wave][0][0]);
     auto request_records_at = [&](int qh, int start, int count) {
-        const uint32_t id = GF_EXPERIMENT == 2 ? 0u : q_id[(qh + start + (n < count ? n : 0)) & (kQCap - 1)];
+        const uint32_t id = q_id[(qh + start + (n < count ? n : 0)) & (kQCap - 1)];
         const char *rec = reinterpret_cast<const char *>(a.records + (size_t)id * kRecDwords);
         const int o3 = (3 + 3 * h) * 16, o4 = (4 + 3 * h) * 16, o5 = (h ? 7 : 5) * 16;
         char *dst = reinterpret_cast<char *>(slot);
@@ -1341,9 +1332,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                         const double L = 1.4426950408889634074;
                         const double c0 = r1.x, c1 = r1.y, c2 = r1.z, c3 = r1.w, c4 = r2.x, c5 = r2.y;
                         double th[5];
-                        if (GF_EXPERIMENT == 3) {
-                            th[0] = th[1] = th[2] = th[3] = th[4] = (double)r1.x;
-                        } else if (h == 0) {  // constant and linear terms + xx: the ones that depend on the brick
+                        if (h == 0) {  // constant and linear terms + xx: the ones that depend on the brick
                             const double ex = Cx - (double)r0.x, ey = Cy - (double)r0.y, ez = Cz - (double)r0.z;
                             const double gx = c0 * ex + c3 * ey + c5 * ez, gy = c3 * ex + c1 * ey + c4 * ez, gz = c5 * ex + c4 * ey + c2 * ez;
                             th[0] = -0.5 * L * (ex * gx + ey * gy + ez * gz);
@@ -1427,12 +1416,8 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                             for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wh[k][kh].v, acc[b0 + k], 0, 0, 0);
                         }
                     };
-                    if (GF_EXPERIMENT != 4) {
-                        pair(0);
-                        pair(2);
-                    } else {
-                        asm volatile("" :: "v"(t1.v), "v"(t2.v), "v"(t3.v), "v"(tb.v), "v"(sh[0].v), "v"(sh[1].v), "v"(sl[0].v), "v"(sl[1].v));
-                    }
+                    pair(0);
+                    pair(2);
 #if GF_TIMELINE
                     asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
                     const unsigned long long tg3 = __builtin_amdgcn_s_memtime();
@@ -1456,11 +1441,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         // (r = 8, 9), so a block leaves as two 16-byte stores per lane (lanes n and n + 32 write adjacent pieces of one
         // 72-byte row) and one 8-byte store of the lower half-wave.  (The version that transposed the rows through LDS
         // into 16-byte stores over 288-byte runs spent 80 dependent LDS operations per wave here: 9.5 of 45 us.)
-        struct __attribute__((packed, aligned(4))) Out4 { float x, y, z, w; };
-        struct __attribute__((packed, aligned(4))) Out2 { float x, y; };
-        if (GF_EXPERIMENT == 1) {
-            asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
-        } else if (!LABELS || a.out_logits) {
+        if (!LABELS || a.out_logits) {
             // All four row addresses first, each in registers of its own, then the stores back to back: hipcc makes a store's
             // address and data registers wait for the store to COMPLETE (vmcnt) before they are written again, so addresses
             // computed block by block in the same registers put a full write round trip between the blocks.
@@ -1551,6 +1532,8 @@ static int mfma_grid(int ntiles_total)
         cus = n;
     }
     const int per_xcd = (ntiles_total + 7) / 8;
+    // every slot taken (two workgroups per CU).  Whole rounds -- 53 workgroups per XCD for 157 tiles, so that the third round
+    // has no idle slots -- measured the same at gs25600 and 6 % slower at gs144000: throughput beats round arithmetic.
     return 8 * std::min(per_xcd, std::max(1, 2 * cus / 8));
 }
 
