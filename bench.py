@@ -22,8 +22,9 @@ Rank 0 prints ONE JSON line.  Next to ``value``, never instead of it:
          (BASELINE config [2]: the native ops of a training step chained through autograd, tools/bench_step.py),
          ``exact_fp32_kernel``, ``two_stream``, ``hip_graph``;
   N > 1  ``kernel_only`` (the same shards without the collective), ``gs144000`` (BASELINE config [4]: the 144 000-Gaussian
-         set sharded N-way, with and without the all-reduce) and ``reduce_scatter_labels`` (reduce-scatter -> labels on the
-         owned slab -> all-gather of labels).
+         set sharded N-way, with and without the all-reduce), ``reduce_scatter_labels`` (reduce-scatter -> labels on the
+         owned slab -> all-gather of labels) and ``slab_partition`` / ``slab_partition_gs144000`` (the SPATIAL partition:
+         every rank renders its band of voxel rows from all Gaussians, no reduction, all-gather of logits or labels).
 """
 import argparse
 import ctypes
@@ -400,9 +401,64 @@ def main():
                     "note": "same K steps ending in labels: reduce-scatter of the partial logits, labels on the owned slab, "
                             "all-gather of the labels"}
 
+        def slab(config):
+            # SPATIAL partition of the same frame (sharded.slab_bounds): rank r renders voxel rows [x0, x1) from ALL the
+            # Gaussians (boxes clipped to the slab inside the op), no reduction; the slabs are all-gathered -- the fp32
+            # logits (46 MB / world per rank) or, for inference that ends in labels, 8 bytes per voxel.
+            from gaussianformer_amd.head import occupancy_labels
+            from gaussianformer_amd.sharded import slab_bounds
+            w2 = wl if config == args.config else Workload(config)
+            s2 = w2.si
+            if s2.variant == "prob":
+                return None
+            pi2, mi2, radii2, cov62 = w2.prep
+            x0, x1 = slab_bounds(s2.H, rank, world)
+            plane = s2.W * s2.D
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            shift = np.array([x0, 0, 0], dtype=pi2.dtype)
+            plan = SplatForwardPlan(w2.variant, up(s2.pts[x0 * plane:x1 * plane]), up(pi2[x0 * plane:x1 * plane] - shift), up(s2.means3D),
+                                    up(mi2 - shift), up(s2.opacities), up(s2.semantics), up(radii2), up(cov62), x1 - x0, s2.W, s2.D,
+                                    flags=_lib.GF_PTS_AUTO)
+            bounds = [slab_bounds(s2.H, r, world) for r in range(world)]
+            tallest = max(b - a for a, b in bounds) * plane
+
+            def gather(t):
+                mine = t.new_zeros((tallest,) + tuple(t.shape[1:]))
+                mine[:t.shape[0]] = t
+                if shared_gpu:
+                    host = torch.empty((world * tallest,) + tuple(t.shape[1:]), dtype=t.dtype)
+                    dist.all_gather_into_tensor(host, mine.cpu())
+                    buf = host.to(dev)
+                else:
+                    buf = t.new_empty((world * tallest,) + tuple(t.shape[1:]))
+                    dist.all_gather_into_tensor(buf, mine)
+                return torch.cat([buf[r * tallest:r * tallest + (b - a) * plane] for r, (a, b) in enumerate(bounds)], dim=0)
+            steps = args.steps if config == args.config else max(10, args.steps // 4)
+            warm = max(2, args.warmup // 2)
+            t_local = timed(lambda: plan.run(w2.stream), steps, warm)
+            t_logits = timed(lambda: gather(plan.run(w2.stream)), steps, warm)
+            t_labels = timed(lambda: gather(occupancy_labels(plan.run(w2.stream))), steps, warm)
+            out = {"config": f"{config}: voxel rows {x0}..{x1} of {s2.H} on rank 0, all {w2.P_total} Gaussians passed to every rank",
+                   "unit": "Gaussians/s", "steps": steps,
+                   "splat_only": {"value": w2.P_total / (t_local / steps), "ms_per_step": t_local / steps * 1e3},
+                   "all_gather_logits": {"value": w2.P_total / (t_logits / steps), "ms_per_step": t_logits / steps * 1e3},
+                   "all_gather_labels": {"value": w2.P_total / (t_labels / steps), "ms_per_step": t_labels / steps * 1e3},
+                   "note": "no reduction: every voxel is computed by one rank from the same Gaussians in the same order as on one GPU"}
+            if os.environ.get("GF_BENCH_CHECK") == "1":
+                full_plan = SplatForwardPlan(w2.variant, up(s2.pts), up(pi2), up(s2.means3D), up(mi2), up(s2.opacities), up(s2.semantics),
+                                             up(radii2), up(cov62), s2.H, s2.W, s2.D, flags=_lib.GF_PTS_AUTO)
+                want = full_plan.run().clone()
+                got = gather(plan.run(w2.stream))
+                torch.cuda.synchronize()
+                out["check_bit_identical_to_single_device"] = bool(torch.equal(got.view(torch.int32), want.view(torch.int32)))
+                assert out["check_bit_identical_to_single_device"]
+            return out
+
         extra("kernel_only", kernel_only)
         extra("gs144000", gs144000)
         extra("reduce_scatter_labels", rs_labels)
+        extra("slab_partition", lambda: slab(args.config))
+        extra("slab_partition_gs144000", lambda: slab("nuscenes_gs144000"))
         if os.environ.get("GF_BENCH_CHECK") == "1":
             # the sharded sum against the single-device result of the whole set (tests)
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)

@@ -361,6 +361,30 @@ class _AggregatorBase(nn.Module):
 
     _radii_mode = _lib.GF_RADII_SCALAR
 
+    def _radii(self, scales):
+        """Integer radii of the wrapper (local_aggregate/__init__.py:141; prob: :150-152; prob_fast: :151)."""
+        raise NotImplementedError
+
+    def forward_slab(self, x0, x1, pts, means3D, opacities, semantics, scales, cov3D):
+        """The outputs of ``forward`` for the voxel rows ``x0 <= x < x1`` only -- the per-rank op of the SPATIAL (slab)
+        partition (``sharded.slab_splat_forward``; an addition over the reference, which runs replicas only, train.py:41-43).
+        ``pts [1, H*W*D, 3]`` must be the dense voxel-centre grid in the reference's x-major order; all P Gaussians
+        are passed: the integer coordinates are taken on the FULL grid exactly as ``forward`` takes them and shifted by
+        ``x0`` afterwards, so a Gaussian's box is clipped to the slab the way ``getRect`` clips it to the grid (a box
+        that misses the slab comes out empty and costs nothing), every voxel of the slab sees the Gaussians it sees
+        in the full call, in the same ascending order: the slab's rows equal the full call's rows bit for bit when the
+        slab starts on a multiple of 8 rows (the binning granule; any start with ``matrix_cores=False``).  Differentiable
+        like ``forward``."""
+        assert 0 <= x0 < x1 <= self.H and pts.shape[0] == 1 and pts.shape[1] == self.H * self.W * self.D
+        n0, n1 = x0 * self.W * self.D, x1 * self.W * self.D
+        pts_s, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D, violations = self._prepare(
+            pts[:, n0:n1], means3D, opacities, semantics, scales, cov3D)
+        radii = self._radii(scales)
+        self._raise_on_violation(violations, radii)
+        cov6 = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
+        shift = points_int.new_tensor([x0, 0, 0])
+        return self._splat(pts_s, points_int - shift, means3D, means3D_int - shift, opacities, semantics, radii, cov6, H=x1 - x0)
+
     def _raise_on_violation(self, violations, radii):
         """One host read for the three range conditions the reference asserts one by one
         (local_aggregate/__init__.py:138,140,142): same AssertionError, one synchronisation."""
@@ -421,18 +445,22 @@ class LocalAggregator(_AggregatorBase):
         self.check_inputs = check_inputs
         self._pc_min_host = [float(v) for v in pc_min]
 
-    def _splat(self, pts, *args):
+    def _splat(self, pts, *args, H=None):
+        H = self.H if H is None else H
         if self.matrix_cores is None:
-            exact = pts.shape[0] == self.H * self.W * self.D and not pts_is_exact_lattice(pts, self.H, self.W, self.D)
+            exact = pts.shape[0] == H * self.W * self.D and not pts_is_exact_lattice(pts, H, self.W, self.D)
             flags = _lib.GF_PTS_AUTO | (_lib.GF_EXACT_FP32 if exact else 0)
         else:
             flags = _lib.GF_PTS_AUTO | (_lib.GF_MFMA_SPLAT if self.matrix_cores else _lib.GF_EXACT_FP32)
-        return _LocalAggregate.apply(pts, *args, self.H, self.W, self.D, flags)
+        return _LocalAggregate.apply(pts, *args, H, self.W, self.D, flags)
+
+    def _radii(self, scales):
+        return torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
 
     def forward(self, pts, means3D, opacities, semantics, scales, cov3D):
         pts, points_int, means3D, means3D_int, opacities, semantics, scales, cov3D, violations = self._prepare(
             pts, means3D, opacities, semantics, scales, cov3D)
-        radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
+        radii = self._radii(scales)
         self._raise_on_violation(violations, radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]   # (xx, yy, zz, xy, yz, xz) of the 3x3, :143
         logits = self._splat(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D)
@@ -462,17 +490,20 @@ class LocalAggregatorProb(_AggregatorBase):
     def _radii_mode(self):
         return _lib.GF_RADII_PER_AXIS if self.per_axis_radii else _lib.GF_RADII_SCALAR_CLAMPED
 
-    def _splat(self, *args):
-        return _LocalAggregateProb.apply(*args, self.H, self.W, self.D)
+    def _splat(self, *args, H=None):
+        return _LocalAggregateProb.apply(*args, self.H if H is None else H, self.W, self.D)
 
-    def forward(self, pts, means3D, opas, semantics, scales, cov3D):
-        pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D, violations = self._prepare(
-            pts, means3D, opas, semantics, scales, cov3D)
+    def _radii(self, scales):
         if self.per_axis_radii:
             radii = torch.ceil(scales * self.scale_multiplier / self.grid_size).to(torch.int)
         else:
             radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
-        radii = radii.clamp(min=self.radii_min)
+        return radii.clamp(min=self.radii_min)
+
+    def forward(self, pts, means3D, opas, semantics, scales, cov3D):
+        pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D, violations = self._prepare(
+            pts, means3D, opas, semantics, scales, cov3D)
+        radii = self._radii(scales)
         self._raise_on_violation(violations, radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
         return _LocalAggregateProb.apply(pts, points_int, means3D, means3D_int, opas, semantics, radii, cov3D,
@@ -485,11 +516,7 @@ class LocalAggregatorProb(_AggregatorBase):
         ``sharded.sharded_splat_forward_prob`` exchange before normalising."""
         pts, points_int, means3D, means3D_int, opas, semantics, scales, cov3D, violations = self._prepare(
             pts, means3D, opas, semantics, scales, cov3D)
-        if self.per_axis_radii:
-            radii = torch.ceil(scales * self.scale_multiplier / self.grid_size).to(torch.int)
-        else:
-            radii = torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)
-        radii = radii.clamp(min=self.radii_min)
+        radii = self._radii(scales)
         self._raise_on_violation(violations, radii)
         cov3D = cov3D.flatten(1)[:, [0, 4, 8, 1, 5, 2]]
         numerator, bin_logits, density, probability, _ = splat_forward(

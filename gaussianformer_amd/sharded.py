@@ -1,4 +1,5 @@
-"""Gaussian-sharded splat forward across the GPUs of one node.
+"""Splat forward across the GPUs of one node: the Gaussian-sharded partition north_star names (partial
+grids + one all-reduce) and the spatial slab partition that needs no reduction (``slab_splat_forward``).
 
 The base splat is linear in the Gaussian set: ``logits = sum_g contrib_g``.  Each rank
 splats a contiguous slice of the Gaussians into its own full ``[N,18]`` fp32 grid and the
@@ -37,6 +38,72 @@ def sharded_splat_forward(local_splat, pts, means3D, opacities, semantics, scale
         logits = logits.contiguous()
         dist.all_reduce(logits, op=dist.ReduceOp.SUM, group=group)
     return logits
+
+
+def slab_bounds(H, rank, world_size, align=8):
+    """Voxel rows ``[x0, x1)`` of ``rank``'s slab of an H-row grid: the rows in blocks of ``align`` (8 = the supertile,
+    the granule the forward bins Gaussians by -- a slab that starts on it keeps the full call's tiles, so its rows come
+    out bit-identical to the single-GPU result with either render kernel), blocks dealt contiguously and balanced."""
+    lo, hi = shard_bounds((H + align - 1) // align, rank, world_size)
+    return min(lo * align, H), min(hi * align, H)
+
+
+def slab_splat_forward(aggregator, pts, means3D, opacities, semantics, scales, cov3D, group=None, gather=True):
+    """SPATIAL partition of one frame's splat over the ranks (SURVEY.md §8e "slab partition with halo Gaussians"): rank r
+    renders the voxel rows ``slab_bounds(H, r, world)`` with ``aggregator.forward_slab`` -- every Gaussian is passed,
+    the ones whose box misses the slab are clipped away inside the op (no device-side compaction, no host read) -- and
+    the slabs are ALL-GATHERED.  No reduction: a voxel's value is computed by exactly one rank from the same Gaussians
+    in the same order as in the single-GPU call, so the gathered grid equals the single-GPU grid bit for bit, and the
+    exchange is each rank's own slab (46 MB / world of fp32 logits) instead of a 46 MB all-reduce -- or, through
+    ``slab_splat_labels``, 8 bytes per voxel of labels.  Works for the prob aggregators too (their ratio and product
+    never cross a slab).  ``aggregator`` is a ``LocalAggregator*`` built for the FULL grid; ``gather=False`` returns the
+    rank's own slab ``(x0, x1, outputs)``.  Returns what ``aggregator.forward`` returns, for the full grid."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    x0, x1 = slab_bounds(aggregator.H, rank, world)
+    if x1 <= x0:
+        raise ValueError(f"rank {rank} of {world} owns no rows of an {aggregator.H}-row grid (8-row blocks): use fewer ranks")
+    out = aggregator.forward_slab(x0, x1, pts, means3D, opacities, semantics, scales, cov3D)
+    if not gather:
+        return x0, x1, out
+    if world == 1:
+        return out
+    return _gather_slabs(out, aggregator, world, group)
+
+
+def _gather_slabs(out, aggregator, world, group):
+    """All-gather of per-rank slabs of unequal height: padded to the tallest slab, trimmed on arrival."""
+    H, plane = aggregator.H, aggregator.W * aggregator.D
+    bounds = [slab_bounds(H, r, world) for r in range(world)]
+    tallest = max(b - a for a, b in bounds) * plane
+    single = not isinstance(out, (tuple, list))
+    parts = [out] if single else list(out)
+    gathered = []
+    for t in parts:
+        mine = t.new_zeros((tallest,) + tuple(t.shape[1:]))
+        mine[:t.shape[0]] = t
+        if t.is_cuda and dist.get_backend(group) == "gloo":   # test mode (ranks sharing one GPU): collective on host copies
+            host = torch.empty((world * tallest,) + tuple(t.shape[1:]), dtype=t.dtype)
+            dist.all_gather_into_tensor(host, mine.cpu().contiguous(), group=group)
+            buf = host.to(t.device)
+        else:
+            buf = t.new_empty((world * tallest,) + tuple(t.shape[1:]))
+            dist.all_gather_into_tensor(buf, mine.contiguous(), group=group)
+        gathered.append(torch.cat([buf[r * tallest:r * tallest + (b - a) * plane] for r, (a, b) in enumerate(bounds)], dim=0))
+    return gathered[0] if single else tuple(gathered)
+
+
+def slab_splat_labels(aggregator, labels_fn, pts, means3D, opacities, semantics, scales, cov3D, group=None):
+    """Slab-partitioned inference that ends in labels: every rank labels its own slab (``labels_fn(outputs) -> int64 [n]``,
+    e.g. ``head.occupancy_labels``) and only the labels are all-gathered (5 MB for the 640 000 voxels)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    x0, x1 = slab_bounds(aggregator.H, rank, world)
+    out = aggregator.forward_slab(x0, x1, pts, means3D, opacities, semantics, scales, cov3D)
+    labels = labels_fn(out)
+    if world == 1:
+        return labels
+    return _gather_slabs(labels, aggregator, world, group)
 
 
 def normalise_prob(numerator, keep, density, probability):

@@ -47,3 +47,8 @@ def test_bench_two_rank_strong_scaling_path(gpu):
     assert b["kernel_only"]["ms_per_step"] <= b["ms_per_step"]
     g = b["gs144000"]
     assert "error" not in g and g["kernel_only_ms_per_step"] > 0 and "144000" in g["config"]
+    for key in ("slab_partition", "slab_partition_gs144000"):
+        sp = b[key]
+        assert "error" not in sp, sp
+        assert sp["check_bit_identical_to_single_device"] is True      # no reduction: the gathered grid IS the single-GPU grid
+        assert sp["splat_only"]["ms_per_step"] <= sp["all_gather_logits"]["ms_per_step"]

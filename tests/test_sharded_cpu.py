@@ -12,7 +12,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from gaussianformer_amd.sharded import shard_bounds, sharded_splat_forward, sharded_splat_forward_prob
+from gaussianformer_amd.sharded import (shard_bounds, sharded_splat_forward, sharded_splat_forward_prob, slab_bounds,
+                                        slab_splat_forward, slab_splat_labels)
 from gaussianformer_amd.synthetic import make_splat_inputs
 
 
@@ -132,3 +133,100 @@ def test_two_rank_sharded_prob_forward_matches_single_rank():
     # a world of one is the plain op
     one = sharded_splat_forward_prob(_local_pieces_factory(si), *args)
     assert np.abs(one[0].numpy() - single["logits"]).max() <= 1e-6
+
+
+# ---- spatial (slab) partition: no reduction, the gathered grid equals the single-rank grid bit for bit
+
+class _OracleAggregator:
+    """Stand-in for ``LocalAggregator`` on CPU: the same integer path (full-grid coordinates, shifted by x0) in front
+    of the CPU oracle instead of the HIP kernels."""
+
+    def __init__(self, si, variant="base"):
+        self.si, self.variant = si, variant
+        self.H, self.W, self.D = si.H, si.W, si.D
+
+    def _run(self, x0, x1, pts, means3D, opacities, semantics, scales, cov3D):
+        si = self.si
+        n0, n1 = x0 * self.W * self.D, x1 * self.W * self.D
+        p = pts[0, n0:n1].numpy()
+        pi, mi, radii, cov6 = oracle.prepare_splat_inputs(p, means3D[0].numpy(), scales[0].numpy(), cov3D[0].numpy(), si.pc_min,
+                                                          si.grid_size, si.scale_multiplier,
+                                                          radii_min=1 if self.variant == "prob" else None)
+        shift = np.array([x0, 0, 0], dtype=pi.dtype)
+        out = oracle.splat_forward(self.variant, p, pi - shift, means3D[0].numpy(), mi - shift, opacities[0].numpy(),
+                                   semantics[0].numpy(), radii, cov6, x1 - x0, self.W, self.D, nthreads=1)
+        if self.variant == "prob":
+            return tuple(torch.from_numpy(out[k]) for k in ("logits", "bin_logits", "density"))
+        return torch.from_numpy(out["logits"])
+
+    def forward_slab(self, x0, x1, *args):
+        return self._run(x0, x1, *args)
+
+    def forward(self, *args):
+        return self._run(0, self.H, *args)
+
+
+def test_slab_bounds_partition():
+    for H in (1, 8, 20, 200, 203):
+        for world in (1, 2, 3, 8):
+            cuts = [slab_bounds(H, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == H
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert all(a % 8 == 0 for a, b in cuts if b > a)   # every non-empty slab starts on the binning granule
+    assert [slab_bounds(200, r, 8) for r in range(8)] == [(0, 32), (32, 56), (56, 80), (80, 104), (104, 128), (128, 152), (152, 176), (176, 200)]
+
+
+def _slab_inputs(config):
+    si = make_splat_inputs(config, seed=33, P=257, H=24, W=12, D=8)
+    t = lambda a: torch.from_numpy(a)[None]
+    return si, (t(si.pts), t(si.means3D), t(si.opacities), t(si.semantics), t(si.scales), t(si.cov3D))
+
+
+def _slab_worker(rank, world, port, q, config):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    si, args = _slab_inputs(config)
+    agg = _OracleAggregator(si, "prob" if config.startswith("prob") else "base")
+    out = slab_splat_forward(agg, *args)
+    out = out if isinstance(out, tuple) else (out,)
+    labels = slab_splat_labels(agg, (lambda o: (o[0] if isinstance(o, tuple) else o).argmax(dim=1)), *args)
+    q.put((rank, [o.numpy() for o in out], labels.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_slab(config, world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, q, config)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+def test_two_rank_slab_partition_is_bit_identical_to_single_rank():
+    for config in ("nuscenes_gs25600_solid", "prob_gs6400"):
+        results = _run_slab(config, 2)
+        si, args = _slab_inputs(config)
+        agg = _OracleAggregator(si, "prob" if config.startswith("prob") else "base")
+        single = agg.forward(*args)
+        single = single if isinstance(single, tuple) else (single,)
+        for r in (0, 1):
+            outs, labels = results[r]
+            for a, b in zip(outs, single):
+                # bitwise (NaN-safe): no reduction, every voxel computed once from the same Gaussians in the same order
+                assert np.array_equal(a.view(np.int32), b.numpy().view(np.int32)), config
+            assert np.array_equal(labels, single[0].argmax(dim=1).numpy())
+    # three ranks on 24 rows (3 blocks of 8): one block each
+    results = _run_slab("nuscenes_gs25600_solid", 3)
+    si, args = _slab_inputs("nuscenes_gs25600_solid")
+    single = _OracleAggregator(si).forward(*args).numpy()
+    assert all(np.array_equal(results[r][0][0], single) for r in range(3))
