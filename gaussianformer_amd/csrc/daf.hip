@@ -17,6 +17,8 @@
 // one workgroup per tile adds its taps row by row in registers -- no float atomics; the order
 // of a row's taps follows integer LDS atomics, so the last bits may differ between runs);
 // shapes the sort does not cover fall back to the reference's atomicAdd scatter.
+#include <stdlib.h>
+
 #include "gf_common.hpp"
 
 namespace gf {
@@ -143,6 +145,56 @@ __global__ __launch_bounds__(256) void gf_daf_fwd_kernel(DafArgs a)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) of[j] = acc[j];
     *reinterpret_cast<T *>(o) = ov;
+}
+
+// The same forward with the channel groups pinned to XCDs.  A block b runs on XCD b % 8 (observed placement, used for
+// speed only); here XCD x works on channel group x % G only, for 1 / (8 / G) of the points: each of its bilinear taps
+// is the group's C / G * 4 bytes of a pixel row (128 B at the nuScenes shape: one cache line) and the XCD's 4 MB L2 sees
+// a quarter of the pyramid (22 of 88 MB; the three coarse levels of all cameras, 5.4 MB, then mostly stay resident)
+// instead of all of it -- the gather is bound by where the pyramid lives, not by instructions.  A point's output row
+// is written in G pieces by G different blocks; arithmetic per (point, channel) is unchanged, so results are bit-identical
+// to gf_daf_fwd_kernel.  LPG = lanes per channel group = C / G / 4.
+template <int LPG>
+__global__ __launch_bounds__(256) void gf_daf_fwd_grouped_kernel(DafArgs a, int chunks_per_sub)
+{
+    constexpr int PB = 256 / LPG;          // points per block
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+    const int group = xcd % a.G, sub = xcd / a.G, nsub = 8 / a.G;
+    if (j >= chunks_per_sub) return;
+    const long long chunk = (long long)j * nsub + sub;
+    const long long bp = chunk * PB + threadIdx.x / LPG;   // batch * pts + point
+    if (bp >= (long long)a.B * a.pts) return;
+    const int b = (int)(bp / a.pts);
+    const int c0 = group * (a.C / a.G) + (int)(threadIdx.x % LPG) * 4;
+    const float *loc = a.loc + bp * a.cams * 2;
+    const float *wts = a.weights + bp * a.cams * a.L * a.G + group;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int cam = 0; cam < a.cams; ++cam) {
+        const float loc_w = loc[2 * cam], loc_h = loc[2 * cam + 1];
+        if (!(loc_w > 0 && loc_w < 1 && loc_h > 0 && loc_h < 1)) continue;  // :166
+        const float *fcam = a.feat + ((size_t)b * a.cams + cam) * a.num_feat * a.C + c0;
+#pragma unroll 2
+        for (int s = 0; s < a.L; ++s) {
+            const int h = a.spatial_shape[2 * s], w = a.spatial_shape[2 * s + 1];
+            const float h_im = loc_h * h - 0.5f, w_im = loc_w * w - 0.5f;  // :174-175
+            const Taps t = make_taps(h_im, w_im, h, w);
+            const float *base = fcam + (size_t)a.scale_start[s] * a.C;
+            const Corners c = clamp_corners(t, h, w);
+            float v1[4], v2[4], v3[4], v4[4];
+            vload<4>(base + (size_t)c.r1 * a.C, v1);
+            vload<4>(base + (size_t)c.r2 * a.C, v2);
+            vload<4>(base + (size_t)c.r3 * a.C, v3);
+            vload<4>(base + (size_t)c.r4 * a.C, v4);
+            const float wt = wts[(cam * a.L + s) * a.G];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x1 = t.ok1 ? v1[q] : 0.f, x2 = t.ok2 ? v2[q] : 0.f, x3 = t.ok3 ? v3[q] : 0.f, x4 = t.ok4 ? v4[q] : 0.f;
+                const float val = (t.w1 * x1 + t.w2 * x2 + t.w3 * x3 + t.w4 * x4);  // :51-53
+                acc[q] += val * wt;                                                   // :182
+            }
+        }
+    }
+    *reinterpret_cast<float4 *>(a.out + bp * a.C + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 // butterfly sum over aligned groups of `width` lanes (power of two <= 64)
@@ -667,7 +719,15 @@ extern "C" int gf_daf_forward(int B, int num_cams, int num_feat, int C, int L, i
     a.total = (long long)B * num_pts * (C / vec);
     const long long blocks = (a.total + 255) / 256;
     GF_CHECK_ARG(blocks < (1ll << 31), "problem too large");
-    if (vec == 4) hipLaunchKernelGGL(gf_daf_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    // channel groups pinned to XCDs (gf_daf_fwd_grouped_kernel) where the layout allows: 4 channels per lane, 1 / 2 / 4 / 8
+    // groups of 32 channels (8 lanes)
+    static const bool plain_only = getenv("GF_DAF_PLAIN") != nullptr;   // development switch
+    if (!plain_only && vec == 4 && (G == 1 || G == 2 || G == 4 || G == 8) && C / G == 32) {
+        const int nsub = 8 / G;
+        const long long npts = (long long)B * num_pts, chunks = (npts + 31) / 32;
+        const int chunks_per_sub = (int)((chunks + nsub - 1) / nsub);
+        hipLaunchKernelGGL(gf_daf_fwd_grouped_kernel<8>, dim3((unsigned)(8 * chunks_per_sub)), dim3(256), 0, stream, a, chunks_per_sub);
+    } else if (vec == 4) hipLaunchKernelGGL(gf_daf_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else if (vec == 2) hipLaunchKernelGGL(gf_daf_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(gf_daf_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     GF_CHECK_LAUNCH();
