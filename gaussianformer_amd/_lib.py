@@ -37,6 +37,7 @@ SIGNATURES = {
     "gf_splat_backward": (_i, [_i] * 9 + [_vp] * 20 + [_vp, _sz, _vp]),
     "gf_splat_box_volumes": (_i, [_i] * 5 + [_vp] * 5),
     "gf_daf_forward": (_i, [_i] * 7 + [_vp] * 7),
+    "gf_daf_forward_pinned": (_i, [_i] * 7 + [_vp] * 7),
     "gf_daf_backward": (_i, [_i] * 7 + [_vp] * 10),
     "gf_daf_backward_workspace_bytes": (_sz, [_i] * 7),
     "gf_daf_backward_sorted": (_i, [_i] * 7 + [_vp] * 9 + [_vp, _sz, _vp]),

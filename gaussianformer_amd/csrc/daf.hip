@@ -701,10 +701,9 @@ static int pick_vec(int C, int G)
 
 }  // namespace gf
 
-extern "C" int gf_daf_forward(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,
-                              const float *mc_ms_feat, const int *spatial_shape,
-                              const int *scale_start_index, const float *sampling_location,
-                              const float *weights, float *output, void *stream_)
+static int daf_forward_impl(bool pin_groups, int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,
+                            const float *mc_ms_feat, const int *spatial_shape, const int *scale_start_index,
+                            const float *sampling_location, const float *weights, float *output, void *stream_)
 {
     using namespace gf;
     hipStream_t stream = (hipStream_t)stream_;
@@ -719,10 +718,9 @@ extern "C" int gf_daf_forward(int B, int num_cams, int num_feat, int C, int L, i
     a.total = (long long)B * num_pts * (C / vec);
     const long long blocks = (a.total + 255) / 256;
     GF_CHECK_ARG(blocks < (1ll << 31), "problem too large");
-    // channel groups pinned to XCDs (gf_daf_fwd_grouped_kernel) where the layout allows: 4 channels per lane, 1 / 2 / 4 / 8
-    // groups of 32 channels (8 lanes)
-    static const bool plain_only = getenv("GF_DAF_PLAIN") != nullptr;   // development switch
-    if (!plain_only && vec == 4 && (G == 1 || G == 2 || G == 4 || G == 8) && C / G == 32) {
+    // channel groups pinned to XCDs (gf_daf_fwd_grouped_kernel) on request, where the layout allows: 4 channels per lane,
+    // 1 / 2 / 4 / 8 groups of 32 channels (8 lanes)
+    if (pin_groups && vec == 4 && (G == 1 || G == 2 || G == 4 || G == 8) && C / G == 32) {
         const int nsub = 8 / G;
         const long long npts = (long long)B * num_pts, chunks = (npts + 31) / 32;
         const int chunks_per_sub = (int)((chunks + nsub - 1) / nsub);
@@ -732,6 +730,24 @@ extern "C" int gf_daf_forward(int B, int num_cams, int num_feat, int C, int L, i
     else hipLaunchKernelGGL(gf_daf_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     GF_CHECK_LAUNCH();
     return GF_OK;
+}
+
+extern "C" int gf_daf_forward(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,
+                              const float *mc_ms_feat, const int *spatial_shape,
+                              const int *scale_start_index, const float *sampling_location,
+                              const float *weights, float *output, void *stream_)
+{
+    return daf_forward_impl(false, B, num_cams, num_feat, C, L, num_pts, G, mc_ms_feat, spatial_shape, scale_start_index,
+                            sampling_location, weights, output, stream_);
+}
+
+extern "C" int gf_daf_forward_pinned(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,
+                                     const float *mc_ms_feat, const int *spatial_shape,
+                                     const int *scale_start_index, const float *sampling_location,
+                                     const float *weights, float *output, void *stream_)
+{
+    return daf_forward_impl(true, B, num_cams, num_feat, C, L, num_pts, G, mc_ms_feat, spatial_shape, scale_start_index,
+                            sampling_location, weights, output, stream_);
 }
 
 extern "C" int gf_daf_backward(int B, int num_cams, int num_feat, int C, int L, int num_pts, int G,

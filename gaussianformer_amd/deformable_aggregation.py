@@ -10,18 +10,22 @@ from torch.autograd.function import Function, once_differentiable
 from . import _lib
 
 
-def deformable_aggregation_forward(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights):
+def deformable_aggregation_forward(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights,
+                                   pin_channel_groups=False):
     """Counterpart of ``deformable_aggregation_ext.deformable_aggregation_forward``
-    (ops/src/deformable_aggregation.cpp:41-71): dims are read from the tensor sizes."""
+    (ops/src/deformable_aggregation.cpp:41-71): dims are read from the tensor sizes.  ``pin_channel_groups`` (extra
+    keyword) takes ``gf_daf_forward_pinned``: channel groups pinned to XCDs, bit-identical output, faster when every
+    point is seen by several cameras at unrelated places, slower on projected geometry (include/gf_hip.h)."""
     lib = _lib.load()
     _lib.require_gpu(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights)
     B, cams, num_feat, C = mc_ms_feat.shape
     L, pts, G = spatial_shape.shape[0], sampling_location.shape[1], weights.shape[4]
     out = torch.empty((B, pts, C), dtype=torch.float32, device=mc_ms_feat.device)
     with torch.cuda.device(mc_ms_feat.device):
-        rc = lib.gf_daf_forward(B, cams, num_feat, C, L, pts, G, _lib.ptr(mc_ms_feat), _lib.ptr(spatial_shape),
-                                _lib.ptr(scale_start_index), _lib.ptr(sampling_location), _lib.ptr(weights),
-                                _lib.ptr(out), _lib.current_stream(mc_ms_feat.device))
+        fn = lib.gf_daf_forward_pinned if pin_channel_groups else lib.gf_daf_forward
+        rc = fn(B, cams, num_feat, C, L, pts, G, _lib.ptr(mc_ms_feat), _lib.ptr(spatial_shape),
+                _lib.ptr(scale_start_index), _lib.ptr(sampling_location), _lib.ptr(weights),
+                _lib.ptr(out), _lib.current_stream(mc_ms_feat.device))
     _lib.check(rc, "gf_daf_forward")
     return out
 
@@ -33,7 +37,11 @@ def _workspace(device, nbytes):
     """Grow-only scratch for the sorted backward (tap ids + counters), one per (device, stream): the kernels
     run on torch's current stream and two streams must not share it."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _workspaces.get(key)
+    ws = _workspaces.pop(key, None)
+    while len(_workspaces) >= 8:             # bounded: least recently used entries go (a process that keeps creating streams)
+        _workspaces.pop(next(iter(_workspaces)))
+    if ws is not None:
+        _workspaces[key] = ws
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = ws

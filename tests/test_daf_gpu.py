@@ -50,6 +50,20 @@ def test_daf_forward_backward(gpu, case):
     assert_grad_close(w.grad.cpu().numpy(), gw, "grad_weights")
 
 
+def test_daf_forward_pinned_channel_groups_is_bit_identical(gpu):
+    """gf_daf_forward_pinned (channel groups pinned to XCDs) against gf_daf_forward: the same bits, at the nuScenes layout
+    (odd point counts, two batches) and for layouts it has to decline (falls back to the plain kernel)."""
+    import torch
+    from gaussianformer_amd.deformable_aggregation import deformable_aggregation_forward
+    for case in (dict(num_pts=20011, B=1), dict(num_pts=777, B=2), dict(num_pts=300, B=1, cams=3, C=32, G=4, levels=((6, 9), (3, 5))),
+                 dict(num_pts=300, B=1, cams=3, C=256, G=8, levels=((6, 9), (3, 5)))):
+        d = _edge_locs(make_daf_inputs(seed=27, **case))
+        t = to_dev(gpu, d["mc_ms_feat"], d["spatial_shape"], d["scale_start_index"], d["sampling_location"], d["weights"])
+        plain = deformable_aggregation_forward(*t)
+        pinned = deformable_aggregation_forward(*t, pin_channel_groups=True)
+        assert torch.equal(plain.view(torch.int32), pinned.view(torch.int32)), case
+
+
 def test_daf_full_feature_pyramid(gpu):
     """nuScenes-shaped pyramid (108x200 .. 14x25, 6 cams, 128 ch, 4 groups), 20 000 sample
     points vs the oracle, plus linearity in the weights at the gs25600 size (230 400 pts)."""

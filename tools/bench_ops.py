@@ -117,14 +117,43 @@ for A in (25600, 144000):
     report("subm_conv weight gradient", f"A={A}", sec, 4 * (2 * rb.total * 128 + 125 * 128 * 128), {"pairs": rb.total, "TFLOPs": flops / sec / 1e12})
 
 DAF_CASES = () if "--splat-only" in sys.argv else ((83200, "prob_gs6400"), (230400, "nuscenes_gs25600_solid"), (1296000, "nuscenes_gs144000"))
+
+
+def projected_inputs(pts):
+    """Sampling locations / weights as the encoder produces them: anchors uniform in the nuScenes range, nine key points each
+    (seven fixed offsets + two more, 0.35 m scale), six pinhole cameras (tools/bench_frame.cameras), masked softmax weights."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_frame
+    from gaussianformer_amd.deformable_prepare import deformable_prepare
+    g = torch.Generator(device="cpu").manual_seed(1)
+    A = pts // 9
+    lo = torch.tensor(bench_frame.PC_RANGE[:3]); hi = torch.tensor(bench_frame.PC_RANGE[3:])
+    centre = lo + (hi - lo) * torch.rand(1, A, 3, generator=g)
+    offs = torch.tensor(bench_frame.FIX_SCALE + [[0.3, 0.3, 0.0], [-0.3, 0.3, 0.0]]) * 0.35
+    kp = (centre[:, :, None] + offs[None, None]).to(dev)
+    pm, wh = bench_frame.cameras(dev)
+    raw = torch.randn(1, A, 6, 4, 9, 4, generator=g).to(dev)
+    loc2, w2 = deformable_prepare(kp, pm, wh, raw)
+    vis = float(((loc2 > 0) & (loc2 < 1)).all(-1).float().sum(-1).mean())
+    return loc2.contiguous(), w2.contiguous(), vis
+
+
 for pts, name in DAF_CASES:
     d = make_daf_inputs(num_pts=pts, seed=0)
     feat, ss, st, loc, w = (torch.from_numpy(d[k]).to(dev) for k in
                             ("mc_ms_feat", "spatial_shape", "scale_start_index", "sampling_location", "weights"))
     fbytes = 4 * feat.numel() + pts * (8 * 6 + 4 * 6 * 4 * 4 + 4 * 128)
-    sec = timed(lambda: deformable_aggregation_forward(feat, ss, st, loc, w))
-    report("daf_forward", name, sec, fbytes, {"sample_points": pts})
-    go = torch.randn(1, pts, 128, device=dev)
-    gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(loc), torch.zeros_like(w)
-    sec = timed(lambda: deformable_aggregation_backward(feat, ss, st, loc, w, go, gf, gl, gw), iters=10)
-    report("daf_backward", name, sec, 2 * 4 * feat.numel() + 2 * pts * (8 * 6 + 4 * 6 * 4 * 4) + 4 * 128 * pts, {"sample_points": pts})
+    bbytes = 2 * 4 * feat.numel() + 2 * pts * (8 * 6 + 4 * 6 * 4 * 4) + 4 * 128 * pts
+    ploc, pw, vis = projected_inputs(pts - pts % 9)
+    uvis = float(((loc > 0) & (loc < 1)).all(-1).float().sum(-1).mean())
+    # both distributions, both forward variants: "uniform" = SURVEY.md section 8d's op-level input (locations uniform in
+    # (-0.2, 1.2)^2, every camera independent: the adversarial case), "projected" = pinhole geometry as in the frame benchmark
+    for dist_name, (l_, w_, v_) in (("uniform", (loc, w, uvis)), ("projected", (ploc, pw, vis))):
+        n_ = l_.shape[1]
+        for variant, pin in (("", False), (" [channel groups pinned to XCDs]", True)):
+            sec = timed(lambda: deformable_aggregation_forward(feat, ss, st, l_, w_, pin_channel_groups=pin))
+            report("daf_forward" + variant, f"{name}, {dist_name} locations", sec, fbytes, {"sample_points": n_, "visible_cameras_per_point": v_})
+        go = torch.randn(1, n_, 128, device=dev)
+        gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(l_), torch.zeros_like(w_)
+        sec = timed(lambda: deformable_aggregation_backward(feat, ss, st, l_, w_, go, gf, gl, gw), iters=10)
+        report("daf_backward", f"{name}, {dist_name} locations", sec, bbytes, {"sample_points": n_, "visible_cameras_per_point": v_})
