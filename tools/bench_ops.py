@@ -2,11 +2,13 @@
 deformable aggregation forward/backward at the BASELINE shapes, with algorithmic-bytes
 roofline fractions.  Prints one JSON line per op."""
 import json
+import os
 import sys
 
 import numpy as np
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ".")
 import oracle  # noqa: E402  (numpy pre-processing restatement only)
 from gaussianformer_amd import _lib  # noqa: E402

@@ -12,13 +12,13 @@ config = sys.argv[5] if len(sys.argv) > 5 else "nuscenes_gs25600_solid"
 P = int(sys.argv[6]) if len(sys.argv) > 6 else 25601
 
 
-def mean_counter(d, counter, kernel="gf_splat_render_kernel"):
+def mean_counter(d, counter, kernel="gf_splat_render"):   # the render kernel of the pass: matrix-core (default flags) or exact-fp32 tile kernel
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter and kernel in r["Kernel_Name"]:
                 acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    (name, vals), = acc.items()
+    name, vals = max(acc.items(), key=lambda kv: len(kv[1]))
     return name, sum(vals) / len(vals), len(vals)
 
 
@@ -30,7 +30,7 @@ N = 640000
 json.dump({
     "source": f"profiles/pmc_{tag}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, {n} launches each, {config})",
     "config": config,
-    "kernel": name[:60],
+    "render_kernel": name[:70],
     "FETCH_SIZE_KiB_raw": fetch,
     "WRITE_SIZE_KiB_raw": write,
     "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
