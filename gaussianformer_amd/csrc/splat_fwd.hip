@@ -1436,36 +1436,71 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 #if GF_TIMELINE
         if (a.timeline && tid == 0) a.timeline[4 * (size_t)logical + 2] = wall_clock64();
 #endif
-        // ---- accumulators C[channel (r&3) + 8 (r>>2) + 4 h][voxel n of block b] -> out_logits, straight from the registers:
-        // lane (n, h) holds, for its voxel, channels 4h..4h+3 (r = 0..3), 8+4h..11+4h (r = 4..7) and -- h = 0 only -- 16, 17
-        // (r = 8, 9), so a block leaves as two 16-byte stores per lane (lanes n and n + 32 write adjacent pieces of one
-        // 72-byte row) and one 8-byte store of the lower half-wave.  (The version that transposed the rows through LDS
-        // into 16-byte stores over 288-byte runs spent 80 dependent LDS operations per wave here: 9.5 of 45 us.)
+        // ---- accumulators C[channel (r&3) + 8 (r>>2) + 4 h][voxel n of block b] -> out_logits.  Lane (n, h) holds, for its
+        // voxel, channels 4h..4h+3 (r = 0..3), 8+4h..11+4h (r = 4..7) and -- h = 0 only -- 16, 17 (r = 8, 9).
         if (!LABELS || a.out_logits) {
-            // All four row addresses first, each in registers of its own, then the stores back to back: hipcc makes a store's
-            // address and data registers wait for the store to COMPLETE (vmcnt) before they are written again, so addresses
-            // computed block by block in the same registers put a full write round trip between the blocks.
             typedef __attribute__((address_space(1))) float gfloat;   // global address space: keeps the stores global_store (not flat)
-            gfloat *rows[4];
-            bool inside[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int cx = Xw + 2 * (b & 1) + (n >> 4), cy = Y0 + ((n >> 2) & 3), cz = Zw + 4 * (b >> 1) + (n & 3);
-                inside[b] = cx < a.H && cy < a.W && cz < a.D;
-                rows[b] = (gfloat *)a.out_logits + (((size_t)(inside[b] ? cx : 0) * a.W + (inside[b] ? cy : 0)) * a.D + (inside[b] ? cz : 0)) * kC;
-            }
-            asm volatile("" : "+v"(rows[0]), "+v"(rows[1]), "+v"(rows[2]), "+v"(rows[3]));
             typedef float nt4v __attribute__((ext_vector_type(4), aligned(4)));
-            typedef float nt2v __attribute__((ext_vector_type(2), aligned(4)));
             typedef __attribute__((address_space(1))) nt4v nt4;
-            typedef __attribute__((address_space(1))) nt2v nt2;
+            if ((a.D & 3) == 0) {
+                // Rows [voxel-in-brick][18] of both bricks go through the wave's (now idle) staging area with 8-byte LDS
+                // writes -- five per block -- and leave as 16-byte stores over the 16 runs of 288 contiguous bytes a brick
+                // owns: whole 64-byte sectors except at the ends of a run.  (Stored straight from the registers -- 32-byte
+                // pieces at a 72-byte pitch -- the kernel wrote 72 MB for its 46 MB of logits: rocprofv3 WRITE_SIZE.)
+                // All store addresses are computed first: hipcc makes a store's address registers wait for the store to
+                // COMPLETE (vmcnt) before they are written again.
+                float *stage = &s_stage[wave][0][0];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (inside[b]) {
-                    // non-temporal: the logits are written once and not read again by this kernel (52.5 -> 50.8 us per step at gs25600)
-                    __builtin_nontemporal_store((nt4v){acc[b][0], acc[b][1], acc[b][2], acc[b][3]}, (nt4 *)(rows[b] + 4 * h));
-                    __builtin_nontemporal_store((nt4v){acc[b][4], acc[b][5], acc[b][6], acc[b][7]}, (nt4 *)(rows[b] + 8 + 4 * h));
-                    if (h == 0) __builtin_nontemporal_store((nt2v){acc[b][8], acc[b][9]}, (nt2 *)(rows[b] + 16));
+                for (int b = 0; b < 4; ++b) {
+                    float *row = stage + ((b >> 1) * 64 + 32 * (b & 1) + n) * kC;
+                    *reinterpret_cast<float2 *>(row + 4 * h) = make_float2(acc[b][0], acc[b][1]);
+                    *reinterpret_cast<float2 *>(row + 4 * h + 2) = make_float2(acc[b][2], acc[b][3]);
+                    *reinterpret_cast<float2 *>(row + 8 + 4 * h) = make_float2(acc[b][4], acc[b][5]);
+                    *reinterpret_cast<float2 *>(row + 10 + 4 * h) = make_float2(acc[b][6], acc[b][7]);
+                    if (h == 0) *reinterpret_cast<float2 *>(row + 16) = make_float2(acc[b][8], acc[b][9]);
+                }
+                // (32-bit element offsets from the uniform base: one register per address)
+                uint32_t off[10];
+                uint32_t okbits = 0u;
+#pragma unroll
+                for (int it = 0; it < 10; ++it) {
+                    const int half = it / 5, i = lane + 64 * (it % 5);           // float4 i of the brick's 16 runs x 18
+                    const int run = i / kC, k = i - run * kC;
+                    const int cx = Xw + (run >> 2), cy = Y0 + (run & 3), Zb = Zw + 4 * half;
+                    const bool ok = i < 16 * kC && cx < a.H && cy < a.W && Zb < a.D;
+                    okbits |= ok ? (1u << it) : 0u;
+                    off[it] = ok ? (uint32_t)((((size_t)cx * a.W + cy) * a.D + Zb) * kC + 4 * k) : 0u;
+                }
+                asm volatile("" : "+v"(off[0]), "+v"(off[1]), "+v"(off[2]), "+v"(off[3]), "+v"(off[4]), "+v"(off[5]), "+v"(off[6]),
+                             "+v"(off[7]), "+v"(off[8]), "+v"(off[9]));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                gfloat *base = (gfloat *)a.out_logits;
+#pragma unroll
+                for (int it = 0; it < 10; ++it) {
+                    if (okbits & (1u << it)) {
+                        const float4 v = *reinterpret_cast<const float4 *>(stage + (it / 5) * 64 * kC + 4 * (lane + 64 * (it % 5)));
+                        __builtin_nontemporal_store((nt4v){v.x, v.y, v.z, v.w}, (nt4 *)(base + off[it]));
+                    }
+                }
+            } else {
+                // depths that are not a multiple of 4 (no reference config): the staged rows leave element by element
+                float *stage = &s_stage[wave][0][0];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float *row = stage + ((b >> 1) * 64 + 32 * (b & 1) + n) * kC;
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) {
+                        const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (c < kC) row[c] = acc[b][r];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < 2 * 64 * kC; i += 64) {
+                    const int half = i / (64 * kC), l = (i % (64 * kC)) / kC, ch = i % kC;
+                    const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zw + 4 * half + (l & 3);
+                    if (cx < a.H && cy < a.W && cz < a.D) a.out_logits[(((size_t)cx * a.W + cy) * a.D + cz) * kC + ch] = stage[i];
                 }
             }
         }

@@ -188,4 +188,6 @@ def test_mfma_module_keyword_and_autograd(gpu):
     assert float(((outs[0] - outs[1]).abs() / outs[0].abs().clamp(min=1.0)).max()) <= 1e-4
     assert not torch.equal(outs[0], outs[1])                       # it really is the other kernel
     for a, b in zip(*grads):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(a.abs().max()))   # the backward does not depend on the forward kernel
+        # the backward does not depend on the forward kernel (boxes split over several waves combine with float atomics:
+        # equal up to summation order)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()))
