@@ -704,7 +704,7 @@ extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, 
     const size_t lds = (size_t)Cin * SW * sizeof(float);
     const dim3 gemm_grid((unsigned)(total_pairs / kPairTile + K3), Cout / SW);  // x >= the number of tiles, whatever the split over the segments
     const int rows = 256 / (Cout / 4);
-    static const bool exact_f32 = getenv("GF_SUBM_F32_MFMA") != nullptr;  // the f32-MFMA kernel, for comparison
+    const bool exact_f32 = getenv("GF_SUBM_F32_MFMA") != nullptr;  // the f32-MFMA kernel, for comparison (read per call: tests flip it)
     if (exact_f32) {
 #define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds, stream, a)
         GF_SUBM_DISPATCH(GF_GEMM);

@@ -283,11 +283,15 @@ int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const
  *      weight'[k] = weight[K^3-1-k]^T), and gf_subm_conv_weight_grad.
  * Without the host read: gf_subm_rulebook_build does steps 1 and 3 in one call for pair arrays the caller sized in
  * advance (`pair_capacity` entries; partial f32 [pair_capacity, Cout]; pass pair_capacity as `total_pairs` below).  A
- * point set with more pairs than that leaves the rulebook EMPTY (apply returns zeros) and sets bit 2 of the refusal
- * word, which the caller reads whenever it next synchronises.
- * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  Both products run on the f32 matrix
- * cores (v_mfma_f32_32x32x2_f32: exact f32, an fmaf chain); results are deterministic except the weight gradient of
- * segments longer than 512 pairs (float atomics between their chunks).
+ * point set with more pairs than that leaves the rulebook EMPTY, sets bit 2 of the refusal word -- which the caller
+ * reads whenever it next synchronises -- and makes gf_subm_conv_apply write NaN to every output row (a refusal must
+ * not look like a feature).
+ * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  gf_subm_conv_apply multiplies on the
+ * bf16 matrix cores with fp32-EQUIVALENT operands: every fp32 value is split into three bf16 terms and a product is
+ * six v_mfma_f32_32x32x16_bf16 partial products accumulated in fp32 (the dropped terms are <= 2^-24 relative each);
+ * GF_SUBM_F32_MFMA=1 in the environment selects the f32-MFMA kernel instead (v_mfma_f32_32x32x2_f32: bitwise an fmaf
+ * chain, ~13 % slower).  The weight gradient runs on f32 MFMAs.  Results are deterministic except the weight gradient
+ * of segments longer than 512 pairs (float atomics between their chunks).
  */
 size_t gf_subm_tables_bytes(int N, int batch, int X, int Y, int Z, int K);
 int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,

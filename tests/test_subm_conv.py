@@ -264,6 +264,36 @@ def test_subm_conv_without_host_read():
         tight(x, anchor)
 
 
+@pytest.mark.parametrize("cin,cout", [(128, 128), (32, 64)])
+def test_subm_conv_bf16_split_against_f32_mfma(cin, cout, monkeypatch):
+    """The default gather-GEMM (fp32 operands split into three bf16 terms, six bf16 MFMAs per product) against the
+    f32-MFMA kernel (GF_SUBM_F32_MFMA=1: bitwise an fmaf chain) on the same rulebook, and both against the fp64
+    definition: the split must stay in fp32's error class, also for operands spanning many binades (a plain bf16 GEMM
+    would be at 4e-3)."""
+    from gaussianformer_amd.sparse_conv import Rulebook
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    N, batch, shape, K = 1200, 1, (12, 10, 6), 5
+    idx = _points(rng, N, batch, shape)
+    g = torch.Generator().manual_seed(9)
+    feat = torch.randn(N, cin, generator=g) * torch.exp2(torch.randint(-12, 12, (N, cin), generator=g).float())
+    weight = torch.randn(K ** 3, cin, cout, generator=g) * torch.exp2(torch.randint(-8, 8, (K ** 3, cin, cout), generator=g).float())
+    ref = _dense_reference(feat.double(), idx.long(), weight.double(), batch, shape, K)
+    # the error scale of an fp32 dot product: eps * sum |a||b|, per output element
+    mag = _dense_reference(feat.double().abs(), idx.long(), weight.double().abs(), batch, shape, K)
+    rb = Rulebook(idx.to(dev), batch, shape, K)
+    monkeypatch.delenv("GF_SUBM_F32_MFMA", raising=False)
+    split = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()
+    monkeypatch.setenv("GF_SUBM_F32_MFMA", "1")
+    exact = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()
+    monkeypatch.delenv("GF_SUBM_F32_MFMA", raising=False)
+    assert not torch.equal(split, exact)                          # two different kernels did run
+    bound = 2.0 ** -20 * mag + 1e-30        # 16 units of fp32 roundoff of sum |a||b| (a plain bf16 product: 2^-8)
+    assert bool(((exact - ref).abs() <= bound).all())
+    assert bool(((split - ref).abs() <= bound).all())
+    assert bool(((split - exact).abs() <= bound).all())
+
+
 def _representative_reference(feat, idx, weight, batch, shape, K):
     """``duplicates="last"`` stated directly (fp64, differentiable): a hash of cell -> the LARGEST point index in it, then
     out[i] = sum_k feat[table[cell(i) + offset_k]] . W[k] -- what spconv's SubMConv3d computes when that duplicate is the
