@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 KERNEL_SAMPLES = 16   # bracketed launches of the separate kernel-timing loop (>= 8)
+SETTLE_STEPS = 300     # untimed steps ahead of the W warm-up steps (GPU clock settle, ~15 ms); reported in the JSON line
 
 
 def headline_metric():
@@ -248,7 +249,9 @@ def main():
     si, P, N = wl.si, wl.P_total, wl.N
     pi, mi, radii, cov6 = wl.prep
 
-    for _ in range(args.warmup):
+    # ---- untimed: SETTLE_STEPS steps to bring the GPU out of its idle power state (the first ~10 ms after start-up run at
+    # a lower clock: 47.7 us per step measured with 20 warm-up steps, 46.3 with 200 or 2000), then the W warm-up steps
+    for _ in range(SETTLE_STEPS + args.warmup):
         wl.step()
     torch.cuda.synchronize()
 
@@ -495,7 +498,7 @@ def main():
                 roofline["traffic_note"] = traffic_note
         out = {
             "metric": headline_metric(),
-            "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: splat forward of ONE frame, P={P} Gaussians -> {si.H}x{si.W}x{si.D}x18 "
