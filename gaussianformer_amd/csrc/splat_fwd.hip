@@ -370,6 +370,7 @@ struct RenderArgs {
     float threshold;
     int raw_numerator;  // prob variant: logits = sum sem * prob, not divided by prob_sum (GF_PROB_NUMERATOR)
     uint32_t *tile_counters;  // matrix-core kernel: next unclaimed tile of XCD x at [64 x] (one cache line each)
+    int dbg;                  // experiments (GF_DBG in the environment)
 };
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
@@ -565,7 +566,7 @@ __device__ __forceinline__ long long label_of(const Acc &S, const RenderArgs &a)
 template <int VARIANT, int EXP, bool LABELS>
 __device__ __forceinline__ void general_body(const RenderArgs &a)
 {
-    for (long long n = (long long)blockIdx.x * kBlock + threadIdx.x; n < a.N; n += (long long)gridDim.x * kBlock) {
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += (long long)gridDim.x * blockDim.x) {
         const int X = a.points_int[3 * n], Y = a.points_int[3 * n + 1], Z = a.points_int[3 * n + 2];
         const float px = a.pts[3 * n], py = a.pts[3 * n + 1], pz = a.pts[3 * n + 2];
         Acc A;
@@ -1123,8 +1124,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         // placement ever differ, two L2s hand out the same index and a tile is computed twice (same values): never skipped.
         // (Inline asm: hipcc waits for a returning atomic at the end of the divergent block that issued it; written this way
         // its round trip runs under the row's LDS-DMA and both are waited for by the one s_waitcnt below.)
-        if (last_zg && tid == 0) {
-            uint32_t *ctr = a.tile_counters + 64 * xcd;
+        const bool late = (a.dbg & 2) != 0;
+        bool claim_issued = false;
+        uint32_t *ctr = a.tile_counters + 64 * xcd;
+        if (last_zg && tid == 0 && !late) {
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
         }
         // The producer is a short chain of dependent steps (scan, barrier, LDS): at equal priority it queues behind the
@@ -1244,7 +1247,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
                 if (ngrp != 1) __syncthreads();
             }
-            if (done && last_zg && tid == 0) {
+            if (done && last_zg && tid == 0 && !late) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) :: "memory");   // (long since back: waited for with the row)
                 s_next = (int)claimed;
             }
@@ -1253,7 +1256,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 #if GF_TIMELINE
             if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)logical + 1] = wall_clock64();
 #endif
-            if (done && last_zg) next_local = s_next;
+            if (done && last_zg && !late) next_local = s_next;
             // The packed boxes of the list's Gaussians come into LDS by LDS-DMA (two 4-byte pieces per entry, gathered by id):
             // the waves then filter the list against their double brick without a single global load, and the only VMEM
             // traffic of the accumulation are the record requests -- no `s_waitcnt vmcnt(0)` of a box load drains them.
@@ -1311,6 +1314,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     __builtin_amdgcn_wave_barrier();
                     const int nnext = min(avail, 32);
                     if (nnext > 0) request_records_at(qhead, qn, nnext);
+                    if (late && last_zg && wave == 0 && last && nnext == 0 && !claim_issued) {
+                        claim_issued = true;
+                        if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+                    }
 #if GF_TIMELINE
                     const unsigned long long tg1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1428,7 +1435,15 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     npend = nnext;
                 }
             }
-            if (done) break;
+            if (done) {
+                if (late && last_zg && wave == 0) {
+                    if (!claim_issued && lane == 0)
+                        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) :: "memory");
+                    if (lane == 0) s_next = (int)claimed;
+                }
+                break;
+            }
             __syncthreads();  // every wave is done with the list before it is refilled
             __builtin_amdgcn_s_setprio(3);
             list_len = 0;
@@ -1518,6 +1533,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     }
 #endif
     // ---- next tile of this workgroup
+    if (a.dbg & 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        next_local = s_next;
+    }
     local = next_local;
     logical = xcd * per_xcd + local;
     s = logical / kTilesPerSuper; t = logical % kTilesPerSuper;
@@ -1527,8 +1546,552 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     bm = a.bitmask + (size_t)s * a.nrow;
     // the slowest wave is done with the list and the scan scratch.  LDS ordering only: a full __syncthreads() also waits
     // (vmcnt) for the output stores just issued to be acknowledged
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!(a.dbg & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Wave-autonomous matrix-core render kernel (bitmask rows of <= kWRow words, i.e. P <= 39 552; longer rows keep the tile
+// kernel above).  The arithmetic is gf_splat_render_mfma_kernel's, group for group; what changes is who owns what:
+// a UNIT of work is one double brick (4 x 4 columns x 8 z), a workgroup is ONE wave, eight of them share a CU, and a
+// wave does everything for its unit by itself -- claims it, brings the supertile's bitmask row into its own LDS, turns it
+// into the candidate list, fetches the boxes, filters, accumulates, stores -- without a single workgroup barrier.  In
+// the tile kernel the four waves of a tile wait for each other at six barriers and at the end of the tile (the slowest
+// of four double bricks sets the pace), and a slot is re-filled in steps of a whole tile (~10 us of a ~37 us launch:
+// 2.4 rounds, the last one a third full); here a slot is re-filled brick by brick.  The price: every wave scans the row
+// and fetches the candidates' boxes itself (four times the tile kernel's box traffic, all of it L2 hits).
+// LDS: 20 480 bytes per wave, carved by hand (eight workgroups fill the CU's 160 KB exactly):
+//   [    0,  6144)  record slot: six 1 KB pieces per group, written by LDS-DMA
+//   [ 6144, 12288)  candidate list: ids, packed box lo, packed box hi, kWList entries each
+//   [    0,  9216)  ... output staging in the epilogue (slot and list are dead by then)
+//   [12288, 17232)  bitmask row (kWRow words)
+//   [17232, 17744)  hit queue (ring of kQCap ids)
+//   [17744, 20480)  opacity * semantics of the current group, [channel][Gaussian]
+constexpr int kWList = 512;
+constexpr int kWRow = 618;
+constexpr int kWLdsDwords = 5120;
+static_assert(3072 + 2 * kWRow + kQCap + (kC + 1) * kSRow == kWLdsDwords, "LDS map of the wave-autonomous kernel");
+static_assert(2 * 64 * kC <= 1536 + 3 * kWList, "output staging fits over the slot and the list");
+
+__global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_u[kWLdsDwords];
+    float4 *slot = reinterpret_cast<float4 *>(s_u);
+    uint32_t *s_lg = s_u + 1536, *s_blo = s_u + 1536 + kWList, *s_bhi = s_u + 1536 + 2 * kWList;
+    float *stage = reinterpret_cast<float *>(s_u);
+    unsigned long long *s_row = reinterpret_cast<unsigned long long *>(s_u + 3072);
+    uint32_t *q_id = s_u + 3072 + 2 * kWRow;
+    float *S = reinterpret_cast<float *>(s_u + 3072 + 2 * kWRow + kQCap);
+
+    const int lane = threadIdx.x;
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int per_super = 4 * ((a.D + 7) >> 3);          // units of a supertile: 2 x 2 column quarters x z bricks
+    const int nunits = a.nsx * a.nsy * per_super;
+    const int per_xcd = (nunits + 7) >> 3;
+
+    // verdicts of the prep launch (see gf_splat_render_mfma_kernel)
+    int verdict = 0;
+    if (a.verify_dense) {
+        const uint4 *vp = reinterpret_cast<const uint4 *>(a.verify_flags) + 16 * lane;
+        uint32_t v = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint4 t = vp[k];
+            v |= t.x | t.y | t.z | t.w;
+        }
+        verdict = (__builtin_amdgcn_ballot_w64((v & 1u) != 0u) ? 1 : 0) | (__builtin_amdgcn_ballot_w64((v & 2u) != 0u) ? 2 : 0) |
+                  (__builtin_amdgcn_ballot_w64((v & 4u) != 0u) ? 4 : 0);
+    }
+    if (blockIdx.x == 0 && lane == 0 && a.state) {
+        a.state[0] = (verdict & 1) ? 1u : 0u;
+        a.state[1] = verdict ? GF_PATH_ARBITRARY : GF_PATH_MATRIX_CORE;
+        a.state[2] = (uint32_t)verdict;
+    }
+    if (verdict) {
+        general_body<GF_SPLAT_BASE, kExpComp, false>(a);
+        return;
+    }
+
+    const int n = lane & 31, h = lane >> 5;
+    for (int i = lane; i < (kC + 1) * kSRow; i += 64) S[i] = 0.f;
+
+    // lattice of the voxel centres (fp64): position of voxel index i along an axis = p0 + i * step
+    using cflt_t = const float __attribute__((address_space(4))) *;
+    cflt_t cp = (cflt_t)(uintptr_t)a.pts;
+    const double p0x = cp[0], p0y = cp[1], p0z = cp[2];
+    const double sx = a.H > 1 ? (double)cp[3 * (size_t)a.W * a.D] - p0x : 1.0;
+    const double sy = a.W > 1 ? (double)cp[3 * (size_t)a.D + 1] - p0y : 1.0;
+    const double sz = a.D > 1 ? (double)cp[3 + 2] - p0z : 1.0;
+
+    // B operands of the exponent MFMAs: monomials and one-hot coordinates of this lane's voxel in each of the four blocks
+    h8 phi[4], hot[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float ux_ = (float)(2 * (b & 1) + (n >> 4)) - 1.5f, uy_ = (float)((n >> 2) & 3) - 1.5f,
+                    uz_ = (float)(4 * (b >> 1) + (n & 3)) - 3.5f;
+        const float m0[8] = {1.f, ux_, uy_, uz_, ux_ * ux_, 0.f, 0.f, 0.f};
+        const float m1[8] = {uy_ * uy_, uz_ * uz_, ux_ * uy_, uy_ * uz_, ux_ * uz_, 0.f, 0.f, 0.f};
+        const int lx = 2 * (b & 1) + (n >> 4), ly = (n >> 2) & 3, zz = 4 * (b >> 1) + (n & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            phi[b][j] = (_Float16)(h ? m1[j] : m0[j]);
+            hot[b][j] = (_Float16)((h ? zz == j : (j < 4 ? lx == j : ly == j - 4)) ? 1.f : 0.f);
+        }
+    }
+
+    using gptr = const __attribute__((address_space(1))) void *;
+    using lptr = __attribute__((address_space(3))) void *;
+    auto request_records_at = [&](int qh, int start, int count) {
+        const uint32_t id = q_id[(qh + start + (n < count ? n : 0)) & (kQCap - 1)];
+        const char *rec = reinterpret_cast<const char *>(a.records + (size_t)id * kRecDwords);
+        const int o3 = (3 + 3 * h) * 16, o4 = (4 + 3 * h) * 16, o5 = (h ? 7 : 5) * 16;
+        char *dst = reinterpret_cast<char *>(slot);
+        __builtin_amdgcn_global_load_lds((gptr)(rec), (lptr)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + 16), (lptr)(dst + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + 32), (lptr)(dst + 2048), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o3), (lptr)(dst + 3072), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o4), (lptr)(dst + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o5), (lptr)(dst + 5120), 16, 0, 0);
+    };
+
+    uint32_t *ctr = a.tile_counters + 64 * xcd;
+    const int nchunk = (a.nwords + 63) >> 6;
+    // unit index -> (supertile, quarter, z brick) -> supertile row and column: divisions by launch constants, as multiplications
+    // by rounded-up reciprocals (exact for the < 2^20 indices of a grid)
+    const uint32_t m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / (unsigned)per_super);
+    const uint32_t m_nsy = (uint32_t)(((1ull << 32) + a.nsy - 1) / (unsigned)a.nsy);
+    int local = (int)(blockIdx.x >> 3);
+    bool row_there = false;  // the bitmask row of unit `local` has already been requested into s_row (by the previous unit)
+    int nst_prev = 0;        // ... and this many store instructions were issued after that request
+    while (true) {  // units of this wave
+        const int logical = xcd * per_xcd + local;
+        if (!(local < per_xcd && logical < nunits)) break;
+        bool next_row = false;
+        int nst = -1;
+        // The next unit is claimed first thing (workgroup scope: the counter of XCD x is only touched by workgroups running on
+        // that XCD, so the RMW is performed in its own L2; inline asm: hipcc would wait for a returning atomic at the end of the
+        // divergent block that issued it).  The answer is waited for together with the bitmask row.
+        uint32_t claimed = 0u;
+        bool have_next = false;
+        const int s = (int)__umulhi((uint32_t)logical, m_ps), r = logical - s * per_super;
+        const int srow = a.nsy == 1 ? s : (int)__umulhi((uint32_t)s, m_nsy), scol = s - srow * a.nsy;   // (2^32 / 1 does not fit)
+        const int Xw = srow * kSuper + 4 * (r & 1), Y0 = scol * kSuper + 4 * ((r >> 1) & 1), Zw = 8 * (r >> 2);
+        if (Xw < a.H && Y0 < a.W) {
+            const unsigned long long *__restrict__ bm = a.bitmask + (size_t)s * a.nrow;
+#if GF_TIMELINE
+            unsigned long long tl[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
+#endif
+            __builtin_amdgcn_s_setprio(3);
+            // the whole bitmask row by LDS-DMA: 128 words per instruction, every piece in flight at once
+            if (!row_there)
+                for (int i = 0; 128 * i < a.nrow; ++i)
+                    if (128 * i + 2 * lane < a.nrow)
+                        __builtin_amdgcn_global_load_lds((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
+            f32x16 acc[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+            const double Cx = p0x + ((double)Xw + 1.5) * sx, Cy = p0y + ((double)Y0 + 1.5) * sy, Cz = p0z + ((double)Zw + 3.5) * sz;
+            int list_len = 0, qlen = 0, qhead = 0, npend = 0, c = 0, sg = 0;
+            // A prefetched row is older than the previous unit's output stores and memory operations complete in order: with
+            // exactly ten stores behind it, "at most ten outstanding" means the row has landed -- without waiting for the stores.
+            if (row_there && nst_prev == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if GF_TIMELINE
+            tl[1] = wall_clock64();
+#endif
+            // ---- fill, fast path (the whole row at once).  Extracting ids bit by bit costs one loop iteration per set bit of the
+            // busiest LANE, and with a word per lane a chunk of 64 words has a lane with four or five candidates while most
+            // have none (0.6 % of the bits are set): 35 iterations of a dependent 64-bit chain per row, 2.3 us.  So the NONZERO
+            // words are first compacted (ballot + count, no loop) into a dense array -- it borrows the record slot, idle until
+            // the first group -- and the bits are extracted from that: three rounds of two or three iterations.
+            {
+                uint32_t *s_dw = s_u;                                                       // [kWList] word index
+                unsigned long long *s_db = reinterpret_cast<unsigned long long *>(s_u + kWList);   // [kWList] its bits
+                int nd = 0;
+                // (unrolled and branch-free up to the reads: the ten LDS reads go out back to back instead of one per iteration)
+                constexpr int kWChunks = (kWRow + 63) / 64;
+                unsigned long long wd[kWChunks];
+#pragma unroll
+                for (int cc = 0; cc < kWChunks; ++cc) {
+                    const int w = 64 * cc + lane;
+                    const unsigned long long x = s_row[min(w, kWRow - 1)];
+                    wd[cc] = w < a.nwords ? x : 0ull;
+                }
+#pragma unroll
+                for (int cc = 0; cc < kWChunks; ++cc) {
+                    const unsigned long long nzm = __builtin_amdgcn_ballot_w64(wd[cc] != 0ull);
+                    const int p = nd + (int)mbcnt(nzm);
+                    if (wd[cc] != 0ull && p < kWList) {
+                        s_dw[p] = (uint32_t)(64 * cc + lane);
+                        s_db[p] = wd[cc];
+                    }
+                    nd += __builtin_popcountll(nzm);
+                }
+                if (nd <= kWList) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    int tot = 0;
+                    bool fits = true;
+                    for (int d0 = 0; d0 < nd; d0 += 64) {
+                        const int i = d0 + lane;
+                        unsigned long long bits = i < nd ? s_db[i] : 0ull;
+                        const uint32_t id0 = (i < nd ? s_dw[i] : 0u) * 64u;
+                        const int cnt = __builtin_popcountll(bits);
+                        const int incl = wave_inclusive_scan(cnt);
+                        const int t = __builtin_amdgcn_readlane(incl, 63);
+                        if (tot + t > kWList) {
+                            fits = false;
+                            break;
+                        }
+                        int pos = tot + incl - cnt;
+                        if (bits) {   // a dense word has at least one bit (only the lanes past the end have none) ...
+                            s_lg[pos++] = id0 + (uint32_t)__builtin_ctzll(bits);
+                            bits &= bits - 1;
+                        }
+                        while (bits) {   // ... and four in five have exactly one
+                            const int j = __builtin_ctzll(bits);
+                            bits &= bits - 1;
+                            s_lg[pos++] = id0 + (uint32_t)j;
+                        }
+                        tot += t;
+                    }
+                    if (fits) {   // the row is consumed: the loop below goes straight to the boxes
+                        list_len = tot;
+                        c = nchunk;
+                    }
+                }
+            }
+            while (true) {  // fill the list from the row, consume it, until the row is exhausted
+                // ---- fill: chunks of 64 words, one per lane; a chunk's candidates go to the list in ascending index (hits of
+                // earlier lanes first).  A chunk that does not fit any more waits for the next round; one with more candidates
+                // than the whole list holds goes in by eight lane groups of eight words (<= 512 candidates each).
+                bool last = false;
+                while (true) {
+                    if (c >= nchunk) {
+                        last = true;
+                        break;
+                    }
+                    const int w = 64 * c + lane;
+                    unsigned long long bits = w < a.nwords ? s_row[w] : 0ull;
+                    const int cnt = __builtin_popcountll(bits);
+                    const int incl = wave_inclusive_scan(cnt);
+                    const int total = __builtin_amdgcn_readlane(incl, 63);
+                    int pos = -1;
+                    if (total <= kWList) {
+                        if (list_len + total > kWList) break;
+                        pos = list_len + incl - cnt;
+                        list_len += total;
+                        ++c;
+                    } else {
+                        bool full = false;
+                        for (; sg < 8; ++sg) {
+                            const int e1 = __builtin_amdgcn_readlane(incl, 8 * sg + 7);
+                            const int e0 = sg ? __builtin_amdgcn_readlane(incl, 8 * sg - 1) : 0;
+                            if (list_len + (e1 - e0) > kWList) {
+                                full = true;
+                                break;
+                            }
+                            if ((lane >> 3) == sg) pos = list_len + (incl - cnt) - e0;
+                            list_len += e1 - e0;
+                        }
+                        // (lanes of the groups admitted in this pass have pos >= 0; groups admitted in an earlier pass were
+                        // written then -- sg says where this pass started)
+                        if (!full) {
+                            sg = 0;
+                            ++c;
+                        }
+                        if (pos >= 0) {
+                            const uint32_t id0 = (uint32_t)w * 64u;
+                            while (bits) {
+                                const int j = __builtin_ctzll(bits);
+                                bits &= bits - 1;
+                                s_lg[pos++] = id0 + (uint32_t)j;
+                            }
+                        }
+                        if (full) break;
+                        continue;
+                    }
+                    const uint32_t id0 = (uint32_t)w * 64u;
+                    while (bits) {
+                        const int j = __builtin_ctzll(bits);
+                        bits &= bits - 1;
+                        s_lg[pos++] = id0 + (uint32_t)j;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#if GF_TIMELINE
+                if (!tl[2]) tl[2] = wall_clock64();
+#endif
+                // ---- the packed boxes of the listed Gaussians, by LDS-DMA (two 4-byte pieces per entry, gathered by id)
+                for (int b0 = 0; b0 < list_len; b0 += 64) {
+                    const uint32_t id = s_lg[min(b0 + lane, list_len - 1)];
+                    __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0), 4, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if GF_TIMELINE
+                if (!tl[3]) tl[3] = wall_clock64();
+#endif
+                __builtin_amdgcn_s_setprio(0);
+                // ---- consume: hits of the double brick -> queue -> groups of 32 (one-deep record pipeline, as in the tile kernel)
+                for (int base = 0; base < list_len || (last && base == 0); base += 64) {
+                    const int i = base + lane;
+                    const int ic = min(i, max(list_len - 1, 0));
+                    const uint32_t eg = s_lg[ic];
+                    const uint32_t blo = s_blo[ic], bhi = s_bhi[ic];
+                    const bool hit = i < list_len && ux(blo) < Xw + 4 && ux(bhi) > Xw && uy(blo) < Y0 + 4 && uy(bhi) > Y0 &&
+                                     uz(blo) < Zw + 8 && uz(bhi) > Zw;
+                    const unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
+                    if (hit) q_id[(qhead + qlen + (int)mbcnt(todo)) & (kQCap - 1)] = eg;
+                    qlen += __builtin_popcountll(todo);
+                    const bool final_batch = last && base + 64 >= list_len;
+                    while (true) {
+                        if (npend == 0) {
+                            if (!(qlen >= 32 || (final_batch && qlen > 0))) break;
+                            npend = min(qlen, 32);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            request_records_at(qhead, 0, npend);
+                        }
+                        const int avail = qlen - npend;
+                        if (!(avail >= 32 || final_batch)) break;   // the successor is requested before this group is worked on
+                        const int qn = npend;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pending group's pieces have landed in the slot
+#if GF_TIMELINE
+                        if (!tl[4]) tl[4] = wall_clock64();
+                        tl[7] += 1;
+#endif
+                        // ---- operands of the group: lane (g = n, h)
+                        const bool live = n < qn;
+                        const float4 r0 = slot[lane], r1 = slot[64 + lane], r2 = slot[128 + lane];
+                        const float4 e0 = slot[192 + lane], e1 = slot[256 + lane], e2 = slot[320 + lane];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // every lane has its pieces: the slot is free again
+                        __builtin_amdgcn_wave_barrier();
+                        const int nnext = min(avail, 32);
+                        if (nnext > 0) request_records_at(qhead, qn, nnext);
+                        // the unit's last group: NOW the next unit is claimed -- as late as its round trip can still hide (under
+                        // this group's blocks): a unit claimed early is a unit no idle wave can take at the end of the launch
+                        const bool last_group = final_batch && nnext == 0;
+                        if (last_group && lane == 0)
+                            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+                        {
+                            const float opa = live ? r0.w : 0.f;
+                            const float v[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+                            if (h == 0) {
+#pragma unroll
+                                for (int k = 0; k < 12; ++k) S[k * kSRow + n] = opa * v[k];
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 6; ++k) S[(12 + k) * kSRow + n] = opa * v[k];
+                            }
+                        }
+                        H8 t1, t2, t3;
+                        {
+                            const double L = 1.4426950408889634074;
+                            const double c0 = r1.x, c1 = r1.y, c2 = r1.z, c3 = r1.w, c4 = r2.x, c5 = r2.y;
+                            double th[5];
+                            if (h == 0) {  // constant and linear terms + xx: the ones that depend on the brick
+                                const double ex = Cx - (double)r0.x, ey = Cy - (double)r0.y, ez = Cz - (double)r0.z;
+                                const double gx = c0 * ex + c3 * ey + c5 * ez, gy = c3 * ex + c1 * ey + c4 * ez, gz = c5 * ex + c4 * ey + c2 * ez;
+                                th[0] = -0.5 * L * (ex * gx + ey * gy + ez * gz);
+                                th[1] = -L * sx * gx; th[2] = -L * sy * gy; th[3] = -L * sz * gz;
+                                th[4] = -0.5 * L * sx * sx * c0;
+                            } else {
+                                th[0] = -0.5 * L * sy * sy * c1; th[1] = -0.5 * L * sz * sz * c2;
+                                th[2] = -L * sx * sy * c3; th[3] = -L * sy * sz * c4; th[4] = -L * sx * sz * c5;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) split3(live ? th[j] : 0.0, t1.e[j], t2.e[j], t3.e[j]);
+#pragma unroll
+                            for (int j = 5; j < 8; ++j) { t1.e[j] = (_Float16)0.f; t2.e[j] = (_Float16)0.f; t3.e[j] = (_Float16)0.f; }
+                        }
+                        H8 tb;
+                        {
+                            const uint32_t glo = __float_as_uint(r2.z), ghi = __float_as_uint(r2.w);
+                            const int x0 = ux(glo) - Xw, x1 = ux(ghi) - Xw, y0 = uy(glo) - Y0, y1 = uy(ghi) - Y0;
+                            const int z0 = uz(glo) - Zw, z1 = uz(ghi) - Zw;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const bool in = h ? (j >= z0 && j < z1) : (j < 4 ? (j >= x0 && j < x1) : (j - 4 >= y0 && j - 4 < y1));
+                                tb.e[j] = (_Float16)((in && live) ? 0.f : -32768.f);
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        H8 sh[2], sl[2];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v4 = *reinterpret_cast<const float4 *>(S + min(n, kC) * kSRow + 8 * q + 4 * h);
+                            const fp16x2 ha = __builtin_amdgcn_cvt_pkrtz(v4.x, v4.y), hb = __builtin_amdgcn_cvt_pkrtz(v4.z, v4.w);
+                            const fp16x2 la = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)ha[0], -1.0f, v4.x), __builtin_fmaf((float)ha[1], -1.0f, v4.y));
+                            const fp16x2 lb = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)hb[0], -1.0f, v4.z), __builtin_fmaf((float)hb[1], -1.0f, v4.w));
+                            sh[q >> 1].p[2 * (q & 1)] = ha; sh[q >> 1].p[2 * (q & 1) + 1] = hb;
+                            sl[q >> 1].p[2 * (q & 1)] = la; sl[q >> 1].p[2 * (q & 1) + 1] = lb;
+                        }
+                        auto pair = [&](int b0) {
+                            f32x16 d0, d1;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) { d0[q] = 0.f; d1[q] = 0.f; }
+                            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t3.v, phi[b0], d0, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t3.v, phi[b0 + 1], d1, 0, 0, 0);
+                            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t2.v, phi[b0], d0, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t2.v, phi[b0 + 1], d1, 0, 0, 0);
+                            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t1.v, phi[b0], d0, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(t1.v, phi[b0 + 1], d1, 0, 0, 0);
+                            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tb.v, hot[b0], d0, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tb.v, hot[b0 + 1], d1, 0, 0, 0);
+                            H8 wh[2][2], wl[2][2];
+                            auto weights = [&](const f32x16 &d, int k) {
+#pragma unroll
+                                for (int q = 0; q < 16; q += 2) {
+                                    const float w0 = __builtin_amdgcn_exp2f(d[q]), w1 = __builtin_amdgcn_exp2f(d[q + 1]);
+                                    const fp16x2 hi = __builtin_amdgcn_cvt_pkrtz(w0, w1);
+                                    float q0, q1;  // exact residuals w - hi, the f16 halves read in place (v_fma_mix_f32)
+                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(hi), "v"(w0));
+                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(hi), "v"(w1));
+                                    wh[k][q >> 3].p[(q & 7) >> 1] = hi;
+                                    wl[k][q >> 3].p[(q & 7) >> 1] = __builtin_amdgcn_cvt_pkrtz(q0, q1);
+                                }
+                            };
+                            weights(d0, 0);
+                            weights(d1, 1);
+#pragma unroll
+                            for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[kh].v, wh[k][kh].v, acc[b0 + k], 0, 0, 0);
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wl[k][kh].v, acc[b0 + k], 0, 0, 0);
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) acc[b0 + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[kh].v, wh[k][kh].v, acc[b0 + k], 0, 0, 0);
+                            }
+                        };
+                        pair(0);
+                        pair(2);
+                        have_next = have_next || last_group;
+                        qhead = (qhead + qn) & (kQCap - 1);
+                        qlen -= qn;
+                        npend = nnext;
+                    }
+                }
+                if (last) break;
+                list_len = 0;
+                __builtin_amdgcn_s_setprio(3);
+            }
+#if GF_TIMELINE
+            asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+            tl[5] = wall_clock64();
+#endif
+            // ---- the next unit (claimed during the last group) and its bitmask row: requested now, it travels under the epilogue
+            if (!have_next && lane == 0)   // a unit without a single hit
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed)::"memory");
+            have_next = true;
+            {
+                const int nl = __builtin_amdgcn_readfirstlane((int)claimed), nlog = xcd * per_xcd + nl;
+                if (nl < per_xcd && nlog < nunits && !(a.dbg & 1)) {
+                    const int s2 = (int)__umulhi((uint32_t)nlog, m_ps), r2 = nlog - s2 * per_super;
+                    const int srow2 = a.nsy == 1 ? s2 : (int)__umulhi((uint32_t)s2, m_nsy), scol2 = s2 - srow2 * a.nsy;
+                    if (srow2 * kSuper + 4 * (r2 & 1) < a.H && scol2 * kSuper + 4 * ((r2 >> 1) & 1) < a.W) {
+                        const unsigned long long *bm2 = a.bitmask + (size_t)s2 * a.nrow;
+                        for (int i = 0; 128 * i < a.nrow; ++i)
+                            if (128 * i + 2 * lane < a.nrow)
+                                __builtin_amdgcn_global_load_lds((gptr)(bm2 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
+                        next_row = true;
+                    }
+                }
+            }
+            // ---- accumulators C[channel (q&3) + 8 (q>>2) + 4 h][voxel n of block b] -> out_logits (see the tile kernel)
+            typedef __attribute__((address_space(1))) float gfloat;
+            typedef float nt4v __attribute__((ext_vector_type(4), aligned(4)));
+            typedef __attribute__((address_space(1))) nt4v nt4;
+            if ((a.D & 3) == 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float *row = stage + ((b >> 1) * 64 + 32 * (b & 1) + n) * kC;
+                    *reinterpret_cast<float2 *>(row + 4 * h) = make_float2(acc[b][0], acc[b][1]);
+                    *reinterpret_cast<float2 *>(row + 4 * h + 2) = make_float2(acc[b][2], acc[b][3]);
+                    *reinterpret_cast<float2 *>(row + 8 + 4 * h) = make_float2(acc[b][4], acc[b][5]);
+                    *reinterpret_cast<float2 *>(row + 10 + 4 * h) = make_float2(acc[b][6], acc[b][7]);
+                    if (h == 0) *reinterpret_cast<float2 *>(row + 16) = make_float2(acc[b][8], acc[b][9]);
+                }
+                uint32_t off[10];
+                uint32_t okbits = 0u;
+                int nst_count = 0;
+#pragma unroll
+                for (int it = 0; it < 10; ++it) {
+                    const int half = it / 5, i = lane + 64 * (it % 5);           // float4 i of the brick's 16 runs x 18
+                    const int run = i / kC, k = i - run * kC;
+                    const int cx = Xw + (run >> 2), cy = Y0 + (run & 3), Zb = Zw + 4 * half;
+                    const bool ok = i < 16 * kC && cx < a.H && cy < a.W && Zb < a.D;
+                    okbits |= ok ? (1u << it) : 0u;
+                    nst_count += __builtin_amdgcn_ballot_w64(ok) != 0ull ? 1 : 0;   // store instructions that will be issued
+                    off[it] = ok ? (uint32_t)((((size_t)cx * a.W + cy) * a.D + Zb) * kC + 4 * k) : 0u;
+                }
+                nst = nst_count;
+                asm volatile("" : "+v"(off[0]), "+v"(off[1]), "+v"(off[2]), "+v"(off[3]), "+v"(off[4]), "+v"(off[5]), "+v"(off[6]),
+                             "+v"(off[7]), "+v"(off[8]), "+v"(off[9]));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                gfloat *obase = (gfloat *)a.out_logits;
+#pragma unroll
+                for (int it = 0; it < 10; ++it) {
+                    if (okbits & (1u << it)) {
+                        const float4 v = *reinterpret_cast<const float4 *>(stage + (it / 5) * 64 * kC + 4 * (lane + 64 * (it % 5)));
+                        __builtin_nontemporal_store((nt4v){v.x, v.y, v.z, v.w}, (nt4 *)(obase + off[it]));
+                    }
+                }
+            } else {
+                // depths that are not a multiple of 4 (no reference config): the staged rows leave element by element
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float *row = stage + ((b >> 1) * 64 + 32 * (b & 1) + n) * kC;
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) {
+                        const int ch = (q & 3) + 8 * (q >> 2) + 4 * h;
+                        if (ch < kC) row[ch] = acc[b][q];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < 2 * 64 * kC; i += 64) {
+                    const int half = i / (64 * kC), l = (i % (64 * kC)) / kC, ch = i % kC;
+                    const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zw + 4 * half + (l & 3);
+                    if (cx < a.H && cy < a.W && cz < a.D) a.out_logits[(((size_t)cx * a.W + cy) * a.D + cz) * kC + ch] = stage[i];
+                }
+            }
+            // the staged rows have been read (their stores are under way): the next unit may write the slot and the list again
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if GF_TIMELINE
+            tl[6] = wall_clock64();
+            if (a.timeline && lane == 0)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a.timeline[8 * (size_t)logical + k] = tl[k];
+#endif
+        }
+        if (!have_next) {   // a unit outside the grid
+            if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed)::"memory");
+        }
+        local = __builtin_amdgcn_readfirstlane((int)claimed);
+        row_there = next_row;
+        nst_prev = nst;
+    }
+}
+
+// workgroups (= waves) of the wave-autonomous kernel: eight per CU (one 20 KB LDS block and 256 VGPRs each), a multiple of 8
+static int mfma_wave_grid(int nunits)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    const int per_xcd = (nunits + 7) / 8;
+    return 8 * std::min(per_xcd, std::max(1, 8 * cus / 8));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1572,12 +2135,26 @@ static int mfma_grid(int ntiles_total)
     return 8 * std::min(per_xcd, std::max(1, 2 * cus / 8));
 }
 
-static void launch_render_mfma(const RenderArgs &r, hipStream_t stream)
+// units (double bricks) of the wave-autonomous kernel for a grid
+static int mfma_wave_units(int nsuper, int D) { return nsuper * 4 * ((D + 7) / 8); }
+
+// which of the two matrix-core kernels renders a call: the wave-autonomous one wherever a bitmask row fits its LDS block
+// (GF_MFMA_TILE in the environment keeps the tile kernel, for comparison)
+static bool mfma_by_wave(int nrow)
+{
+    static const bool force_tile = getenv("GF_MFMA_TILE") != nullptr;
+    return nrow <= kWRow && !force_tile;
+}
+
+static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stream)
 {
     hipEvent_t ev0, ev1;
     const bool prof = profile_slot(&ev0, &ev1);
     if (prof) (void)hipEventRecord(ev0, stream);
-    hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
+    if (mfma_by_wave(r.nrow))
+        hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
+    else
+        hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
     if (prof) (void)hipEventRecord(ev1, stream);
 }
 
@@ -1701,7 +2278,9 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.lattice = (mfma && verify) ? 1 : 0;
     uint32_t *tile_counters = ws.flags + 4608;  // [64 x], x < 8: inside the 32 KB flag section, past the verdicts
     pa.tile_counters = mfma ? tile_counters : nullptr;
-    pa.tile_counter_init = mfma ? (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8) : 0u;
+    pa.tile_counter_init = !mfma ? 0u
+                           : mfma_by_wave(ws.nrow) ? (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8)
+                                                   : (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8);
     const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
@@ -1723,8 +2302,9 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
     ra.tile_counters = tile_counters;
+    { const char *e = getenv("GF_DBG"); ra.dbg = e ? atoi(e) : 0; }
     if (mfma)
-        launch_render_mfma(ra, stream);
+        launch_render_mfma(ra, ws.nsuper, stream);
     else if (variant == GF_SPLAT_BASE)
         launch_render_exp<GF_SPLAT_BASE>(flags, dense_candidate, ra, stream);
     else

@@ -30,7 +30,7 @@ from gaussianformer_amd.local_aggregate import LocalAggregator  # noqa: E402
 from gaussianformer_amd.sparse_conv import SparseConv3D  # noqa: E402
 from gaussianformer_amd.synthetic import DAF_LEVELS, voxel_centres  # noqa: E402
 
-PC_RANGE = [-40.0, -40.0, -1.0, 40.0, 40.0, 5.4]
+PC_RANGE = [-50.0, -50.0, -5.0, 50.0, 50.0, 3.0]      # config/nuscenes_gs25600_solid.py:69
 CAMS, LEVELS, GROUPS, KEY_PTS, EMBED = 6, 4, 4, 9, 128
 
 
@@ -71,7 +71,7 @@ def run(anchors=25600, steps=10, warmup=3):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     A = args.anchors
-    H, W, D, cell = 200, 200, 16, 0.4
+    H, W, D, cell = 200, 200, 16, 0.5      # grid_size 0.5 m (config :154): voxel centres are exact in fp32
     pc_min = PC_RANGE[:3]
 
     blocks = torch.nn.ModuleList([Block() for _ in range(4)]).to(dev)
