@@ -1655,6 +1655,9 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     };
 
     uint32_t *ctr = a.tile_counters + 64 * xcd;
+    // (Longer rows, walked in pieces of kWRow words with the next piece requested while the current one is consumed, were built
+    // and measured at P = 144 000 -- four pieces: 94 against the tile kernel's 84 us per step, every wave scanning 2 250 words
+    // by itself -- so rows that do not fit s_row stay with the tile kernel.)
     const int nchunk = (a.nwords + 63) >> 6;
     // unit index -> (supertile, quarter, z brick) -> supertile row and column: divisions by launch constants, as multiplications
     // by rounded-up reciprocals (exact for the < 2^20 indices of a grid)
@@ -1682,9 +1685,9 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             unsigned long long tl[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
 #endif
             __builtin_amdgcn_s_setprio(3);
-            // the whole bitmask row by LDS-DMA: 128 words per instruction, every piece in flight at once
+            // a piece of the bitmask row by LDS-DMA: 128 words per instruction, all of them in flight at once
             if (!row_there)
-                for (int i = 0; 128 * i < a.nrow; ++i)
+                for (int i = 0; 128 * i < a.nrow; ++i)   // (rows are padded to an even word count)
                     if (128 * i + 2 * lane < a.nrow)
                         __builtin_amdgcn_global_load_lds((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
             f32x16 acc[4];
@@ -1693,7 +1696,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
             const double Cx = p0x + ((double)Xw + 1.5) * sx, Cy = p0y + ((double)Y0 + 1.5) * sy, Cz = p0z + ((double)Zw + 3.5) * sz;
-            int list_len = 0, qlen = 0, qhead = 0, npend = 0, c = 0, sg = 0;
+            int list_len = 0, qlen = 0, qhead = 0, npend = 0;
             // A prefetched row is older than the previous unit's output stores and memory operations complete in order: with
             // exactly ten stores behind it, "at most ten outstanding" means the row has landed -- without waiting for the stores.
             if (row_there && nst_prev == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -1701,51 +1704,53 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
 #if GF_TIMELINE
             tl[1] = wall_clock64();
 #endif
+            int c = 0, sg = 0;
             // ---- fill, fast path (the whole row at once).  Extracting ids bit by bit costs one loop iteration per set bit of the
             // busiest LANE, and with a word per lane a chunk of 64 words has a lane with four or five candidates while most
             // have none (0.6 % of the bits are set): 35 iterations of a dependent 64-bit chain per row, 2.3 us.  So the NONZERO
-            // words are first compacted (ballot + count, no loop) into a dense array -- it borrows the record slot, idle until
-            // the first group -- and the bits are extracted from that: three rounds of two or three iterations.
+            // words are first compacted (one scan of per-lane counts, no loop) into a dense array -- it borrows the record slot, idle
+            // until the first group -- and the bits are extracted from that: three rounds of two or three iterations.
             {
-                uint32_t *s_dw = s_u;                                                       // [kWList] word index
-                unsigned long long *s_db = reinterpret_cast<unsigned long long *>(s_u + kWList);   // [kWList] its bits
-                int nd = 0;
-                // (unrolled and branch-free up to the reads: the ten LDS reads go out back to back instead of one per iteration)
-                constexpr int kWChunks = (kWRow + 63) / 64;
-                unsigned long long wd[kWChunks];
+                constexpr int kWDense = kWList;
+                uint32_t *s_dw = s_u;                                                               // [kWDense] word index
+                unsigned long long *s_db = reinterpret_cast<unsigned long long *>(s_u + kWDense);  // [kWDense] its bits
+                // (lane L owns the kw consecutive words [kw L, kw L + kw): one wave scan of the per-lane counts places them all)
+                constexpr int kWPer = (kWRow + 63) / 64;
+                const int kw = nchunk;
+                unsigned long long wd[kWPer];
+                int mine = 0;
 #pragma unroll
-                for (int cc = 0; cc < kWChunks; ++cc) {
-                    const int w = 64 * cc + lane;
-                    const unsigned long long x = s_row[min(w, kWRow - 1)];
-                    wd[cc] = w < a.nwords ? x : 0ull;
+                for (int k = 0; k < kWPer; ++k) wd[k] = s_row[min(kw * lane + k, kWRow - 1)];
+                // (all ten reads are issued, back to back: left to itself hipcc sinks each one into the branch of its `k < kw`
+                // and waits for it there -- ten LDS round trips in a row)
+                static_assert(kWPer == 10, "operand list below");
+                asm volatile("" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]), "+v"(wd[3]), "+v"(wd[4]), "+v"(wd[5]), "+v"(wd[6]), "+v"(wd[7]),
+                             "+v"(wd[8]), "+v"(wd[9]));
+#pragma unroll
+                for (int k = 0; k < kWPer; ++k) {
+                    const int w = kw * lane + k;
+                    wd[k] = (k < kw && w < a.nwords) ? wd[k] : 0ull;
+                    mine += wd[k] != 0ull ? 1 : 0;
                 }
+                const int incl_nz = wave_inclusive_scan(mine);
+                const int nd = __builtin_amdgcn_readlane(incl_nz, 63);
+                if (nd <= kWDense) {
+                    int p = incl_nz - mine;
 #pragma unroll
-                for (int cc = 0; cc < kWChunks; ++cc) {
-                    const unsigned long long nzm = __builtin_amdgcn_ballot_w64(wd[cc] != 0ull);
-                    const int p = nd + (int)mbcnt(nzm);
-                    if (wd[cc] != 0ull && p < kWList) {
-                        s_dw[p] = (uint32_t)(64 * cc + lane);
-                        s_db[p] = wd[cc];
+                    for (int k = 0; k < kWPer; ++k) {
+                        if (wd[k] != 0ull) {
+                            s_dw[p] = (uint32_t)(kw * lane + k);
+                            s_db[p] = wd[k];
+                            ++p;
+                        }
                     }
-                    nd += __builtin_popcountll(nzm);
                 }
-                if (nd <= kWList) {
+                if (nd <= kWDense) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     int tot = 0;
                     bool fits = true;
-                    for (int d0 = 0; d0 < nd; d0 += 64) {
-                        const int i = d0 + lane;
-                        unsigned long long bits = i < nd ? s_db[i] : 0ull;
-                        const uint32_t id0 = (i < nd ? s_dw[i] : 0u) * 64u;
-                        const int cnt = __builtin_popcountll(bits);
-                        const int incl = wave_inclusive_scan(cnt);
-                        const int t = __builtin_amdgcn_readlane(incl, 63);
-                        if (tot + t > kWList) {
-                            fits = false;
-                            break;
-                        }
-                        int pos = tot + incl - cnt;
+                    auto extract = [&](unsigned long long bits, uint32_t id0, int pos) {
                         if (bits) {   // a dense word has at least one bit (only the lanes past the end have none) ...
                             s_lg[pos++] = id0 + (uint32_t)__builtin_ctzll(bits);
                             bits &= bits - 1;
@@ -1755,7 +1760,51 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                             bits &= bits - 1;
                             s_lg[pos++] = id0 + (uint32_t)j;
                         }
-                        tot += t;
+                    };
+                    if (nd <= 192) {
+                        // the usual case, three rounds side by side: reads, counts and scans of the rounds do not depend on each other
+                        unsigned long long bb[3];
+                        uint32_t ii[3];
+                        int cn[3], in_[3], tt[3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            bb[q] = s_db[64 * q + lane];
+                            ii[q] = s_dw[64 * q + lane];
+                        }
+                        asm volatile("" : "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(ii[0]), "+v"(ii[1]), "+v"(ii[2]));   // (as above)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            bb[q] = 64 * q + lane < nd ? bb[q] : 0ull;
+                            ii[q] *= 64u;
+                            cn[q] = __builtin_popcountll(bb[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) in_[q] = wave_inclusive_scan(cn[q]);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) tt[q] = __builtin_amdgcn_readlane(in_[q], 63);
+                        tot = tt[0] + tt[1] + tt[2];
+                        if (tot <= kWList) {
+                            extract(bb[0], ii[0], in_[0] - cn[0]);
+                            extract(bb[1], ii[1], tt[0] + in_[1] - cn[1]);
+                            extract(bb[2], ii[2], tt[0] + tt[1] + in_[2] - cn[2]);
+                        } else {
+                            fits = false;
+                        }
+                    } else {
+                        for (int d0 = 0; d0 < nd; d0 += 64) {
+                            const int i = d0 + lane;
+                            const unsigned long long bits = i < nd ? s_db[i] : 0ull;
+                            const uint32_t id0 = (i < nd ? s_dw[i] : 0u) * 64u;
+                            const int cnt = __builtin_popcountll(bits);
+                            const int incl = wave_inclusive_scan(cnt);
+                            const int t = __builtin_amdgcn_readlane(incl, 63);
+                            if (tot + t > kWList) {
+                                fits = false;
+                                break;
+                            }
+                            extract(bits, id0, tot + incl - cnt);
+                            tot += t;
+                        }
                     }
                     if (fits) {   // the row is consumed: the loop below goes straight to the boxes
                         list_len = tot;
@@ -2017,18 +2066,26 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                     *reinterpret_cast<float2 *>(row + 10 + 4 * h) = make_float2(acc[b][6], acc[b][7]);
                     if (h == 0) *reinterpret_cast<float2 *>(row + 16) = make_float2(acc[b][8], acc[b][9]);
                 }
+                // float4 i = lane + 64 j (j < 5) of a brick's 16 runs x 18: run i / 18 = column (run >> 2, run & 3), piece i % 18; the
+                // upper brick's rows lie 4 voxels = 72 floats further on.  Ten 32-bit element offsets from the uniform base, all
+                // computed first (hipcc makes a store's address registers wait for the store to COMPLETE before they are rewritten).
                 uint32_t off[10];
                 uint32_t okbits = 0u;
                 int nst_count = 0;
 #pragma unroll
-                for (int it = 0; it < 10; ++it) {
-                    const int half = it / 5, i = lane + 64 * (it % 5);           // float4 i of the brick's 16 runs x 18
+                for (int j = 0; j < 5; ++j) {
+                    const int i = lane + 64 * j;
                     const int run = i / kC, k = i - run * kC;
-                    const int cx = Xw + (run >> 2), cy = Y0 + (run & 3), Zb = Zw + 4 * half;
-                    const bool ok = i < 16 * kC && cx < a.H && cy < a.W && Zb < a.D;
-                    okbits |= ok ? (1u << it) : 0u;
-                    nst_count += __builtin_amdgcn_ballot_w64(ok) != 0ull ? 1 : 0;   // store instructions that will be issued
-                    off[it] = ok ? (uint32_t)((((size_t)cx * a.W + cy) * a.D + Zb) * kC + 4 * k) : 0u;
+                    const int cx = Xw + (run >> 2), cy = Y0 + (run & 3);
+                    const bool okc = i < 16 * kC && cx < a.H && cy < a.W;
+                    const uint32_t o = (uint32_t)((((size_t)cx * a.W + cy) * a.D + Zw) * kC + 4 * k);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const bool ok = okc && Zw + 4 * half < a.D;
+                        okbits |= ok ? (1u << (5 * half + j)) : 0u;
+                        nst_count += __builtin_amdgcn_ballot_w64(ok) != 0ull ? 1 : 0;   // store instructions that will be issued
+                        off[5 * half + j] = ok ? o + 4 * kC * half : 0u;
+                    }
                 }
                 nst = nst_count;
                 asm volatile("" : "+v"(off[0]), "+v"(off[1]), "+v"(off[2]), "+v"(off[3]), "+v"(off[4]), "+v"(off[5]), "+v"(off[6]),
@@ -2036,12 +2093,15 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 gfloat *obase = (gfloat *)a.out_logits;
+                // all ten LDS reads first (unconditional: a lane without a store reads a row it will not use), then the stores
+                float4 val[10];
+#pragma unroll
+                for (int it = 0; it < 10; ++it)
+                    val[it] = *reinterpret_cast<const float4 *>(stage + (it / 5) * 64 * kC + 4 * (lane + 64 * (it % 5)));
 #pragma unroll
                 for (int it = 0; it < 10; ++it) {
-                    if (okbits & (1u << it)) {
-                        const float4 v = *reinterpret_cast<const float4 *>(stage + (it / 5) * 64 * kC + 4 * (lane + 64 * (it % 5)));
-                        __builtin_nontemporal_store((nt4v){v.x, v.y, v.z, v.w}, (nt4 *)(obase + off[it]));
-                    }
+                    if (okbits & (1u << it))
+                        __builtin_nontemporal_store((nt4v){val[it].x, val[it].y, val[it].z, val[it].w}, (nt4 *)(obase + off[it]));
                 }
             } else {
                 // depths that are not a multiple of 4 (no reference config): the staged rows leave element by element
