@@ -370,7 +370,6 @@ struct RenderArgs {
     float threshold;
     int raw_numerator;  // prob variant: logits = sum sem * prob, not divided by prob_sum (GF_PROB_NUMERATOR)
     uint32_t *tile_counters;  // matrix-core kernel: next unclaimed tile of XCD x at [64 x] (one cache line each)
-    int dbg;                  // experiments (GF_DBG in the environment)
 };
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
@@ -990,8 +989,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Persistent workgroups: two per CU, each walks tiles of ITS XCD (workgroup b runs on XCD b % 8; consecutive logical
     // tiles stay on one XCD so its L2 keeps their bitmask rows, boxes and records).  The first tile is the workgroup's slot,
-    // the following ones come from a per-XCD counter (zeroed by the prep kernel), claimed while the current tile's list is
-    // complete -- early enough to fetch the next tile's first bitmask words under the whole accumulation.
+    // the following ones come from a per-XCD counter (initialised by the prep kernel), claimed late in the current tile.
     __shared__ int s_next;
     const int xcd = (int)(blockIdx.x & 7u);
     const int per_xcd = (a.ntiles_total + 7) >> 3;  // logical tiles per XCD (the last XCD's tail may be short)
@@ -1116,20 +1114,17 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         int list_len = 0, w_next = 0, wi = 0, grp = 0, ngrp = 0, total = 0, off = 0, qlen = 0, qhead = 0, npend = 0;
         unsigned long long hits = 0ull;
         bool done = false;
-        // The next tile is claimed NOW (one returning device-scope atomic, ~1-2 us): its answer is first looked at when this
-        // tile's list is complete, so the round trip runs under the producer instead of in front of the accumulation.
-        uint32_t claimed = 0u;
+        // The next tile is claimed LATE: by wave 0 when it starts its last group of this tile (one returning atomic whose round
+        // trip hides under that group's blocks).  Claimed at the start of the tile -- as it was -- the next tile is reserved for
+        // a whole tile time, and near the end of the launch a reserved tile is a tile no idle workgroup can take (-1.5 us at
+        // P = 144 000).
         // Scope: the counter of XCD x is only touched by the workgroups with blockIdx % 8 == x, which run on that XCD, so a
         // workgroup-scope RMW -- performed in the XCD's own L2, no trip to the memory side -- is enough.  Should the
         // placement ever differ, two L2s hand out the same index and a tile is computed twice (same values): never skipped.
-        // (Inline asm: hipcc waits for a returning atomic at the end of the divergent block that issued it; written this way
-        // its round trip runs under the row's LDS-DMA and both are waited for by the one s_waitcnt below.)
-        const bool late = (a.dbg & 2) != 0;
+        // (Inline asm: hipcc waits for a returning atomic at the end of the divergent block that issued it.)
+        uint32_t claimed = 0u;
         bool claim_issued = false;
         uint32_t *ctr = a.tile_counters + 64 * xcd;
-        if (last_zg && tid == 0 && !late) {
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
-        }
         // The producer is a short chain of dependent steps (scan, barrier, LDS): at equal priority it queues behind the
         // other workgroup's accumulation on every SIMD; raised, it costs that workgroup a few hundred issue slots.
         __builtin_amdgcn_s_setprio(3);
@@ -1247,16 +1242,11 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 if (ngrp == 32 && (tid & 7) == 0) s_scan[8 + (tid >> 3)] = (uint32_t)off;
                 if (ngrp != 1) __syncthreads();
             }
-            if (done && last_zg && tid == 0 && !late) {
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) :: "memory");   // (long since back: waited for with the row)
-                s_next = (int)claimed;
-            }
-            __syncthreads();  // list complete (and the next tile claimed)
+            __syncthreads();  // list complete
             __builtin_amdgcn_s_setprio(0);
 #if GF_TIMELINE
             if (a.timeline && tid == 0 && done) a.timeline[4 * (size_t)logical + 1] = wall_clock64();
 #endif
-            if (done && last_zg && !late) next_local = s_next;
             // The packed boxes of the list's Gaussians come into LDS by LDS-DMA (two 4-byte pieces per entry, gathered by id):
             // the waves then filter the list against their double brick without a single global load, and the only VMEM
             // traffic of the accumulation are the record requests -- no `s_waitcnt vmcnt(0)` of a box load drains them.
@@ -1314,7 +1304,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                     __builtin_amdgcn_wave_barrier();
                     const int nnext = min(avail, 32);
                     if (nnext > 0) request_records_at(qhead, qn, nnext);
-                    if (late && last_zg && wave == 0 && last && nnext == 0 && !claim_issued) {
+                    if (last_zg && wave == 0 && last && nnext == 0 && !claim_issued) {
                         claim_issued = true;
                         if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
                     }
@@ -1436,7 +1426,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 }
             }
             if (done) {
-                if (late && last_zg && wave == 0) {
+                if (last_zg && wave == 0) {
                     if (!claim_issued && lane == 0)
                         asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) :: "memory");
@@ -1533,10 +1523,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     }
 #endif
     // ---- next tile of this workgroup
-    if (a.dbg & 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        next_local = s_next;
-    }
+    // the slowest wave is done with the list and the scan scratch, and wave 0 has published the tile it claimed.  LDS ordering
+    // only: a full __syncthreads() also waits (vmcnt) for the output stores just issued to be acknowledged
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    next_local = s_next;
     local = next_local;
     logical = xcd * per_xcd + local;
     s = logical / kTilesPerSuper; t = logical % kTilesPerSuper;
@@ -1546,7 +1536,6 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     bm = a.bitmask + (size_t)s * a.nrow;
     // the slowest wave is done with the list and the scan scratch.  LDS ordering only: a full __syncthreads() also waits
     // (vmcnt) for the output stores just issued to be acknowledged
-    if (!(a.dbg & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -2040,7 +2029,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             have_next = true;
             {
                 const int nl = __builtin_amdgcn_readfirstlane((int)claimed), nlog = xcd * per_xcd + nl;
-                if (nl < per_xcd && nlog < nunits && !(a.dbg & 1)) {
+                if (nl < per_xcd && nlog < nunits) {
                     const int s2 = (int)__umulhi((uint32_t)nlog, m_ps), r2 = nlog - s2 * per_super;
                     const int srow2 = a.nsy == 1 ? s2 : (int)__umulhi((uint32_t)s2, m_nsy), scol2 = s2 - srow2 * a.nsy;
                     if (srow2 * kSuper + 4 * (r2 & 1) < a.H && scol2 * kSuper + 4 * ((r2 >> 1) & 1) < a.W) {
@@ -2202,8 +2191,7 @@ static int mfma_wave_units(int nsuper, int D) { return nsuper * 4 * ((D + 7) / 8
 // (GF_MFMA_TILE in the environment keeps the tile kernel, for comparison)
 static bool mfma_by_wave(int nrow)
 {
-    static const bool force_tile = getenv("GF_MFMA_TILE") != nullptr;
-    return nrow <= kWRow && !force_tile;
+    return nrow <= kWRow && getenv("GF_MFMA_TILE") == nullptr;   // (read per call: a test runs both kernels in one process)
 }
 
 static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stream)
@@ -2362,7 +2350,6 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
     ra.tile_counters = tile_counters;
-    { const char *e = getenv("GF_DBG"); ra.dbg = e ? atoi(e) : 0; }
     if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);
     else if (variant == GF_SPLAT_BASE)

@@ -62,6 +62,30 @@ def test_mfma_crowded_tile(gpu):
     assert_logits_close(got["logits"], ref, tol=1e-4)
 
 
+@pytest.mark.parametrize("config,kw", [
+    ("nuscenes_gs25600_solid", {}),                                   # the headline shape: 401 bitmask words, ~165 candidates per supertile
+    ("nuscenes_gs144000", dict(P=6000, H=20, W=20, D=16)),            # crowded: lists longer than the wave kernel's, refills
+    ("nuscenes_gs25600_solid", dict(P=39000, H=44, W=36, D=24)),     # 610 words (nearly the longest row it takes), three z bricks
+    ("nuscenes_gs25600_solid", dict(P=700, H=9, W=7, D=4)),          # one supertile column, one partial brick
+])
+def test_mfma_wave_and_tile_kernels_agree_bit_for_bit(gpu, config, kw, monkeypatch):
+    """The two matrix-core kernels -- one wave per double brick (rows of <= 618 words) and one workgroup per tile
+    (GF_MFMA_TILE=1 forces it) -- take a double brick's hits in the same groups of 32 in ascending index and run the same
+    arithmetic on them: equal bits, whatever path (fast fill, chunked refill) built the lists."""
+    from gaussianformer_amd import _lib
+    si = make_splat_inputs(config, seed=4, **kw)
+    pi, mi, radii, cov6 = prep(si)
+    monkeypatch.delenv("GF_MFMA_TILE", raising=False)
+    wave, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    monkeypatch.setenv("GF_MFMA_TILE", "1")
+    tile, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    monkeypatch.delenv("GF_MFMA_TILE", raising=False)
+    assert np.isfinite(wave["logits"]).all()
+    assert np.array_equal(wave["logits"], tile["logits"])
+    ref = _oracle_logits(si, pi, mi, radii, cov6)
+    assert_logits_close(wave["logits"], ref, tol=1e-4)
+
+
 def test_mfma_inexact_lattice_falls_back(gpu):
     """pts one ulp off the lattice in a few voxels (still inside their voxels): the device-side check must notice -- the
     kernel evaluates its polynomial on the lattice, not on pts -- and the arbitrary-points body must produce the result

@@ -7,11 +7,13 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$R.log 2>&
 bash tools/collect_profiles.sh $R > gpurun_out/collect_$R.log 2>&1; head -3 gpurun_out/collect_$R.log | cut -c1-600
 timeout 600 python tools/bench_ops.py > gpurun_out/profiles_$R/bench_ops_$R.jsonl 2> gpurun_out/bench_ops.err; cat gpurun_out/profiles_$R/bench_ops_$R.jsonl
 timeout 300 python tools/timeline.py nuscenes_gs25600_solid exact > gpurun_out/profiles_$R/timeline_render_$R.txt 2>&1
-timeout 300 python tools/timeline.py nuscenes_gs25600_solid > gpurun_out/profiles_$R/timeline_render_mfma_$R.txt 2>&1; tail -14 gpurun_out/profiles_$R/timeline_render_mfma_$R.txt
-timeout 300 python tools/timeline.py nuscenes_gs144000 > gpurun_out/profiles_$R/timeline_render_mfma_gs144000_$R.txt 2>&1
+timeout 300 python tools/timeline_wave.py nuscenes_gs25600_solid > gpurun_out/profiles_$R/timeline_render_mfma_wave_$R.txt 2>&1; tail -12 gpurun_out/profiles_$R/timeline_render_mfma_wave_$R.txt
+timeout 300 python tools/timeline.py nuscenes_gs25600_solid > gpurun_out/profiles_$R/timeline_render_mfma_tile_$R.txt 2>&1
+timeout 300 python tools/timeline.py nuscenes_gs144000 > gpurun_out/profiles_$R/timeline_render_mfma_tile_gs144000_$R.txt 2>&1
 timeout 300 python tools/probe_dense.py > gpurun_out/profiles_$R/probe_assume_dense_$R.txt 2>&1
 bash tools/gpu/kernel_pair.sh > gpurun_out/profiles_$R/kernel_pair_$R.txt 2>&1; cat gpurun_out/profiles_$R/kernel_pair_$R.txt
 timeout 300 python tools/mfma_probe.py > gpurun_out/profiles_$R/mfma_probe_$R.txt 2>&1; grep "us per step\|oracle/_ref" gpurun_out/profiles_$R/mfma_probe_$R.txt
+echo "--- GF_MFMA_TILE=1 (the tile matrix-core kernel at every P)" >> gpurun_out/profiles_$R/mfma_probe_$R.txt; GF_MFMA_TILE=1 timeout 300 python tools/mfma_probe.py 2>&1 | grep "mfma" >> gpurun_out/profiles_$R/mfma_probe_$R.txt
 timeout 300 python tools/bench_frame.py --frames 20 --graph > gpurun_out/profiles_$R/bench_frame_$R.jsonl 2> gpurun_out/bench_frame.err; cut -c1-140 gpurun_out/profiles_$R/bench_frame_$R.jsonl
 rm -rf gpurun_out/kt_frame; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_frame -- python tools/bench_frame.py --configs nuscenes_gs25600_solid --frames 10 > gpurun_out/kt_frame.log 2>&1; cp $(find gpurun_out/kt_frame -name '*kernel_stats.csv' | head -1) gpurun_out/profiles_$R/kernel_stats_frame_gs25600_$R.csv
 timeout 300 python tools/uniform_experiment.py > gpurun_out/profiles_$R/uniform_experiment_$R.txt 2>&1
