@@ -1673,7 +1673,6 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
 #if GF_TIMELINE
             unsigned long long tl[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
 #endif
-            __builtin_amdgcn_s_setprio(3);
             // a piece of the bitmask row by LDS-DMA: 128 words per instruction, all of them in flight at once
             if (!row_there)
                 for (int i = 0; 128 * i < a.nrow; ++i)   // (rows are padded to an even word count)
@@ -1873,7 +1872,6 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
 #if GF_TIMELINE
                 if (!tl[3]) tl[3] = wall_clock64();
 #endif
-                __builtin_amdgcn_s_setprio(0);
                 // ---- consume: hits of the double brick -> queue -> groups of 32 (one-deep record pipeline, as in the tile kernel)
                 for (int base = 0; base < list_len || (last && base == 0); base += 64) {
                     const int i = base + lane;
@@ -2016,7 +2014,6 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 }
                 if (last) break;
                 list_len = 0;
-                __builtin_amdgcn_s_setprio(3);
             }
 #if GF_TIMELINE
             asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
