@@ -1578,6 +1578,30 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     const int nunits = a.nsx * a.nsy * per_super;
     const int per_xcd = (nunits + 7) >> 3;
 
+    // unit index -> (supertile, quarter, z brick) -> supertile row and column: divisions by launch constants, as multiplications
+    // by rounded-up reciprocals (exact for the < 2^20 indices of a grid)
+    const uint32_t m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / (unsigned)per_super);
+    const uint32_t m_nsy = (uint32_t)(((1ull << 32) + a.nsy - 1) / (unsigned)a.nsy);
+    using gptr = const __attribute__((address_space(1))) void *;
+    using lptr = __attribute__((address_space(3))) void *;
+    int local = (int)(blockIdx.x >> 3);
+    bool row_there = false;  // the bitmask row of unit `local` has already been requested into s_row
+    // The first unit's bitmask row is requested before anything else: its round trip then runs under the verdict loads and the
+    // set-up below instead of behind them (a failed verdict wastes one LDS-DMA).
+    {
+        const int logical = xcd * per_xcd + local;
+        if (local < per_xcd && logical < nunits) {
+            const int s0 = (int)__umulhi((uint32_t)logical, m_ps), r0 = logical - s0 * per_super;
+            const int srow0 = a.nsy == 1 ? s0 : (int)__umulhi((uint32_t)s0, m_nsy), scol0 = s0 - srow0 * a.nsy;
+            if (srow0 * kSuper + 4 * (r0 & 1) < a.H && scol0 * kSuper + 4 * ((r0 >> 1) & 1) < a.W) {
+                const unsigned long long *bm0 = a.bitmask + (size_t)s0 * a.nrow;
+                for (int i = 0; 128 * i < a.nrow; ++i)
+                    if (128 * i + 2 * lane < a.nrow)
+                        __builtin_amdgcn_global_load_lds((gptr)(bm0 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
+                row_there = true;
+            }
+        }
+    }
     // verdicts of the prep launch (see gf_splat_render_mfma_kernel)
     int verdict = 0;
     if (a.verify_dense) {
@@ -1628,8 +1652,6 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
         }
     }
 
-    using gptr = const __attribute__((address_space(1))) void *;
-    using lptr = __attribute__((address_space(3))) void *;
     auto request_records_at = [&](int qh, int start, int count) {
         const uint32_t id = q_id[(qh + start + (n < count ? n : 0)) & (kQCap - 1)];
         const char *rec = reinterpret_cast<const char *>(a.records + (size_t)id * kRecDwords);
@@ -1648,12 +1670,6 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     // and measured at P = 144 000 -- four pieces: 94 against the tile kernel's 84 us per step, every wave scanning 2 250 words
     // by itself -- so rows that do not fit s_row stay with the tile kernel.)
     const int nchunk = (a.nwords + 63) >> 6;
-    // unit index -> (supertile, quarter, z brick) -> supertile row and column: divisions by launch constants, as multiplications
-    // by rounded-up reciprocals (exact for the < 2^20 indices of a grid)
-    const uint32_t m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / (unsigned)per_super);
-    const uint32_t m_nsy = (uint32_t)(((1ull << 32) + a.nsy - 1) / (unsigned)a.nsy);
-    int local = (int)(blockIdx.x >> 3);
-    bool row_there = false;  // the bitmask row of unit `local` has already been requested into s_row (by the previous unit)
     int nst_prev = 0;        // ... and this many store instructions were issued after that request
     while (true) {  // units of this wave
         const int logical = xcd * per_xcd + local;
