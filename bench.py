@@ -220,7 +220,8 @@ def main():
             """Which body rendered the last call (state block, word 1) and the device verdict bits (word 2)."""
             w = self.plan.state_words()
             names = {_lib.GF_PATH_EXACT_TILE: "gf_splat_render_kernel (exact-fp32 tile kernel)",
-                     _lib.GF_PATH_MATRIX_CORE: "gf_splat_render_mfma_kernel (split-f16 MFMA, fp32 accumulate)",
+                     _lib.GF_PATH_MATRIX_CORE: "gf_splat_render_mfma_kernel (split-f16 MFMA, fp32 accumulate; one workgroup per tile)",
+                     _lib.GF_PATH_MATRIX_CORE_WAVE: "gf_splat_render_mfma_wave_kernel (split-f16 MFMA, fp32 accumulate; one wave per double brick)",
                      _lib.GF_PATH_ARBITRARY: "arbitrary-points body (FALL-BACK: a device verdict failed)"}
             return names.get(w[1], str(w[1])), w[2]
 

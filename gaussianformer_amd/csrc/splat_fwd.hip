@@ -1617,7 +1617,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     }
     if (blockIdx.x == 0 && lane == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
-        a.state[1] = verdict ? GF_PATH_ARBITRARY : GF_PATH_MATRIX_CORE;
+        a.state[1] = verdict ? GF_PATH_ARBITRARY : GF_PATH_MATRIX_CORE_WAVE;
         a.state[2] = (uint32_t)verdict;
     }
     if (verdict) {

@@ -75,7 +75,8 @@ extern "C" {
 
 /* values of word 1 of the state block after gf_splat_forward: which body rendered the call */
 #define GF_PATH_EXACT_TILE 0     /* exact-fp32 tile kernel (dense grid) */
-#define GF_PATH_MATRIX_CORE 1    /* split-f16 MFMA kernel (dense exact lattice) */
+#define GF_PATH_MATRIX_CORE 1    /* split-f16 MFMA kernel (dense exact lattice), one workgroup per tile: P > 39 552 */
+#define GF_PATH_MATRIX_CORE_WAVE 3 /* the same arithmetic (equal bits), one wave per double brick: P <= 39 552 */
 #define GF_PATH_ARBITRARY 2      /* arbitrary-points body (pts not the dense grid, or a failed lattice / range verdict) */
 
 int gf_abi_version(void);

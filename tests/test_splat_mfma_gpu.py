@@ -132,7 +132,7 @@ def test_mfma_coefficient_range_verdict(gpu):
     cov6[5] = cov6[6]
     t[7] = torch.from_numpy(cov6).to(gpu)
     _, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D)
-    assert state.view(torch.int32)[:3].tolist() == [0, _lib.GF_PATH_MATRIX_CORE, 0]
+    assert state.view(torch.int32)[:3].tolist() == [0, _lib.GF_PATH_MATRIX_CORE_WAVE, 0]   # (a small P: the wave kernel)
 
 
 @pytest.mark.parametrize("config", ["nuscenes_gs25600_solid", "nuscenes_gs144000"])
