@@ -98,3 +98,16 @@ def test_ctypes_signatures_match_the_header_prototypes():
         restype, argtypes = _lib.SIGNATURES[name]
         got = [klass_c(t) for t in argtypes]
         assert got == want, (name, got, want)
+
+
+def test_python_constants_match_the_header_defines():
+    """Every GF_* constant gaussianformer_amd._lib mirrors has the value include/gf_hip.h gives it (flags, path and
+    verdict codes, the ABI version): a drifted flag would silently select another kernel."""
+    text = open(os.path.join(ROOT, "include", "gf_hip.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(GF_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b", text, flags=re.M)}
+    assert defines["GF_ABI_VERSION"] == _lib.GF_ABI_VERSION
+    mirrored = [n for n in dir(_lib) if n.startswith("GF_") and isinstance(getattr(_lib, n), int)]
+    assert len(mirrored) >= 15
+    for n in mirrored:
+        assert n in defines, f"{n} is not defined in include/gf_hip.h"
+        assert defines[n] == getattr(_lib, n), (n, defines[n], getattr(_lib, n))
