@@ -2073,7 +2073,6 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 // computed first (hipcc makes a store's address registers wait for the store to COMPLETE before they are rewritten).
                 uint32_t off[10];
                 uint32_t okbits = 0u;
-                int nst_count = 0;
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     const int i = lane + 64 * j;
@@ -2085,11 +2084,11 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                     for (int half = 0; half < 2; ++half) {
                         const bool ok = okc && Zw + 4 * half < a.D;
                         okbits |= ok ? (1u << (5 * half + j)) : 0u;
-                        nst_count += __builtin_amdgcn_ballot_w64(ok) != 0ull ? 1 : 0;   // store instructions that will be issued
                         off[5 * half + j] = ok ? o + 4 * kC * half : 0u;
                     }
                 }
-                nst = nst_count;
+                // (a unit inside the grid issues all ten store instructions: the count the next unit's row wait relies on)
+                nst = (Xw + 4 <= a.H && Y0 + 4 <= a.W && Zw + 8 <= a.D) ? 10 : -1;
                 asm volatile("" : "+v"(off[0]), "+v"(off[1]), "+v"(off[2]), "+v"(off[3]), "+v"(off[4]), "+v"(off[5]), "+v"(off[6]),
                              "+v"(off[7]), "+v"(off[8]), "+v"(off[9]));
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
