@@ -359,8 +359,64 @@ def main():
                            "HBM; frames_per_s = eager launches, frames_per_s_graph = the same frame replayed as one captured HIP graph")
             return out
 
+        def gs144000_forward():
+            # BASELINE config [3]: the same measurement for nuscenes_gs144000 (P = 144 000 into the same grid), so the
+            # driver's line records it: K/4 plain steps for the step time, then bracketed launches for the render kernel
+            w3 = Workload("nuscenes_gs144000")
+            steps = max(10, args.steps // 4)
+            for _ in range(30):
+                w3.step()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            for _ in range(steps):
+                w3.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t5) / steps
+            _lib.check(lib.gf_profile_enable(KERNEL_SAMPLES), "gf_profile_enable")
+            for _ in range(KERNEL_SAMPLES):
+                w3.step()
+            torch.cuda.synchronize()
+            b3 = (ctypes.c_float * KERNEL_SAMPLES)()
+            n3 = lib.gf_profile_read(b3, KERNEL_SAMPLES)
+            lib.gf_profile_enable(0)
+            k_ms = float(np.mean(b3[:n3])) if n3 > 0 else None
+            name3, bits3 = w3.path()
+            ab = algorithmic_bytes(w3.P_total, w3.N)
+            traffic3, traffic_step3, note3 = committed_traffic("nuscenes_gs144000")
+            r = {"config": f"nuscenes_gs144000: splat forward of ONE frame, P={w3.P_total} -> {w3.si.H}x{w3.si.W}x{w3.si.D}x18, bs=1",
+                 "value": w3.P_total / dt, "unit": "Gaussians/s", "ms_per_step": dt * 1e3, "steps": steps,
+                 "roofline": None if not k_ms else {
+                     "bound": "hbm", "achieved": ab / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic3, "traffic_step": traffic_step3,
+                     "kernel": name3, "verdict_bits": bits3, "kernel_us": k_ms * 1e3, "kernel_launches_timed": n3,
+                     "algorithmic_bytes": ab, "op_achieved": ab / dt / 1e9, "op_frac": ab / dt / 1e9 / HBM_PEAK_GBS}}
+            if note3:
+                r["roofline"]["traffic_note"] = note3
+            return r
+
+        def verified_once():
+            # the same K steps with the pts scan skipped (GF_PTS_ASSUME_DENSE: the grid was verified once, as
+            # LocalAggregator.register_grid does for a tensor it is handed every frame); the range verdicts still run.
+            # NEVER the headline: `value` above re-verifies the grid in every step.
+            plan = SplatForwardPlan(wl.variant, *wl.tensors, si.H, si.W, si.D, flags=_lib.GF_PTS_ASSUME_DENSE)
+            ref_out = wl.plan.run(wl.stream).clone()
+            same = bool(torch.equal(plan.run(wl.stream), ref_out))
+            for _ in range(max(2, args.warmup // 2)):
+                plan.run(wl.stream)
+            torch.cuda.synchronize()
+            t6 = time.perf_counter()
+            for _ in range(args.steps):
+                plan.run(wl.stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t6
+            return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
+                    "bit_identical_to_headline": same,
+                    "note": "same K steps with GF_PTS_ASSUME_DENSE (pts / points_int not re-scanned; range verdicts kept)"}
+
         extra("two_stream", two_stream)
         extra("hip_graph", hip_graph)
+        extra("verified_once", verified_once)
+        extra("gs144000_forward", gs144000_forward)
         def train_step():
             # BASELINE config [2]: the native ops of one training step chained through autograd (tools/bench_step.py)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -501,7 +557,11 @@ def main():
             "metric": headline_metric(),
             "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32",
+            # what the arithmetic of the kernel that ran is (inputs, outputs and accumulators are fp32 in every case)
+            "arithmetic": ("split-f16 operands (hi + lo) on v_mfma_f32_32x32x16_f16, fp32 accumulate; exponent coefficients "
+                           "formed in fp64" if "mfma" in kernel_name else "fp32 VALU"),
+            "data": "synthetic",
             "config": {"workload": f"{args.config}: splat forward of ONE frame, P={P} Gaussians -> {si.H}x{si.W}x{si.D}x18 "
                                    f"grid (N={N} voxel-centre points), bs=1",
                        "P_total": P, "P_per_gpu": P_launch, "N": N, "pts_layout": "auto-detected dense grid",

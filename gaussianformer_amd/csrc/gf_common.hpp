@@ -45,6 +45,7 @@ struct SplatWorkspace {
     int *seg;               // [P][8] backward: (index, volume, box lo[3], box hi[3]) of the Gaussian at each sorted position
     uint32_t *sort_hist;    // [64][ceil(P/256)] + [64] backward: per-(cell, block) counts -> offsets, cell totals
     float *dotlg;           // [N]  prob backward: sum_c dL/dlogits[n][c] * logits[n][c]
+    uint32_t *range_flags;  // [nwords + 4] forward, matrix-core kernel: per 64 Gaussians, 4 = theta range, 8 = opacity * semantics range
     int nwords, nrow, nsx, nsy, nsuper;
     size_t total_bytes;
 };
@@ -73,6 +74,7 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.seg = (int *)(p + off); off += align256((size_t)P * 32);
     ws.sort_hist = (uint32_t *)(p + off); off += align256(((size_t)64 * ((P + 255) / 256) + 64) * 4);
     ws.dotlg = (float *)(p + off); off += align256((size_t)(N > 0 ? N : 0) * 4);
+    ws.range_flags = (uint32_t *)(p + off); off += align256((size_t)(ws.nwords + 4) * 4);
     ws.total_bytes = off;
     return ws;
 }

@@ -53,6 +53,9 @@ struct PrepArgs {
     int P, N, H, W, D, nwords, nrow, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det, lattice;
     uint32_t *tile_counters;  // null, or the eight per-XCD tile counters of the matrix-core render kernel ...
     uint32_t tile_counter_init;  // ... and the value they start from (the workgroups per XCD: those tiles are taken)
+    uint32_t *range_flags;   // null, or [nwords + 4]: per wave of 64 Gaussians, bit 2 = a Gaussian's theta may leave the f16
+                             // range, bit 3 = |opacity * semantics| may (matrix-core render kernel: both change per frame, so
+                             // they are checked in the records pass on EVERY call, GF_PTS_ASSUME_DENSE included)
 };
 
 constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
@@ -143,24 +146,8 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 }
             }
         }
-        // coefficient range (matrix-core render kernel only): its exponent polynomial carries theta in f16 terms, so every
-        // |theta| must stay below 65504.  Bound for all bricks a Gaussian can meet: the brick centre is at most
-        // (radius + 3) voxels from the mean along x / y and (radius + 5) along z, and |theta_0| = 0.72 e^T A e
-        // <= 0.72 trace(A) |e|^2 dominates the linear and quadratic coefficients.  (NaN-safe: a NaN bound is "bad".)
-        bool bad_range = false;
-        if (a.lattice) {
-            for (int g = vb * 64 + lane; g < a.P; g += kVerifyBlocks * 64) {
-                const float c0 = a.cov3D[6 * (size_t)g], c1 = a.cov3D[6 * (size_t)g + 1], c2 = a.cov3D[6 * (size_t)g + 2];
-                const int r0 = a.radii[a.per_axis ? 3 * g : g], r1 = a.radii[a.per_axis ? 3 * g + 1 : g],
-                          r2 = a.radii[a.per_axis ? 3 * g + 2 : g];
-                const double ex = (min(r0, a.H) + 3) * fabs(sx), ey = (min(r1, a.W) + 3) * fabs(sy), ez = (min(r2, a.D) + 5) * fabs(sz);
-                const double bound = 0.7213475204444817 * ((double)fabsf(c0) + fabsf(c1) + fabsf(c2)) * (ex * ex + ey * ey + ez * ez);
-                bad_range |= !(bound < 3.0e4);
-            }
-        }
-        const unsigned long long any = __builtin_amdgcn_ballot_w64(bad), any2 = __builtin_amdgcn_ballot_w64(bad_lattice),
-                                 any3 = __builtin_amdgcn_ballot_w64(bad_range);
-        if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u) | (any3 ? 4u : 0u);
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(bad), any2 = __builtin_amdgcn_ballot_w64(bad_lattice);
+        if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u);
         return;
     }
     if (a.tile_counters && blockIdx.x == 0 && threadIdx.x < 8) a.tile_counters[64 * threadIdx.x] = a.tile_counter_init;
@@ -168,6 +155,46 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     const int g = word * 64 + lane;
     const bool valid = g < a.P;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    // Range verdicts of the matrix-core render kernel (they depend on each frame's covariances, radii, opacities and
+    // semantics, so they run here, in the records pass of every call -- GF_PTS_ASSUME_DENSE skips the point scans, not these):
+    //   bit 2, overflow: the exponent polynomial carries theta in f16 terms, so every |theta| must stay below 65504.  Bound for
+    //     all bricks a Gaussian can meet: the brick centre is at most (radius + 3) voxels from the mean along x / y and
+    //     (radius + 5) along z, and |theta_0| = 0.72 e^T A e <= 0.72 trace(A) |e|^2 dominates the linear and quadratic
+    //     coefficients;
+    //   bit 2, accuracy: the monomials of the exponent are summed in fp32, so a voxel whose weight matters (w >= 1e-4, i.e.
+    //     d^T A d <= 18.4 = 4.3^2 for its offset d from the mean) sees an absolute error of ~ 4e-8 |theta_0| in its exponent
+    //     (measured: 1.7e-5 / 3.1e-5 at |theta_0| <= 650, the nuScenes configs).  With u the voxel's offset from the brick
+    //     centre (|u_i| <= rho = 1.5, 1.5, 3.5 steps), sqrt(e^T A e) <= 4.3 + sqrt(max_u u^T A u) and max_u u^T A u <= Q =
+    //     sum_ij |A_ij| rho_i rho_j: the call stays on the matrix cores while 0.72 (4.3 + sqrt Q)^2 < 1200 (predicted error
+    //     6e-5 of the weight; an isotropic Gaussian on the 0.5 m grid: sigma >= 0.056 m);
+    //   bit 3: S' = opacity * semantics is split into f16 hi + lo by truncation, which saturates at 65504.
+    // (NaN-safe: a NaN bound is "bad".)
+    uint32_t range_bits = 0u;
+    double lsx = 0, lsy = 0, lsz = 0;   // |lattice steps|
+    if (a.range_flags) {
+        const double p0x = a.pts[0], p0y = a.pts[1], p0z = a.pts[2];
+        lsx = a.H > 1 ? fabs((double)a.pts[3 * (size_t)a.W * a.D] - p0x) : 1.0;
+        lsy = a.W > 1 ? fabs((double)a.pts[3 * (size_t)a.D + 1] - p0y) : 1.0;
+        lsz = a.D > 1 ? fabs((double)a.pts[3 + 2] - p0z) : 1.0;
+    }
+    auto range_of = [&](const float *c, const float *sm, float opa, int r0, int r1, int r2) -> uint32_t {
+        const double ex = (min(r0, a.H) + 3) * lsx, ey = (min(r1, a.W) + 3) * lsy, ez = (min(r2, a.D) + 5) * lsz;
+        const double bound = 0.7213475204444817 * ((double)fabsf(c[0]) + fabsf(c[1]) + fabsf(c[2])) * (ex * ex + ey * ey + ez * ez);
+        const double rx = 1.5 * lsx, ry = 1.5 * lsy, rz = 3.5 * lsz;
+        const double Q = fabsf(c[0]) * rx * rx + fabsf(c[1]) * ry * ry + fabsf(c[2]) * rz * rz +
+                         2.0 * (fabsf(c[3]) * rx * ry + fabsf(c[4]) * ry * rz + fabsf(c[5]) * rx * rz);
+        const double sq = 4.3 + sqrt(Q);
+        const double near_bound = 0.7213475204444817 * sq * sq;
+        float smax = 0.f;
+        bool snan = false;
+#pragma unroll
+        for (int j = 0; j < kC; ++j) {
+            const float v = fabsf(opa * sm[j]);
+            snan |= !(v == v);
+            smax = fmaxf(smax, v);
+        }
+        return ((!(bound < 3.0e4) || !(near_bound < 1200.0)) ? 4u : 0u) | ((snan || !(smax < 3.0e4f)) ? 8u : 0u);
+    };
     // Small P (one wave per workgroup): the kernel is a chain of memory round trips, so every input of
     // this lane's Gaussian is requested up front in straight-line code -- the box inputs first, they are
     // waited for first -- from a clamped index instead of under `if (valid)`: a load inside a branch is
@@ -190,6 +217,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             lo[0] = min(a.H, max(0, m0 - r0)); hi[0] = min(a.H, max(0, m0 + r0 + 1));
             lo[1] = min(a.W, max(0, m1 - r1)); hi[1] = min(a.W, max(0, m1 + r1 + 1));
             lo[2] = min(a.D, max(0, m2 - r2)); hi[2] = min(a.D, max(0, m2 + r2 + 1));
+            if (a.range_flags) range_bits = range_of(c_in, sm_in, opa_in, r0, r1, r2);
         }
     } else if (valid) {
         gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
@@ -286,7 +314,11 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 kdet = prob_kdet(c0, c1, c2, c3, c4, c5, a.exact_det);
             }
             float4 *rec = reinterpret_cast<float4 *>(row);
-            rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], a.opacity[g]);
+            const float opa_g = a.opacity[g];
+            rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], opa_g);
+            if (a.range_flags)
+                range_bits = range_of(row + kRecCov, row + kRecSem, opa_g, a.radii[a.per_axis ? 3 * g : g],
+                                      a.radii[a.per_axis ? 3 * g + 1 : g], a.radii[a.per_axis ? 3 * g + 2 : g]);
             if (a.prescale) {
                 // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
                 // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
@@ -307,6 +339,14 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             const float4 *src4 = reinterpret_cast<const float4 *>(R);
             for (int i = lane; i < ng * (kRecDwords / 4); i += 64) dst[i] = src4[i];
         }
+    }
+    if (a.range_flags) {
+        // one word per wave of 64 Gaussians, stored unconditionally (nothing to zero); the last wave also clears the
+        // padding the render kernels' 16-byte reads cover
+        const unsigned long long b2 = __builtin_amdgcn_ballot_w64((range_bits & 4u) != 0u),
+                                 b3 = __builtin_amdgcn_ballot_w64((range_bits & 8u) != 0u);
+        if (lane == 0 && word < a.nwords) a.range_flags[word] = (b2 ? 4u : 0u) | (b3 ? 8u : 0u);
+        if (word == a.nwords - 1 && lane >= 1 && lane <= 3) a.range_flags[a.nwords - 1 + lane] = 0u;
     }
     const unsigned long long mybit = 1ull << lane;
     for (int s0 = 0; s0 < nsuper; s0 += chunk) {
@@ -370,6 +410,8 @@ struct RenderArgs {
     float threshold;
     int raw_numerator;  // prob variant: logits = sum sem * prob, not divided by prob_sum (GF_PROB_NUMERATOR)
     uint32_t *tile_counters;  // matrix-core kernel: next unclaimed tile of XCD x at [64 x] (one cache line each)
+    const uint32_t *range_flags;  // matrix-core kernels: the records pass's range verdicts, nrange4 16-byte pieces (null = none)
+    int nrange4;
 };
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
@@ -1010,13 +1052,24 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nrow;
 
     // verdicts of the prep launch: bit 0 = a point is not in its voxel, bit 1 = pts is not an exact affine lattice,
-    // bit 2 = a Gaussian's coefficients may leave the f16 range -- any of them sends the call to the arbitrary-points body
+    // -- either sends the call to the arbitrary-points body
     int verdict = 0;
     if (a.verify_dense) {
         const uint32_t v = vf.x | vf.y | vf.z | vf.w;
-        verdict = (__syncthreads_or((v & 1u) != 0u) ? 1 : 0) | (__syncthreads_or((v & 6u) != 0u) ? 2 : 0);
+        verdict = (__syncthreads_or((v & 1u) != 0u) ? 1 : 0) | (__syncthreads_or((v & 2u) != 0u) ? 2 : 0);
     }
-    const int nondense = verdict;
+    // ... and of its records pass (every call): bit 2 = a Gaussian's theta, bit 3 = its opacity * semantics may leave the f16 range
+    int range_bits = 0;
+    if (a.range_flags) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.range_flags);
+        uint32_t v = 0u;
+        for (int k = tid; k < a.nrange4; k += kBlock) {
+            const uint4 t4 = rp[k];
+            v |= t4.x | t4.y | t4.z | t4.w;
+        }
+        range_bits = (__syncthreads_or((v & 4u) != 0u) ? 4 : 0) | (__syncthreads_or((v & 8u) != 0u) ? 8 : 0);
+    }
+    const int nondense = verdict | range_bits;
     if (blockIdx.x == 0 && tid == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
         a.state[1] = nondense ? GF_PATH_ARBITRARY : GF_PATH_MATRIX_CORE;
@@ -1024,10 +1077,10 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     if (blockIdx.x == 0 && a.state && a.verify_dense) {
         // the exact verdict bits, for the caller's diagnostics
         const uint32_t v = vf.x | vf.y | vf.z | vf.w;
-        const int b1 = __syncthreads_or((v & 2u) != 0u), b2 = __syncthreads_or((v & 4u) != 0u);
-        if (tid == 0) a.state[2] = (uint32_t)((verdict & 1) | (b1 ? 2 : 0) | (b2 ? 4 : 0));
+        const int b1 = __syncthreads_or((v & 2u) != 0u);
+        if (tid == 0) a.state[2] = (uint32_t)((verdict & 1) | (b1 ? 2 : 0) | range_bits);
     } else if (blockIdx.x == 0 && tid == 0 && a.state) {
-        a.state[2] = 0u;
+        a.state[2] = (uint32_t)range_bits;
     }
     if (nondense) {
         general_body<GF_SPLAT_BASE, kExpComp, LABELS>(a);
@@ -1612,8 +1665,16 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             const uint4 t = vp[k];
             v |= t.x | t.y | t.z | t.w;
         }
-        verdict = (__builtin_amdgcn_ballot_w64((v & 1u) != 0u) ? 1 : 0) | (__builtin_amdgcn_ballot_w64((v & 2u) != 0u) ? 2 : 0) |
-                  (__builtin_amdgcn_ballot_w64((v & 4u) != 0u) ? 4 : 0);
+        verdict = (__builtin_amdgcn_ballot_w64((v & 1u) != 0u) ? 1 : 0) | (__builtin_amdgcn_ballot_w64((v & 2u) != 0u) ? 2 : 0);
+    }
+    if (a.range_flags) {   // the records pass's range verdicts (every call, GF_PTS_ASSUME_DENSE included)
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.range_flags);
+        uint32_t v = 0u;
+        for (int k = lane; k < a.nrange4; k += 64) {
+            const uint4 t4 = rp[k];
+            v |= t4.x | t4.y | t4.z | t4.w;
+        }
+        verdict |= (__builtin_amdgcn_ballot_w64((v & 4u) != 0u) ? 4 : 0) | (__builtin_amdgcn_ballot_w64((v & 8u) != 0u) ? 8 : 0);
     }
     if (blockIdx.x == 0 && lane == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
@@ -2338,6 +2399,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.lattice = (mfma && verify) ? 1 : 0;
     uint32_t *tile_counters = ws.flags + 4608;  // [64 x], x < 8: inside the 32 KB flag section, past the verdicts
     pa.tile_counters = mfma ? tile_counters : nullptr;
+    pa.range_flags = mfma ? ws.range_flags : nullptr;
     pa.tile_counter_init = !mfma ? 0u
                            : mfma_by_wave(ws.nrow) ? (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8)
                                                    : (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8);
@@ -2362,6 +2424,8 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
     ra.tile_counters = tile_counters;
+    ra.range_flags = mfma ? ws.range_flags : nullptr;
+    ra.nrange4 = (ws.nwords + 3) / 4;
     if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);
     else if (variant == GF_SPLAT_BASE)

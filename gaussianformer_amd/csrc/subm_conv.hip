@@ -12,7 +12,8 @@
 //
 // Pipeline (all on the device; the pair count is the only value the host reads, like spconv):
 //   grid     : head[cell] / next[point] linked lists (atomicExch), cells in a dense int table
-//   count    : per offset k, how many (out i, in j) pairs; per (i, k) the count
+//   count    : per offset k, how many (out i, in j) pairs; per (i, k) the count; the lists re-linked in ascending point index
+//              (next2 / first2) so that everything downstream is reproducible bit for bit
 //   scan     : offsets of the K^3 pair segments and of their 32-pair tiles
 //   fill     : pair_in / pair_out arrays grouped by k; slot_first[i][k]
 //   gemm     : per tile of 32 pairs of one k: partial[slot] = feat[pair_in[slot]] . W[k]  (W[k] in LDS)
@@ -30,7 +31,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct SubmTables {
     int *head;              // [cells]  first point of the cell's list, -1 = empty
-    int *next;              // [N]
+    int *next;              // [N]      ... in insertion order (atomicExch: differs from run to run)
+    int *next2;             // [N]      the same lists in ASCENDING point index: successor of a point, -1 = last
+    int *first2;            // [N]      at the index of a cell's head: the smallest point index of the cell (entry of the ascending list)
     int *slot_first;        // [N][K3]  first pair slot of (out point, offset); defined only where cnt > 0 (never cleared)
     unsigned short *cnt;    // [N][K3]  pairs of (out point, offset); a cell with more than 65535 points raises total[1]
     unsigned long long *kcount;  // [K3] pairs per offset (64-bit: crowded cells square their population)
@@ -69,6 +72,8 @@ static SubmTables subm_carve(void *base, int N, long long cells, int K3, size_t 
     SubmTables t;
     t.head = (int *)(p + off); off += subm_align((size_t)cells * 4);
     t.next = (int *)(p + off); off += subm_align((size_t)N * 4);
+    t.next2 = (int *)(p + off); off += subm_align((size_t)N * 4);
+    t.first2 = (int *)(p + off); off += subm_align((size_t)N * 4);
     t.slot_first = (int *)(p + off); off += subm_align((size_t)N * K3 * 4);
     t.cnt = (unsigned short *)(p + off); off += subm_align((size_t)N * K3 * 2);
     t.kcount = (unsigned long long *)(p + off); off += subm_align((size_t)K3 * 8);
@@ -114,9 +119,32 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
     int z = 0;
     if (i < a.N) {
         const int4 c = *reinterpret_cast<const int4 *>(a.indices + 4 * (size_t)i);
-        if (subm_cell(a, c.x, c.y, c.z, c.w) >= 0) {
+        const long long own = subm_cell(a, c.x, c.y, c.z, c.w);
+        if (own >= 0) {
             col = subm_cell(a, c.x, c.y + kxy / a.K - r, c.z + kxy % a.K - r, 0);
             z = c.w;
+        }
+        if (!FILL && kxy == 0) {
+            // The cell lists come out of gf_subm_grid_kernel in insertion order (atomicExch), which differs from run to run;
+            // the fill pass writes a cell's pairs in list order and the reduce kernel sums an output row's partial rows in
+            // slot order, so with two or more points in a cell the fp32 sum of their contributions would change its rounding
+            // between two runs on the same input (observed as labels differing between an eager and a captured frame at
+            // 144 000 points).  The fill pass therefore walks the lists in ASCENDING point index: every point finds its own
+            // successor (the smallest larger index of its cell) and the cell's smallest point announces itself at the head's
+            // slot -- no atomics, O(list length) per point, any list length.
+            if (own < 0) {
+                a.t.next2[i] = -1;
+            } else {
+                const int h = a.t.head[own];
+                int succ = 0x7fffffff;
+                bool smallest = true;
+                for (int j = h; j >= 0; j = a.t.next[j]) {
+                    if (j > i && j < succ) succ = j;
+                    smallest = smallest && j >= i;
+                }
+                a.t.next2[i] = succ == 0x7fffffff ? -1 : succ;
+                if (smallest) a.t.first2[h] = i;
+            }
         }
     }
     // the count pass leaves one byte per (point, column): which of the K cells along z hold points.  The fill
@@ -135,7 +163,8 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
         const int zz = z + kz - r;
         if (kz < a.K && col >= 0 && zz >= 0 && zz < a.Z && (!FILL || ((seen >> kz) & 1u))) {
             first[kz] = a.t.head[col + zz];
-            for (int j = first[kz]; j >= 0; j = a.t.next[j]) ++c[kz];
+            if (FILL && first[kz] >= 0) first[kz] = a.t.first2[first[kz]];   // entry of the ascending list
+            for (int j = first[kz]; j >= 0; j = FILL ? a.t.next2[j] : a.t.next[j]) ++c[kz];
         }
         if (!FILL && c[kz]) seen |= 1u << kz;
         unsigned int v = c[kz];
@@ -174,7 +203,7 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
         for (int w = 0; w < wave; ++w) before += s_w[kz][w];
         unsigned int slot = s_base[kz] + before;
         a.t.slot_first[(size_t)i * a.K3 + kxy * a.K + kz] = (int)slot;
-        for (int j = first[kz]; j >= 0; j = a.t.next[j]) {
+        for (int j = first[kz]; j >= 0; j = a.t.next2[j]) {
             a.pair_in[slot] = j;
             a.pair_out[slot] = i;
             ++slot;

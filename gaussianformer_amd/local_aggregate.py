@@ -70,6 +70,22 @@ def pts_is_exact_lattice(pts, H, W, D):
     return ok
 
 
+def grid_is_exact_lattice(pc_min, grid_size, H, W, D):
+    """Host-only (no device work, no synchronisation): are the fp32 voxel centres of a module's grid --
+    ``arange(n) * grid_size + 0.5 * grid_size + pc_min`` in fp32, the arithmetic of the reference's ``get_meshgrid``
+    (dataset/transform_3d.py:487-499) -- an exact affine lattice ``c[0] + i * (c[1] - c[0])``?  True for the nuScenes
+    grid (multiples of 0.25 m), false e.g. for a 0.4 m cell.  The modules use it to choose the exact-fp32 kernel up front
+    for grids the matrix-core kernel's device verdict would send to the slow arbitrary-points body every frame."""
+    import numpy as np
+    g = np.float32(grid_size)
+    for n, lo in zip((H, W, D), pc_min):
+        c = (np.arange(n, dtype=np.float32) * g + np.float32(0.5) * g + np.float32(lo)).astype(np.float64)
+        step = c[1] - c[0] if n > 1 else 1.0
+        if not np.array_equal(c, c[0] + np.arange(n, dtype=np.float64) * step):
+            return False
+    return True
+
+
 def _contig(t, dtype):
     if t.dtype != dtype:
         t = t.to(dtype)
@@ -427,8 +443,9 @@ class LocalAggregator(_AggregatorBase):
 
     ``matrix_cores`` (extra keyword) selects the forward kernel: ``None`` (default) = the library default, i.e. the
     split-f16 MFMA kernel (``GF_MFMA_SPLAT``: ~2e-5 from the reference, tolerance 1e-4) whenever ``pts`` is the dense
-    grid of exactly representable voxel centres -- checked once per ``pts`` tensor on the host (``pts_is_exact_lattice``)
-    so that a grid that is not (e.g. a 0.4 m cell) goes straight to the exact-fp32 kernel -- ``True`` = request it
+    grid of exactly representable voxel centres -- judged once per module from (pc_min, grid_size, H, W, D) on the host
+    (``grid_is_exact_lattice``: no device work, no synchronisation), so that a grid that is not (e.g. a 0.4 m cell) goes
+    straight to the exact-fp32 kernel; the device verdict still guards every call -- ``True`` = request it
     regardless of that check (the device verdict still guards every call), ``False`` = always the exact-fp32 kernel
     (``GF_EXACT_FP32``: ~2e-6 from the reference).  The backward is the same exact-fp32 kernel in every case."""
 
@@ -445,13 +462,39 @@ class LocalAggregator(_AggregatorBase):
         self.check_inputs = check_inputs
         self._pc_min_host = [float(v) for v in pc_min]
 
+    def register_grid(self, pts):
+        """Optional: verify ONCE that ``pts [1, H*W*D, 3]`` (or ``[H*W*D, 3]``) is the dense grid -- point n in voxel n and an
+        exact affine lattice: one host read -- and remember the tensor (a strong reference, so its address cannot be recycled
+        by another tensor).  Later ``forward`` calls that pass this very tensor, unmodified (same storage address, shape and
+        version counter), then tell the library so (``GF_PTS_ASSUME_DENSE``): the per-call scan of pts / points_int -- 15 MB
+        and ~3.6 us at the nuScenes grid -- is skipped.  The range verdicts, which depend on each frame's Gaussians, still
+        run in every call.  Returns whether the tensor qualified.  Callers that build a new ``pts`` tensor per frame (the
+        reference's dataloader does) simply never hit it and keep the per-call device verdict."""
+        flat = pts.detach().reshape(-1, 3)
+        ok = flat.shape[0] == self.H * self.W * self.D and pts_is_exact_lattice(flat, self.H, self.W, self.D)
+        if ok:
+            pi = ((flat - self.pc_min.to(flat.device)) / self.grid_size).to(torch.int).long()
+            key = (pi[:, 0] * self.W + pi[:, 1]) * self.D + pi[:, 2]
+            ok = bool(((pi[:, 1] >= 0) & (pi[:, 1] < self.W) & (pi[:, 2] >= 0) & (pi[:, 2] < self.D) &
+                       (key == torch.arange(flat.shape[0], device=flat.device))).all().item())
+        self._registered = (pts, pts.data_ptr(), pts._version, flat.shape[0]) if ok else None
+        return ok
+
+    def _is_registered(self, pts):
+        reg = getattr(self, "_registered", None)
+        return (reg is not None and pts.data_ptr() == reg[1] and pts._version == reg[2] and reg[0]._version == reg[2]
+                and pts.shape[0] == reg[3] and pts.is_contiguous())
+
     def _splat(self, pts, *args, H=None):
         H = self.H if H is None else H
+        pts_flag = _lib.GF_PTS_ASSUME_DENSE if (H == self.H and self._is_registered(pts)) else _lib.GF_PTS_AUTO
         if self.matrix_cores is None:
-            exact = pts.shape[0] == H * self.W * self.D and not pts_is_exact_lattice(pts, H, self.W, self.D)
-            flags = _lib.GF_PTS_AUTO | (_lib.GF_EXACT_FP32 if exact else 0)
+            # the grid of this module, judged on the host once (no device work): not an exact lattice -> exact-fp32 kernel
+            if self._grid_exact is None:
+                self._grid_exact = grid_is_exact_lattice(self._pc_min_host, self.grid_size, self.H, self.W, self.D)
+            flags = pts_flag | (0 if self._grid_exact else _lib.GF_EXACT_FP32)
         else:
-            flags = _lib.GF_PTS_AUTO | (_lib.GF_MFMA_SPLAT if self.matrix_cores else _lib.GF_EXACT_FP32)
+            flags = pts_flag | (_lib.GF_MFMA_SPLAT if self.matrix_cores else _lib.GF_EXACT_FP32)
         return _LocalAggregate.apply(pts, *args, H, self.W, self.D, flags)
 
     def _radii(self, scales):

@@ -48,6 +48,19 @@ def slab_bounds(H, rank, world_size, align=8):
     return min(lo * align, H), min(hi * align, H)
 
 
+def _own_slab(H, group):
+    """``(rank, world, x0, x1)`` of the calling rank.  The bounds of EVERY rank are evaluated on every rank and an empty
+    slab anywhere raises everywhere: a rank that raised alone would leave the others waiting in the all-gather."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bounds = [slab_bounds(H, r, world) for r in range(world)]
+    empty = [r for r, (a, b) in enumerate(bounds) if b <= a]
+    if empty:
+        raise ValueError(f"ranks {empty} of {world} own no rows of an {H}-row grid (8-row blocks): use at most "
+                         f"{(H + 7) // 8} ranks")
+    return rank, world, bounds[rank][0], bounds[rank][1]
+
+
 def slab_splat_forward(aggregator, pts, means3D, opacities, semantics, scales, cov3D, group=None, gather=True):
     """SPATIAL partition of one frame's splat over the ranks (SURVEY.md §8e "slab partition with halo Gaussians"): rank r
     renders the voxel rows ``slab_bounds(H, r, world)`` with ``aggregator.forward_slab`` -- every Gaussian is passed,
@@ -57,12 +70,11 @@ def slab_splat_forward(aggregator, pts, means3D, opacities, semantics, scales, c
     exchange is each rank's own slab (46 MB / world of fp32 logits) instead of a 46 MB all-reduce -- or, through
     ``slab_splat_labels``, 8 bytes per voxel of labels.  Works for the prob aggregators too (their ratio and product
     never cross a slab).  ``aggregator`` is a ``LocalAggregator*`` built for the FULL grid; ``gather=False`` returns the
-    rank's own slab ``(x0, x1, outputs)``.  Returns what ``aggregator.forward`` returns, for the full grid."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    x0, x1 = slab_bounds(aggregator.H, rank, world)
-    if x1 <= x0:
-        raise ValueError(f"rank {rank} of {world} owns no rows of an {aggregator.H}-row grid (8-row blocks): use fewer ranks")
+    rank's own slab ``(x0, x1, outputs)``, which is differentiable like ``aggregator.forward`` (training: a per-voxel
+    loss is a sum over slabs, only the Gaussians' gradients -- 112 B each -- need an all-reduce).  With ``gather=True`` it
+    returns the VALUES ``aggregator.forward`` returns for the full grid: the all-gather is inference-only, its result
+    carries no autograd history (asserted: gathered outputs never require grad)."""
+    rank, world, x0, x1 = _own_slab(aggregator.H, group)
     out = aggregator.forward_slab(x0, x1, pts, means3D, opacities, semantics, scales, cov3D)
     if not gather:
         return x0, x1, out
@@ -72,7 +84,10 @@ def slab_splat_forward(aggregator, pts, means3D, opacities, semantics, scales, c
 
 
 def _gather_slabs(out, aggregator, world, group):
-    """All-gather of per-rank slabs of unequal height: padded to the tallest slab, trimmed on arrival."""
+    """All-gather of per-rank slabs of unequal height: padded to the tallest slab, trimmed on arrival.  Values only:
+    the inputs are detached (a collective has no backward here), so nothing downstream can silently drop a gradient
+    it believes it has -- differentiate the per-rank slab (``gather=False``) instead."""
+    out = out.detach() if not isinstance(out, (tuple, list)) else tuple(t.detach() for t in out)
     H, plane = aggregator.H, aggregator.W * aggregator.D
     bounds = [slab_bounds(H, r, world) for r in range(world)]
     tallest = max(b - a for a, b in bounds) * plane
@@ -96,9 +111,7 @@ def _gather_slabs(out, aggregator, world, group):
 def slab_splat_labels(aggregator, labels_fn, pts, means3D, opacities, semantics, scales, cov3D, group=None):
     """Slab-partitioned inference that ends in labels: every rank labels its own slab (``labels_fn(outputs) -> int64 [n]``,
     e.g. ``head.occupancy_labels``) and only the labels are all-gathered (5 MB for the 640 000 voxels)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    x0, x1 = slab_bounds(aggregator.H, rank, world)
+    rank, world, x0, x1 = _own_slab(aggregator.H, group)
     out = aggregator.forward_slab(x0, x1, pts, means3D, opacities, semantics, scales, cov3D)
     labels = labels_fn(out)
     if world == 1:

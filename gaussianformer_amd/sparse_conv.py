@@ -87,19 +87,22 @@ class Rulebook:
         """Reads the device status (synchronises): returns the pair count, raises if the point set was refused."""
         total, refused = self._status.tolist()
         self.checked = True
+        self.pair_count = int(total)
         if refused:
             self._raise(total, refused)
         return total
 
     def poll(self):
         """Non-blocking :meth:`check` of a ``pair_capacity`` rulebook: ``None`` while the status copy is still in
-        flight, else the pair count -- raising like :meth:`check` if the point set was refused."""
+        flight, else the pair count (the device's count, the same number :meth:`check` returns -- not the capacity the
+        arrays were sized with) -- raising like :meth:`check` if the point set was refused."""
         if self.checked:
-            return self.total
+            return self.pair_count
         if self._status_event is None or not self._status_event.query():
             return None
         total, refused = self._host_status.tolist()
         self.checked = True
+        self.pair_count = int(total)
         if refused:
             self._raise(total, refused)
         return total

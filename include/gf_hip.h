@@ -62,11 +62,12 @@ extern "C" {
  * §3.2b; measured 1.7e-5 / 3.1e-5 from the reference's own kernels at gs25600 / gs144000, tolerance 1e-4).  This is
  * the DEFAULT whenever it applies: base variant, N == H*W*D without GF_PTS_GENERAL, no label epilogue, none of the
  * three exp-flavour flags and no GF_EXACT_FP32.  It needs pts to be an exact affine lattice of voxel centres and
- * quadratic-form coefficients inside the f16 range (|theta| < 3e4 by a per-Gaussian bound); with GF_PTS_AUTO both
- * are verified on the device in the same launches and a call that fails either runs the arbitrary-points body
- * instead (correct, ~7x slower; reported in the state block, see gf_splat_state_bytes) -- so callers whose voxel
- * centres are not exactly representable (e.g. a 0.4 m cell) should pass GF_EXACT_FP32.  With GF_PTS_ASSUME_DENSE
- * the caller asserts both conditions.  GF_MFMA_SPLAT requests this kernel explicitly (it overrides an exp-flavour
+ * operands inside the f16 range (|theta| < 3e4 by a per-Gaussian bound, |opacity * semantics| < 3e4).  The lattice is
+ * verified on the device with GF_PTS_AUTO and asserted by the caller with GF_PTS_ASSUME_DENSE (a static property of the
+ * grid); the two range conditions depend on each frame's Gaussians and are verified in the records pass of EVERY call,
+ * whatever the pts flag.  A call that fails any verdict runs the arbitrary-points body instead (correct, ~7x slower;
+ * reported in the state block, see gf_splat_state_bytes) -- so callers whose voxel centres are not exactly
+ * representable (e.g. a 0.4 m cell) should pass GF_EXACT_FP32.  GF_MFMA_SPLAT requests this kernel explicitly (it overrides an exp-flavour
  * flag); the prob variant, the label epilogue and arbitrary points ignore it. */
 #define GF_MFMA_SPLAT 128
 /* Forward on the exact-fp32 VALU tile kernel (2.3e-6 / 1.0e-6 from the reference; ascending-Gaussian summation order,
@@ -92,7 +93,8 @@ size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D);
  *   [1] GF_PATH_* -- the body that rendered the forward (a GF_PATH_ARBITRARY on an N == H*W*D call is the slow
  *       fall-back of a failed verdict: visible to the caller after its next synchronisation)
  *   [2] verdict bits of the device-side checks: 1 = a point is not in its voxel, 2 = pts is not an exact affine
- *       lattice, 4 = a Gaussian's quadratic-form coefficients may leave the f16 range (matrix-core kernel only) */
+ *       lattice, 4 = a Gaussian's quadratic-form coefficients may leave the f16 range, 8 = a Gaussian's
+ *       |opacity * semantics| may (4 and 8: matrix-core kernel only, checked on every call) */
 size_t gf_splat_state_bytes(void);
 
 /*

@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -230,3 +231,25 @@ def test_two_rank_slab_partition_is_bit_identical_to_single_rank():
     si, args = _slab_inputs("nuscenes_gs25600_solid")
     single = _OracleAggregator(si).forward(*args).numpy()
     assert all(np.array_equal(results[r][0][0], single) for r in range(3))
+
+
+def test_slab_entry_points_refuse_an_empty_slab_on_every_rank(monkeypatch):
+    """with more ranks than 8-row blocks (H = 16, world = 4) ranks 2 and 3 own nothing.  Every rank must raise
+    -- a rank that raised alone would leave the others waiting in the all-gather -- from both entry points."""
+    import torch.distributed as dist
+    from gaussianformer_amd import sharded
+
+    class _Agg:
+        H, W, D = 16, 8, 8
+
+        def forward_slab(self, *a):
+            raise AssertionError("must not be reached")
+
+    for rank in range(4):
+        monkeypatch.setattr(dist, "is_initialized", lambda: True)
+        monkeypatch.setattr(dist, "get_world_size", lambda group=None: 4)
+        monkeypatch.setattr(dist, "get_rank", lambda group=None, r=rank: r)
+        for call in (lambda: sharded.slab_splat_forward(_Agg(), *[None] * 6),
+                     lambda: sharded.slab_splat_labels(_Agg(), lambda o: o, *[None] * 6)):
+            with pytest.raises(ValueError, match="own no rows"):
+                call()
