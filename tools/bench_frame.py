@@ -116,13 +116,18 @@ class Refine(nn.Module):
     """Stand-in for SparseGaussian3DRefinementModule (refine_module.py:64-125): MLP on feature + embedding, residual
     update of the anchor, decoded Gaussian properties."""
 
-    def __init__(self, anchor_dim, scale_range):
+    def __init__(self, anchor_dim, scale_range, sem_dim):
         super().__init__()
         self.layers = nn.Sequential(nn.Linear(EMBED, EMBED), nn.ReLU(True), nn.LayerNorm(EMBED),
                                     nn.Linear(EMBED, EMBED), nn.ReLU(True), nn.LayerNorm(EMBED), nn.Linear(EMBED, anchor_dim))
         self.scale_range = scale_range
         with torch.no_grad():
             self.layers[-1].weight.mul_(0.05)
+            # semantic columns: full-size weights and a positive bias, so that with random weights the occupied classes win
+            # against the empty Gaussian's scalar (10.0) where Gaussians are dense and different classes win in different
+            # voxels -- the eager-vs-graph label comparison below is then a comparison of many labels, not of one
+            self.layers[-1].weight[anchor_dim - sem_dim:].mul_(20.0 * 4.0)
+            self.layers[-1].bias[anchor_dim - sem_dim:].add_(2.5)
 
     def forward(self, feat, anchor, anchor_embed):
         out = self.layers(feat + anchor_embed)
@@ -144,7 +149,7 @@ class Frame(nn.Module):
         layers = []
         for op in order:
             layers.append({"deformable": lambda: Deformable(c["scale_range"], 2), "ffn": FFN, "norm": lambda: nn.LayerNorm(EMBED),
-                           "refine": lambda: Refine(self.anchor_dim, c["scale_range"]),
+                           "refine": lambda: Refine(self.anchor_dim, c["scale_range"], c["sem_dim"]),
                            "spconv": lambda: SparseConv3D(EMBED, EMBED, PC_RANGE, [0.5, 0.5, 0.5], use_out_proj=True,
                                                           pairs_per_point=64)}[op]())   # no host read per rulebook
         self.layers = nn.ModuleList(layers)
@@ -232,10 +237,13 @@ def run(config="nuscenes_gs25600_solid", frames=10, warmup=3, device="cuda:0", g
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / frames
     model.check()
+    again = model(anchor, feat, maps, pm, wh, pts)     # the frame is reproducible bit for bit: same input, same labels
+    torch.cuda.synchronize(dev)
     hist = torch.bincount(labels, minlength=18).tolist()
     out = {"config": config, "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "frames": frames, "anchors": A,
            "sample_points_per_block": A * (len(FIX_SCALE) + 2), "voxels": int(labels.numel()),
-           "labels_used": int(sum(1 for h in hist if h)),
+           "labels_used": int(sum(1 for h in hist if h)), "label_histogram": hist,
+           "eager_labels_equal_eager": bool(torch.equal(again, labels)),
            "scope": "inference frame: feature_maps_format once, 4 encoder blocks (spconv / deformable / ffn / norm / refine in the "
                     "reference's order), fused Gaussian pre-processing, splat, occupancy labels; image backbone excluded; "
                     "FFN / LayerNorm / refine / anchor encoder / weights_fc (applied to the anchor and camera parts separately) are torch stand-ins with random weights"}
