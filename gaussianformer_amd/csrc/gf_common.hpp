@@ -14,10 +14,14 @@ constexpr int kSuper = 8;            // a supertile is 8x8 voxel columns (the bi
 constexpr int kTileX = 8, kTileY = 4;  // a tile (one workgroup) is 8x4 voxel columns x all z; a brick is 4x4x4
 constexpr int kTilesPerSuper = (kSuper / kTileX) * (kSuper / kTileY);
 constexpr int kRecDwords = 32;       // packed per-Gaussian record, 128 B
+constexpr int kWRow = 618;           // bitmask row words (P <= 39 552) the wave-autonomous matrix-core kernels (forward and backward) hold in LDS
+constexpr int kBwdRowDwords = 32;    // matrix-core backward: one 128-B row of partial gradients per (Gaussian, double brick)
+constexpr int kBwdBigRows = 512;     // ... a Gaussian with more rows than this is summed by whole workgroups (big list)
+constexpr int kBwdBigCap = 1024;     // ... entries of that list
 
 // record layout (dwords)
 //  0..2 mean xyz | 3 opacity | 4..9 cov (xx,yy,zz,xy,yz,xz) | 10 box lo | 11 box hi (excl.)
-//  12..29 semantics[18] | 30 prob: (2pi)^-1.5 * sqrt(det) | 31 unused
+//  12..29 semantics[18] | 30 prob: (2pi)^-1.5 * sqrt(det) | 31 matrix-core backward: first row of the Gaussian's partial-gradient rows (uint32; forward: 0)
 constexpr int kRecMean = 0, kRecOpa = 3, kRecCov = 4, kRecLo = 10, kRecHi = 11, kRecSem = 12,
               kRecKdet = 30;
 
@@ -46,6 +50,10 @@ struct SplatWorkspace {
     uint32_t *sort_hist;    // [64][ceil(P/256)] + [64] backward: per-(cell, block) counts -> offsets, cell totals
     float *dotlg;           // [N]  prob backward: sum_c dL/dlogits[n][c] * logits[n][c]
     uint32_t *range_flags;  // [nwords + 4] forward, matrix-core kernel: per 64 Gaussians, 4 = theta range, 8 = opacity * semantics range
+    uint32_t *bwd_alloc;    // [64]  matrix-core backward: [0] row cursor, [1] big-list length, [2] Gaussians without rows (atomics instead)
+    int *bwd_big;           // [kBwdBigCap] matrix-core backward: Gaussians with more than kBwdBigRows rows
+    float *bwd_rows;        // [bwd_cap][32] matrix-core backward: partial gradients per (Gaussian, double brick)
+    uint32_t bwd_cap;       // rows available (0: the shape does not take the matrix-core backward)
     int nwords, nrow, nsx, nsy, nsuper;
     size_t total_bytes;
 };
@@ -75,6 +83,17 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.sort_hist = (uint32_t *)(p + off); off += align256(((size_t)64 * ((P + 255) / 256) + 64) * 4);
     ws.dotlg = (float *)(p + off); off += align256((size_t)(N > 0 ? N : 0) * 4);
     ws.range_flags = (uint32_t *)(p + off); off += align256((size_t)(ws.nwords + 4) * 4);
+    // matrix-core backward (rows of <= kWRow bitmask words): a Gaussian whose box meets k double bricks (4 x 4 x 8 voxels)
+    // owns k rows; 16 per Gaussian on average plus two whole-grid Gaussians are provided for (the nuScenes configs need
+    // ~13.5), what does not fit is accumulated with atomics instead
+    {
+        const long long nunits = (long long)ws.nsuper * 4 * ((D + 7) / 8);
+        const long long cap = ws.nrow <= kWRow ? 16ll * P + 2 * nunits + 1024 : 0;
+        ws.bwd_cap = (uint32_t)(cap < (1ll << 31) ? cap : (1ll << 31) - 1);
+    }
+    ws.bwd_alloc = (uint32_t *)(p + off); off += 256;
+    ws.bwd_big = (int *)(p + off); off += align256((size_t)kBwdBigCap * 4);
+    ws.bwd_rows = (float *)(p + off); off += align256((size_t)ws.bwd_cap * kBwdRowDwords * 4);
     ws.total_bytes = off;
     return ws;
 }
@@ -106,6 +125,23 @@ __device__ __forceinline__ void prob_det_kdet(float c0, float c1, float c2, floa
         kdet = powf(2 * 3.1415926535, -1.5) * powf(deter, 0.5);
     }
 }
+
+// ---- shared between splat_fwd.hip and splat_bwd_mfma.hip ----
+// The records pass of the forward (gf_splat_prep_kernel: records, packed boxes, supertile bitmask) run for the matrix-core
+// backward: no point scans, no range verdicts, natural-log covariance; additionally every Gaussian is given its rows of
+// the partial-gradient buffer (record dword 31; splat_bwd_mfma.hip).  Launches one kernel on `stream`.
+void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, int D, const float *pts, const int *points_int,
+                              const float *means3D, const int *means3D_int, const float *opacity, const float *semantics,
+                              const int *radii, const float *cov3D, const SplatWorkspace &ws, hipStream_t stream);
+
+// The matrix-core backward of the base variant (splat_bwd_mfma.hip): zero -> records pass -> gradient kernel -> row sums.
+// gate: 0 = unconditional; 1 = stands down unless the forward's state block says a matrix-core body rendered the call;
+// 2 = writes NaN gradients in that case.
+void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, int D, const float *pts, const int *points_int,
+                                const float *means3D, const int *means3D_int, const float *opacity, const float *semantics,
+                                const int *radii, const float *cov3D, const float *out_grad, float *means_grad,
+                                float *opa_grad, float *sem_grad, float *cov_grad, const uint32_t *state,
+                                const SplatWorkspace &ws, int gate, hipStream_t stream);
 
 // ---- error reporting ----------------------------------------------------------------
 void set_error(const char *fmt, ...);

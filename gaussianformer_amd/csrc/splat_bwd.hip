@@ -20,6 +20,8 @@
 //                        waves -- e.g. the whole-grid Gaussian -- are order-dependent).
 //
 // Launches: [voxel->point map (arbitrary pts only)] -> volumes -> gradient kernel.
+#include <stdlib.h>
+
 #include "gf_common.hpp"
 
 namespace gf {
@@ -56,7 +58,16 @@ struct BwdArgs {
     uint32_t *sort_hist;  // [kSortCells][nblk]
     float *dotlg;         // prob only, [N]: sum_c out_grad[n][c] * logits[n][c]
     int P, N, H, W, D, per_axis, force_general, assume_dense, nblk, exact_det;
+    int gate;   // 1: every kernel of this (Gaussian-major) pipeline stands down when the forward's state block says a matrix-core
+                // body rendered the call -- the matrix-core backward (splat_bwd_mfma.hip), launched beside it, takes the call then
 };
+
+__device__ __forceinline__ bool gated_off(const BwdArgs &a)
+{
+    if (!a.gate || a.state == nullptr) return false;
+    const uint32_t w = a.state[1];
+    return a.state[0] == 0u && (w == (uint32_t)GF_PATH_MATRIX_CORE || w == (uint32_t)GF_PATH_MATRIX_CORE_WAVE);
+}
 
 constexpr int kBwdMaxBlk = 1024;  // LDS prefix capacity: P <= 262 144 Gaussians
 
@@ -161,6 +172,7 @@ __device__ __forceinline__ int sort_cell(const BwdArgs &a, int g)
 // One thread per Gaussian: box volume, per-(cell, block) histogram, zeroed outputs.
 __global__ __launch_bounds__(256) void gf_bwd_vol_kernel(BwdArgs a)
 {
+    if (gated_off(a)) return;
     __shared__ uint32_t s_hist[kSortCells];
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (threadIdx.x < kSortCells) s_hist[threadIdx.x] = 0u;
@@ -190,6 +202,7 @@ __global__ __launch_bounds__(256) void gf_bwd_vol_kernel(BwdArgs a)
 // kSortCells.. carry the voxel2pts scatter (independent work, one launch less).
 __global__ __launch_bounds__(256) void gf_bwd_sort_scan_kernel(BwdArgs a)
 {
+    if (gated_off(a)) return;
     if (blockIdx.x >= kSortCells) {
         if (pts_are_dense(a)) return;
         const long long nb = gridDim.x - kSortCells;
@@ -229,6 +242,7 @@ __global__ __launch_bounds__(256) void gf_bwd_sort_scan_kernel(BwdArgs a)
 // id); per-(wave, cell) counts in LDS give the offset of the wave inside the block.
 __global__ __launch_bounds__(256) void gf_bwd_sort_scatter_kernel(BwdArgs a)
 {
+    if (gated_off(a)) return;
     __shared__ uint32_t s_wc[4][kSortCells];
     __shared__ uint32_t s_base[kSortCells];
     const int g = blockIdx.x * 256 + threadIdx.x, wave = threadIdx.x >> 6;
@@ -268,6 +282,7 @@ __global__ __launch_bounds__(256) void gf_bwd_sort_scatter_kernel(BwdArgs a)
 // here, so the gradient kernel gathers ONE 72-byte row per pair instead of two.
 __global__ __launch_bounds__(256) void gf_bwd_dot_kernel(BwdArgs a)
 {
+    if (gated_off(a)) return;
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
     if (n >= a.N) return;
     const float2 *g = reinterpret_cast<const float2 *>(a.out_grad + (size_t)n * kC);
@@ -285,6 +300,7 @@ __global__ __launch_bounds__(256) void gf_bwd_dot_kernel(BwdArgs a)
 // Sums of 256 consecutive sorted volumes (the coarse level of the range search).
 __global__ __launch_bounds__(256) void gf_bwd_bsum_kernel(BwdArgs a)
 {
+    if (gated_off(a)) return;
     __shared__ uint32_t s_w[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t sum = i < a.P ? a.vols[i] : 0u;
@@ -350,6 +366,7 @@ __device__ __forceinline__ int reduce_slot(int lane)
 template <int VARIANT>
 __global__ __launch_bounds__(256, VARIANT == GF_SPLAT_BASE ? 4 : 3) void gf_splat_bwd_kernel(BwdArgs a)
 {
+    if (gated_off(a)) return;
     __shared__ unsigned long long s_pref[kBwdMaxBlk + 1];  // exclusive prefix of the block sums
     __shared__ __attribute__((aligned(16))) float s_rows_all[4 * 64 * kC];
     __shared__ int s_pidx_all[4 * 64];
@@ -701,6 +718,25 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     a.force_general = ((long long)N != V || (flags & GF_PTS_GENERAL)) ? 1 : 0;
     a.assume_dense = (!a.force_general && (flags & GF_PTS_ASSUME_DENSE)) ? 1 : 0;
     a.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
+    a.gate = 0;
+
+    // The matrix-core backward (splat_bwd_mfma.hip) takes the calls the forward's matrix-core kernels rendered -- word 1 of
+    // the state block, which only the device knows.  Default: BOTH pipelines are launched, each gated on that word (the
+    // one that stands down costs its empty launches).  GF_EXACT_FP32: the Gaussian-major kernels only (exact fp32, the path of
+    // every other case).  GF_MFMA_SPLAT: the caller has seen the state block (e.g. an asynchronous copy of it) and asserts the
+    // matrix-core path; a state block that says otherwise yields NaN gradients, not wrong ones.
+    const bool mfma_eligible = variant == GF_SPLAT_BASE && !a.force_general && state != nullptr && ws.bwd_cap > 0 &&
+                               !(flags & GF_EXACT_FP32) && getenv("GF_BWD_EXACT") == nullptr;
+    if (mfma_eligible) {
+        const int gate = (flags & GF_MFMA_SPLAT) ? 2 : 1;
+        launch_splat_backward_mfma(a.per_axis, P, N, H, W, D, pts, points_int, means3D, means3D_int, opacity, semantics, radii, cov3D,
+                                   logits_grad, means3D_grad, opacity_grad, semantics_grad, cov3D_grad, a.state, ws, gate, stream);
+        if (gate == 2) {
+            GF_CHECK_LAUNCH();
+            return GF_OK;
+        }
+        a.gate = 1;
+    }
 
     const int v2p_blocks = a.assume_dense || N == 0 ? 0 : 2048;
     hipLaunchKernelGGL(gf_bwd_vol_kernel, dim3(a.nblk), dim3(256), 0, stream, a);

@@ -1,0 +1,918 @@
+// splat_bwd_mfma.hip -- Gaussian -> voxel splat, backward of the base variant on the matrix cores, for gfx950 (MI355X).
+//
+// The reference (model/head/localagg/src/backward.cu:62-102) walks every Gaussian's box voxel by voxel; the Gaussian-major
+// kernel of splat_bwd.hip does the same walk in parallel and gathers one 72-byte dL/dlogits row per (Gaussian, voxel) pair
+// -- 12.6 M pairs = 0.9 GB of L2 gather for 46 MB of distinct rows.  This file turns the walk round: VOXEL-major, on the
+// forward's work decomposition (gf_splat_render_mfma_wave_kernel, splat_fwd.hip): one wave per double brick (4 x 4 x 8
+// voxels = four blocks of 32), which loads its 128 gradient rows ONCE, finds the Gaussians that touch it from the supertile
+// bitmask and takes them in groups of 32.  Per group and block (32 Gaussians x 32 voxels), with
+//     e[v,g] = exp(-1/2 d^T Sigma^-1 d),  d = mean_g - p_v        T[v,g] = sum_c dL[v,c] sem[g,c]
+// the gradient of backward.cu:72-87 is a set of contractions over voxels
+//     dopa[g]   = sum_v e T                      dsem[g,c] = opa sum_v e[v,g] dL[v,c]
+//     dcov[g]   = opa sum_v e T (-1/2 dx^2, ..)  dmean[g]  = -opa Sigma^-1 sum_v e T d
+// and everything that depends on a voxel only through monomials of its offset u from the brick centre is a moment
+//     M_m[g] = sum_v phi_m(u_v) (e T)[v,g],   phi = (1, ux, uy, uz, ux^2, uy^2, uz^2, ux uy, uy uz, ux uz)
+// (d = -(C - mean + s u) with C the brick centre and s the lattice steps: ten moments give the nine mean / covariance sums).
+// On the matrix cores:
+//   1. exponent   D'[v,g] = phi(u_v) . theta(g) + box term -- the forward's four v_mfma_f32_32x32x16_f16 with the operands
+//                 SWAPPED (A = monomials / one-hot coordinates of the voxels, B = split theta of the Gaussians), so that the
+//                 result has lane = Gaussian, register = voxel: the B-operand layout of a contraction over voxels;
+//   2. T'[v,g]    nine v_mfma_f32_32x32x2_f32 (exact fp32): A = dL[v][c] straight from the staged rows, B = sem[g][c];
+//   3. e = exp2(D'), K = e T'; both split into f16 hi + lo in registers (they ARE B operands already);
+//   4. moments    M += Phi^T (K_hi + K_lo): 4 MFMAs;   dsem  += dL^T (e_hi + e_lo), dL split hi + lo: 6 MFMAs.
+// Per Gaussian and double brick the 28 sums leave as ONE 128-byte row of a partial buffer (rows handed out by the records
+// pass, gf_splat_prep_kernel) and gf_splat_bwd_rows_kernel adds a Gaussian's rows up in a fixed order: no float atomics
+// (Gaussians with more than 512 rows -- the whole-grid "empty" Gaussian -- are summed by whole workgroups and combined
+// with atomics; Gaussians the buffer has no room for fall back to atomics).
+//
+// Ranges.  dL is scaled per double brick and the semantics per Gaussian by powers of two (exact) so that the f16 operands
+// stay in range whatever the loss scale is; undone in fp64 when the row is written.
+//
+// The kernel applies where the forward's matrix-core kernel does (dense exact lattice, theta in range: word 1 of the
+// forward's state block says a matrix-core body rendered the call) and to rows of <= kWRow bitmask words.
+#include "gf_common.hpp"
+
+#ifndef GF_TIMELINE
+#define GF_TIMELINE 0  // -DGF_TIMELINE=1: per-unit timestamps of the gradient kernel (tools/timeline_bwd.py)
+#endif
+
+namespace gf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+union H8 {
+    h8 v;
+    fp16x2 p[4];
+    _Float16 e[8];
+};
+
+struct BwdMArgs {
+    const float *pts;            // lattice: pts[0] and the three axis steps
+    const float *records;        // [P][32]   (gf_splat_prep_kernel; natural-log covariance, dword 31 = first row)
+    const uint2 *boxes;          // [P]
+    const unsigned long long *bitmask;
+    const float *out_grad;       // [N,18]
+    float *rows;                 // [cap][32]
+    float *means_grad, *opa_grad, *sem_grad, *cov_grad;
+    const uint32_t *state;       // the forward's state block
+    uint32_t *tile_counters;     // [64 x]: next unclaimed unit of XCD x
+    const uint32_t *alloc;       // [0] rows handed out, [1] big-list length
+    const int *big;              // big list
+    int P, N, nwords, nrow, H, W, D, nsx, nsy;
+    int gate;                    // 1: run only if the forward's state says "matrix cores"; 2: write NaN gradients otherwise
+    unsigned long long *timeline;  // debug (GF_TIMELINE builds): 8 stamps per unit
+};
+
+constexpr int kMList = 256;      // candidate list entries (ids, packed box lo, packed box hi) in LDS
+constexpr int kMQCap = 128;      // hit queue (ring)
+constexpr int kMPitch = 132;     // floats per channel row of the staged dL: [18][132], column = block * 32 + voxel in block
+// LDS map (dwords): [0, 1536) record slot (six 1 KB pieces per group) | [1536, 2304) list | [2304, 4680) dL | [4680, 4808) queue.
+// The unit's bitmask row lands at [768, 768 + 2 kWRow): the upper half of the slot and most of the list, both idle until the
+// row has been read into registers; the dense-word compaction borrows [0, 768).
+constexpr int kMLdsDwords = 1536 + 3 * kMList + kC * kMPitch + kMQCap;
+constexpr int kMRowAt = 768;
+static_assert(kMRowAt + 2 * kWRow <= 1536 + 3 * kMList, "the bitmask row fits over the slot's upper half and the list");
+static_assert(3 * kMList <= kMRowAt, "the dense-word compaction borrows the lower half of the record slot");
+static_assert(kMLdsDwords * 4 <= 20480, "eight single-wave workgroups per CU");
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+    return v;
+}
+
+// three f16 terms of an fp64 value (see splat_fwd.hip)
+__device__ __forceinline__ void split3(double t, _Float16 &a, _Float16 &b, _Float16 &c)
+{
+    float hi = (float)t;
+    asm volatile("" : "+v"(hi));
+    const float lo = (float)(t - (double)hi);
+    a = (_Float16)hi;
+    float r = (hi - (float)a) + lo;
+    asm volatile("" : "+v"(r));
+    b = (_Float16)r;
+    c = (_Float16)(r - (float)b);
+}
+
+// f16 hi + lo of sixteen fp32 values held as an MFMA D fragment: the two K chunks (registers 0..7, 8..15) of a B operand
+__device__ __forceinline__ void split16(const f32x16 &d, H8 (&hi)[2], H8 (&lo)[2])
+{
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+        const float w0 = d[q], w1 = d[q + 1];
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(w0, w1);
+        float q0, q1;  // exact residuals, the f16 halves read in place
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(h), "v"(w0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(h), "v"(w1));
+        hi[q >> 3].p[(q & 7) >> 1] = h;
+        lo[q >> 3].p[(q & 7) >> 1] = __builtin_amdgcn_cvt_pkrtz(q0, q1);
+    }
+}
+
+__device__ __forceinline__ bool state_is_matrix_core(const uint32_t *state)
+{
+    const uint32_t w = state[1];
+    return state[0] == 0u && (w == (uint32_t)GF_PATH_MATRIX_CORE || w == (uint32_t)GF_PATH_MATRIX_CORE_WAVE);
+}
+
+// ---------------------------------------------------------------------------------------
+// zeroes the four gradient outputs and the row allocator (one launch ahead of the records pass)
+struct BwdZeroArgs {
+    float *means_grad, *opa_grad, *sem_grad, *cov_grad;
+    uint32_t *alloc;
+    const uint32_t *state;
+    int P, gate;
+};
+
+__global__ __launch_bounds__(256) void gf_splat_bwd_zero_kernel(BwdZeroArgs a)
+{
+    if (blockIdx.x == 0 && threadIdx.x < 64) a.alloc[threadIdx.x] = 0u;
+    if (a.gate == 1 && !state_is_matrix_core(a.state)) return;
+    const float fill = (a.gate == 2 && !state_is_matrix_core(a.state)) ? __uint_as_float(0x7fc00000u) : 0.f;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.P) {
+        a.opa_grad[i] = fill;
+        a.means_grad[3 * (size_t)i] = fill; a.means_grad[3 * (size_t)i + 1] = fill; a.means_grad[3 * (size_t)i + 2] = fill;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.cov_grad[6 * (size_t)i + k] = fill;
+#pragma unroll
+        for (int k = 0; k < kC; ++k) a.sem_grad[(size_t)kC * i + k] = fill;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_u[kMLdsDwords];
+    float4 *slot = reinterpret_cast<float4 *>(s_u);
+    uint32_t *s_lg = s_u + 1536, *s_blo = s_u + 1536 + kMList, *s_bhi = s_u + 1536 + 2 * kMList;
+    float *s_dl = reinterpret_cast<float *>(s_u + 1536 + 3 * kMList);
+    unsigned long long *s_row = reinterpret_cast<unsigned long long *>(s_u + kMRowAt);
+    uint32_t *q_id = s_u + 1536 + 3 * kMList + kC * kMPitch;
+
+    if (a.gate && !state_is_matrix_core(a.state)) return;
+
+    const int lane = threadIdx.x;
+    const int n = lane & 31, h = lane >> 5;
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int per_super = 4 * ((a.D + 7) >> 3);
+    const int nunits = a.nsx * a.nsy * per_super;
+    const int per_xcd = (nunits + 7) >> 3;
+    const uint32_t m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / (unsigned)per_super);
+    const uint32_t m_nsy = (uint32_t)(((1ull << 32) + a.nsy - 1) / (unsigned)a.nsy);
+    using gptr = const __attribute__((address_space(1))) void *;
+    using lptr = __attribute__((address_space(3))) void *;
+
+    // lattice of the voxel centres (fp64): position of voxel index i along an axis = p0 + i * step
+    using cflt_t = const float __attribute__((address_space(4))) *;
+    cflt_t cp = (cflt_t)(uintptr_t)a.pts;
+    const double p0x = cp[0], p0y = cp[1], p0z = cp[2];
+    const double sx = a.H > 1 ? (double)cp[3 * (size_t)a.W * a.D] - p0x : 1.0;
+    const double sy = a.W > 1 ? (double)cp[3 * (size_t)a.D + 1] - p0y : 1.0;
+    const double sz = a.D > 1 ? (double)cp[3 + 2] - p0z : 1.0;
+
+    // A operands of the exponent MFMAs: monomials (phi) and one-hot coordinates (hot) of voxel n of each block.  The one-hot
+    // operand of half 0 (x, y) only depends on b & 1 and that of half 1 (z) on b >> 1: two registers sets, selected per block.
+    h8 phi[4], hotv[2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float ux_ = (float)(2 * (b & 1) + (n >> 4)) - 1.5f, uy_ = (float)((n >> 2) & 3) - 1.5f,
+                    uz_ = (float)(4 * (b >> 1) + (n & 3)) - 3.5f;
+        const float m0[8] = {1.f, ux_, uy_, uz_, ux_ * ux_, 0.f, 0.f, 0.f};
+        const float m1[8] = {uy_ * uy_, uz_ * uz_, ux_ * uy_, uy_ * uz_, ux_ * uz_, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) phi[b][j] = (_Float16)(h ? m1[j] : m0[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {   // half 0: block parity k (lx = 2 k + (n >> 4)); half 1: z brick k (zz = 4 k + (n & 3))
+        const int lx = 2 * k + (n >> 4), ly = (n >> 2) & 3, zz = 4 * k + (n & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hotv[k][j] = (_Float16)((h ? zz == j : (j < 4 ? lx == j : ly == j - 4)) ? 1.f : 0.f);
+    }
+    // A operand of the moment MFMAs: row r = lane & 31 holds monomial m(r) for r in {0,1,2,3, 8,9,10,11, 16,17} (the rows half 0
+    // of a lane receives in registers 0..9 of the D fragment), K element j of chunk kc = voxel (q & 3) + 8 (q >> 2) + 4 h of the
+    // block, q = 8 kc + j -- the voxel that register q of the exponent fragment holds in this half: x index kc, y index
+    // h + 2 (j >> 2), z index j & 3.  A monomial is a product of per-axis powers, so the eight values of an operand are
+    // X(b & 1, kc) * Y(j >> 2) * Z(b >> 1, j & 3): twelve registers of factors instead of a 32-register table, four packed
+    // multiplies per operand (all values are small dyadic rationals: exact in f16).
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    half2_t xy2[4][2], z2[2][2];   // xy2[2 (b & 1) + kc][jy] = (X Y, X Y);  z2[b >> 1][0 / 1] = (Z(z = 0), Z(1)) / (Z(2), Z(3))
+    {
+        const int mono = (n & 4) ? -1 : ((n & 3) + 4 * (n >> 3));   // rows 0-3 -> 0-3, 8-11 -> 4-7, 16,17 -> 8,9
+        const int pa[10] = {0, 1, 0, 0, 2, 0, 0, 1, 0, 1}, pb[10] = {0, 0, 1, 0, 0, 2, 0, 1, 1, 0}, pc[10] = {0, 0, 0, 1, 0, 0, 2, 0, 1, 1};
+        int ea = 0, eb = 0, ec = 0;
+#pragma unroll
+        for (int m = 0; m < 10; ++m) {
+            ea = mono == m ? pa[m] : ea; eb = mono == m ? pb[m] : eb; ec = mono == m ? pc[m] : ec;
+        }
+        const bool valid_row = mono >= 0 && mono < 10;
+        auto pw = [](float x, int e) { return e == 0 ? 1.f : (e == 1 ? x : x * x); };
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int jy = 0; jy < 2; ++jy) {
+                const float v = valid_row ? pw((float)t - 1.5f, ea) * pw((float)(h + 2 * jy) - 1.5f, eb) : 0.f;
+                xy2[t][jy] = (half2_t){(_Float16)v, (_Float16)v};
+            }
+#pragma unroll
+        for (int bz = 0; bz < 2; ++bz)
+#pragma unroll
+            for (int zp = 0; zp < 2; ++zp)
+                z2[bz][zp] = (half2_t){(_Float16)pw((float)(4 * bz + 2 * zp) - 3.5f, ec), (_Float16)pw((float)(4 * bz + 2 * zp + 1) - 3.5f, ec)};
+    }
+
+    auto request_records_at = [&](int qh, int start, int count) {
+        const uint32_t id = q_id[(qh + start + (n < count ? n : 0)) & (kMQCap - 1)];
+        const char *rec = reinterpret_cast<const char *>(a.records + (size_t)id * kRecDwords);
+        // half 0: mean/opacity, cov, cov + box, semantics 0..11;  half 1: the same three, semantics 8..19 (+ first row)
+        const int o3 = (3 + 2 * h) * 16, o4 = (4 + 2 * h) * 16, o5 = (5 + 2 * h) * 16;
+        char *dst = reinterpret_cast<char *>(slot);
+        __builtin_amdgcn_global_load_lds((gptr)(rec), (lptr)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + 16), (lptr)(dst + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + 32), (lptr)(dst + 2048), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o3), (lptr)(dst + 3072), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o4), (lptr)(dst + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(rec + o5), (lptr)(dst + 5120), 16, 0, 0);
+    };
+    auto request_row = [&](const unsigned long long *bm) {
+        for (int i = 0; 128 * i < a.nrow; ++i)
+            if (128 * i + 2 * lane < a.nrow)
+                __builtin_amdgcn_global_load_lds((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
+    };
+
+    uint32_t *ctr = a.tile_counters + 64 * xcd;
+    const int nchunk = (a.nwords + 63) >> 6;
+    int local = (int)(blockIdx.x >> 3);
+    while (true) {  // units of this wave
+        const int logical = xcd * per_xcd + local;
+        if (!(local < per_xcd && logical < nunits)) break;
+        uint32_t claimed = 0u;
+        const int s = (int)__umulhi((uint32_t)logical, m_ps), r = logical - s * per_super;
+        const int srow = a.nsy == 1 ? s : (int)__umulhi((uint32_t)s, m_nsy), scol = s - srow * a.nsy;
+        const int Xw = srow * kSuper + 4 * (r & 1), Y0 = scol * kSuper + 4 * ((r >> 1) & 1), Zw = 8 * (r >> 2);
+        if (Xw < a.H && Y0 < a.W) {
+#if GF_TIMELINE
+            unsigned long long tl[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
+#endif
+            // ---- the unit's bitmask row and its 128 gradient rows, both by LDS-DMA: the rows as 36 four-byte gathers, one per
+            // (channel, half of the unit) -- lane = voxel in block order -- so that they land TRANSPOSED, [channel][voxel], with
+            // no register or VALU in between (a first version carried them through 36 registers and an LDS scatter: the
+            // registers spilled and the unit spent 23 of its 41 us there)
+            request_row(a.bitmask + (size_t)s * a.nrow);
+            bool dl_ok[2];
+            {
+                const int lx = 2 * (lane >> 5) + ((lane >> 4) & 1), ly = (lane >> 2) & 3;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int z = 4 * half + (lane & 3);
+                    dl_ok[half] = Xw + lx < a.H && Y0 + ly < a.W && Zw + z < a.D;
+                    const size_t vox = dl_ok[half] ? ((size_t)(Xw + lx) * a.W + (Y0 + ly)) * a.D + (Zw + z) : 0;
+                    const float *src = a.out_grad + vox * kC;
+#pragma unroll
+                    for (int ch = 0; ch < kC; ++ch)
+                        __builtin_amdgcn_global_load_lds((gptr)(src + ch), (lptr)(s_dl + ch * kMPitch + 64 * half), 4, 0, 0);
+                }
+            }
+            // (36 requests were issued behind the row's: "at most 36 outstanding" = the row has landed)
+            asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+#if GF_TIMELINE
+            tl[1] = wall_clock64();
+#endif
+            int list_len = 0, qlen = 0, qhead = 0, npend = 0;
+            int c = 0, sg = 0;
+            // ---- candidate list from the row: the forward's fast path (nonzero words compacted, bits extracted side by side)
+            {
+                constexpr int kWDense = kMList;
+                uint32_t *s_dw = s_u;
+                unsigned long long *s_db = reinterpret_cast<unsigned long long *>(s_u + kWDense);
+                constexpr int kWPer = (kWRow + 63) / 64;
+                const int kw = nchunk;
+                unsigned long long wd[kWPer];
+                int mine = 0;
+#pragma unroll
+                for (int k = 0; k < kWPer; ++k) wd[k] = s_row[min(kw * lane + k, kWRow - 1)];
+                static_assert(kWPer == 10, "operand list below");
+                asm volatile("" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]), "+v"(wd[3]), "+v"(wd[4]), "+v"(wd[5]), "+v"(wd[6]), "+v"(wd[7]),
+                             "+v"(wd[8]), "+v"(wd[9]));
+#pragma unroll
+                for (int k = 0; k < kWPer; ++k) {
+                    const int w = kw * lane + k;
+                    wd[k] = (k < kw && w < a.nwords) ? wd[k] : 0ull;
+                    mine += wd[k] != 0ull ? 1 : 0;
+                }
+                const int incl_nz = wave_incl_scan(mine);
+                const int nd = __builtin_amdgcn_readlane(incl_nz, 63);
+                if (nd <= kWDense) {
+                    int p = incl_nz - mine;
+#pragma unroll
+                    for (int k = 0; k < kWPer; ++k) {
+                        if (wd[k] != 0ull) {
+                            s_dw[p] = (uint32_t)(kw * lane + k);
+                            s_db[p] = wd[k];
+                            ++p;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    int tot = 0;
+                    bool fits = true;
+                    auto extract = [&](unsigned long long bits, uint32_t id0, int pos) {
+                        if (bits) {   // a dense word has at least one bit (only the lanes past the end have none) ...
+                            s_lg[pos++] = id0 + (uint32_t)__builtin_ctzll(bits);
+                            bits &= bits - 1;
+                        }
+                        while (bits) {   // ... and four in five have exactly one
+                            const int j = __builtin_ctzll(bits);
+                            bits &= bits - 1;
+                            s_lg[pos++] = id0 + (uint32_t)j;
+                        }
+                    };
+                    if (nd <= 192) {
+                        // the usual case, three rounds side by side (reads, counts and scans of the rounds are independent)
+                        unsigned long long bb[3];
+                        uint32_t ii[3];
+                        int cn[3], in_[3], tt[3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            bb[q] = s_db[64 * q + lane];
+                            ii[q] = s_dw[64 * q + lane];
+                        }
+                        asm volatile("" : "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(ii[0]), "+v"(ii[1]), "+v"(ii[2]));
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            bb[q] = 64 * q + lane < nd ? bb[q] : 0ull;
+                            ii[q] *= 64u;
+                            cn[q] = __builtin_popcountll(bb[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) in_[q] = wave_incl_scan(cn[q]);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) tt[q] = __builtin_amdgcn_readlane(in_[q], 63);
+                        tot = tt[0] + tt[1] + tt[2];
+                        if (tot <= kMList) {
+                            // (the list overlaps the row's LDS area: every lane has its row words in registers by now)
+                            extract(bb[0], ii[0], in_[0] - cn[0]);
+                            extract(bb[1], ii[1], tt[0] + in_[1] - cn[1]);
+                            extract(bb[2], ii[2], tt[0] + tt[1] + in_[2] - cn[2]);
+                        } else {
+                            fits = false;
+                        }
+                    } else {
+                        for (int d0 = 0; d0 < nd; d0 += 64) {
+                            const int i = d0 + lane;
+                            const unsigned long long bits = i < nd ? s_db[i] : 0ull;
+                            const uint32_t id0 = (i < nd ? s_dw[i] : 0u) * 64u;
+                            const int cnt = __builtin_popcountll(bits);
+                            const int incl = wave_incl_scan(cnt);
+                            const int t = __builtin_amdgcn_readlane(incl, 63);
+                            if (tot + t > kMList) {
+                                fits = false;
+                                break;
+                            }
+                            extract(bits, id0, tot + incl - cnt);
+                            tot += t;
+                        }
+                    }
+                    if (fits) {
+                        list_len = tot;
+                        c = nchunk;
+                    }
+                }
+            }
+            // (The gradient rows take the row's place in LDS now.  A list longer than kMList -- the chunked fill below, a rare
+            // path -- reads the row's words again from global memory, where they are L2-hot.)
+            const unsigned long long *bm_row = a.bitmask + (size_t)s * a.nrow;
+#if GF_TIMELINE
+            tl[2] = wall_clock64();
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- the gradient rows have landed (wait for everything: the dense path below has no request of its own in flight);
+            // columns of voxels outside the grid (partial units) are cleared, then the unit's largest |dL| gives the power of two
+            // that brings the f16 operands made from these rows to [16, 32)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float dmax = 0.f;
+            {
+                const bool partial = !(Xw + 4 <= a.H && Y0 + 4 <= a.W && Zw + 8 <= a.D);
+                if (partial) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        if (!dl_ok[half])
+#pragma unroll
+                            for (int ch = 0; ch < kC; ++ch) s_dl[ch * kMPitch + 64 * half + lane] = 0.f;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                float v[2 * kC];
+#pragma unroll
+                for (int ch = 0; ch < kC; ++ch) {
+                    v[2 * ch] = s_dl[ch * kMPitch + lane];
+                    v[2 * ch + 1] = s_dl[ch * kMPitch + 64 + lane];
+                }
+#pragma unroll
+                for (int k = 0; k < 2 * kC; ++k) dmax = fmaxf(dmax, fabsf(v[k]));
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, d, 64));
+            }
+            const int dex = min(254, max(5, (int)((__float_as_uint(dmax) >> 23) & 255u)));
+            const float dscale = dmax > 0.f ? __uint_as_float((uint32_t)(258 - dex) << 23) : 1.f;   // 2^(131 - dex)
+            const int dshift = dmax > 0.f ? dex - 131 : 0;   // true value = scaled value * 2^dshift
+            const double Cx = p0x + ((double)Xw + 1.5) * sx, Cy = p0y + ((double)Y0 + 1.5) * sy, Cz = p0z + ((double)Zw + 3.5) * sz;
+            bool have_next = false;
+            bool stores_behind = false;   // the newest record request has a group's six row stores behind it
+#if GF_TIMELINE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tl[3] = wall_clock64();
+#endif
+            while (true) {  // fill the list (chunked path only), consume it, until the row is exhausted
+                bool last = false;
+                while (true) {
+                    if (c >= nchunk) {
+                        last = true;
+                        break;
+                    }
+                    // chunk c: word 64 c + lane
+                    const int w = 64 * c + lane;
+                    unsigned long long bits = w < a.nwords ? bm_row[w] : 0ull;
+                    const int cnt = __builtin_popcountll(bits);
+                    const int incl = wave_incl_scan(cnt);
+                    const int total = __builtin_amdgcn_readlane(incl, 63);
+                    int pos = -1;
+                    if (total <= kMList) {
+                        if (list_len + total > kMList) break;
+                        pos = list_len + incl - cnt;
+                        list_len += total;
+                        ++c;
+                    } else {
+                        bool full = false;
+                        for (; sg < 8; ++sg) {
+                            const int e1 = __builtin_amdgcn_readlane(incl, 8 * sg + 7);
+                            const int e0 = sg ? __builtin_amdgcn_readlane(incl, 8 * sg - 1) : 0;
+                            if (list_len + (e1 - e0) > kMList) {
+                                full = true;
+                                break;
+                            }
+                            if ((lane >> 3) == sg) pos = list_len + (incl - cnt) - e0;
+                            list_len += e1 - e0;
+                        }
+                        if (!full) {
+                            sg = 0;
+                            ++c;
+                        }
+                        if (pos >= 0) {
+                            const uint32_t id0 = (uint32_t)w * 64u;
+                            while (bits) {
+                                const int j = __builtin_ctzll(bits);
+                                bits &= bits - 1;
+                                s_lg[pos++] = id0 + (uint32_t)j;
+                            }
+                        }
+                        if (full) break;
+                        continue;
+                    }
+                    const uint32_t id0 = (uint32_t)w * 64u;
+                    while (bits) {
+                        const int j = __builtin_ctzll(bits);
+                        bits &= bits - 1;
+                        s_lg[pos++] = id0 + (uint32_t)j;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // ---- packed boxes of the listed Gaussians, by LDS-DMA
+                for (int b0 = 0; b0 < list_len; b0 += 64) {
+                    const uint32_t id = s_lg[min(b0 + lane, list_len - 1)];
+                    __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0), 4, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                stores_behind = false;
+                // ---- consume: hits of the double brick -> queue -> groups of 32, one-deep record pipeline
+                for (int base = 0; base < list_len || (last && base == 0); base += 64) {
+                    const int i = base + lane;
+                    const int ic = min(i, max(list_len - 1, 0));
+                    const uint32_t eg = s_lg[ic];
+                    const uint32_t blo = s_blo[ic], bhi = s_bhi[ic];
+                    const bool hit = i < list_len && ux(blo) < Xw + 4 && ux(bhi) > Xw && uy(blo) < Y0 + 4 && uy(bhi) > Y0 &&
+                                     uz(blo) < Zw + 8 && uz(bhi) > Zw;
+                    const unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
+                    if (hit) q_id[(qhead + qlen + (int)mbcnt(todo)) & (kMQCap - 1)] = eg;
+                    qlen += __builtin_popcountll(todo);
+                    const bool final_batch = last && base + 64 >= list_len;
+                    while (true) {
+                        if (npend == 0) {
+                            if (!(qlen >= 32 || (final_batch && qlen > 0))) break;
+                            npend = min(qlen, 32);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            request_records_at(qhead, 0, npend);
+                            stores_behind = false;
+                        }
+                        const int avail = qlen - npend;
+                        if (!(avail >= 32 || final_batch)) break;
+                        const int qn = npend;
+                        // The pending group's record pieces have landed.  After a group that stored rows, exactly six store
+                        // instructions (or more atomics) were issued BEHIND that request and memory operations complete in order:
+                        // "at most six outstanding" means the pieces are there -- without waiting for the stores to be acknowledged
+                        // (with a full wait every group paid the ~3 us of its predecessor's write acknowledgements).
+                        if (stores_behind) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if GF_TIMELINE
+                        if (!tl[4]) tl[4] = wall_clock64();
+                        tl[7] += 1;
+#endif
+                        const bool live = n < qn;
+                        const float4 r0 = slot[lane], r1 = slot[64 + lane], r2 = slot[128 + lane];
+                        const float4 e0 = slot[192 + lane], e1 = slot[256 + lane], e2 = slot[320 + lane];
+                        const uint32_t my_id = q_id[(qhead + (live ? n : 0)) & (kMQCap - 1)];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const int nnext = min(avail, 32);
+                        if (nnext > 0) request_records_at(qhead, qn, nnext);
+                        const bool last_group = final_batch && nnext == 0;
+                        if (last_group && lane == 0)
+                            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+                        // ---- B operand of the T contraction: semantics, nine channels per half (half 0: 0..8, half 1: 9..17), scaled
+                        // per Gaussian by a power of two to max |sem| in [0.5, 1)
+                        float sb[9];
+                        {
+                            const float lo9[9] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};    // half 0: pieces 3, 4, 5 = ch 0..11
+                            const float hi9[9] = {e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y};    // half 1: pieces 5, 6, 7 = ch 8..19
+#pragma unroll
+                            for (int j = 0; j < 9; ++j) sb[j] = live ? (h ? hi9[j] : lo9[j]) : 0.f;
+                        }
+                        float smax = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) smax = fmaxf(smax, fabsf(sb[j]));
+                        smax = fmaxf(smax, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, smax))));
+                        const int sex = min(252, (int)((__float_as_uint(smax) >> 23) & 255u));
+                        const float sscale = smax > 0.f ? __uint_as_float((uint32_t)(253 - sex) << 23) : 1.f;
+                        const int sshift = smax > 0.f ? sex - 126 : 0;   // true semantics = operand * 2^sshift
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) sb[j] = (sb[j] * sscale) * dscale;   // T' = T 2^-(sshift + dshift); two exact steps (the product of the scales may overflow)
+                        // ---- B operands of the exponent: theta in fp64, three f16 terms (the forward's A operands)
+                        H8 t1, t2, t3;
+                        double ex = 0, ey = 0, ez = 0;
+                        {
+                            const double L = 1.4426950408889634074;
+                            const double c0 = r1.x, c1 = r1.y, c2 = r1.z, c3 = r1.w, c4 = r2.x, c5 = r2.y;
+                            double th[5];
+                            if (h == 0) {
+                                ex = Cx - (double)r0.x; ey = Cy - (double)r0.y; ez = Cz - (double)r0.z;
+                                const double gx = c0 * ex + c3 * ey + c5 * ez, gy = c3 * ex + c1 * ey + c4 * ez, gz = c5 * ex + c4 * ey + c2 * ez;
+                                th[0] = -0.5 * L * (ex * gx + ey * gy + ez * gz);
+                                th[1] = -L * sx * gx; th[2] = -L * sy * gy; th[3] = -L * sz * gz;
+                                th[4] = -0.5 * L * sx * sx * c0;
+                            } else {
+                                th[0] = -0.5 * L * sy * sy * c1; th[1] = -0.5 * L * sz * sz * c2;
+                                th[2] = -L * sx * sy * c3; th[3] = -L * sy * sz * c4; th[4] = -L * sx * sz * c5;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) split3(live ? th[j] : 0.0, t1.e[j], t2.e[j], t3.e[j]);
+#pragma unroll
+                            for (int j = 5; j < 8; ++j) { t1.e[j] = (_Float16)0.f; t2.e[j] = (_Float16)0.f; t3.e[j] = (_Float16)0.f; }
+                        }
+                        H8 tb;
+                        {
+                            const uint32_t glo = __float_as_uint(r2.z), ghi = __float_as_uint(r2.w);
+                            const int x0 = ux(glo) - Xw, x1 = ux(ghi) - Xw, y0 = uy(glo) - Y0, y1 = uy(ghi) - Y0;
+                            const int z0 = uz(glo) - Zw, z1 = uz(ghi) - Zw;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const bool in = h ? (j >= z0 && j < z1) : (j < 4 ? (j >= x0 && j < x1) : (j - 4 >= y0 && j - 4 < y1));
+                                tb.e[j] = (_Float16)((in && live) ? 0.f : -32768.f);
+                            }
+                        }
+                        f32x16 mom, dsm;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) { mom[q] = 0.f; dsm[q] = 0.f; }
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            // one-hot operand of this block: half 0 takes set b & 1, half 1 set b >> 1
+                            const int sel = h ? (b >> 1) : (b & 1);
+                            H8 hot;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const H8 v0 = {hotv[0]}, v1 = {hotv[1]};
+                                hot.p[j] = sel ? v1.p[j] : v0.p[j];
+                            }
+                            f32x16 d, T;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) { d[q] = 0.f; T[q] = 0.f; }
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[b], t3.v, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[b], t2.v, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[b], t1.v, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(hot.v, tb.v, d, 0, 0, 0);
+                            // T'[v, g] = sum_c dL[v][c] sem[g][c]: MFMA j multiplies channel j (half 0) and 9 + j (half 1)
+                            const float *dlp = s_dl + (9 * h) * kMPitch + 32 * b + n;
+                            float av[9];
+#pragma unroll
+                            for (int j = 0; j < 9; ++j) av[j] = dlp[j * kMPitch];
+#pragma unroll
+                            for (int j = 0; j < 9; ++j) T = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], sb[j], T, 0, 0, 0);
+                            f32x16 e, K;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) e[q] = __builtin_amdgcn_exp2f(d[q]);
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) K[q] = e[q] * T[q];
+                            H8 eh[2], el[2], kh_[2], kl_[2];
+                            split16(e, eh, el);
+                            split16(K, kh_, kl_);
+#pragma unroll
+                            for (int kc = 0; kc < 2; ++kc) {
+                                union { h8 v; half2_t p[4]; } pt;
+                                pt.p[0] = xy2[2 * (b & 1) + kc][0] * z2[b >> 1][0];
+                                pt.p[1] = xy2[2 * (b & 1) + kc][0] * z2[b >> 1][1];
+                                pt.p[2] = xy2[2 * (b & 1) + kc][1] * z2[b >> 1][0];
+                                pt.p[3] = xy2[2 * (b & 1) + kc][1] * z2[b >> 1][1];
+                                mom = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt.v, kl_[kc].v, mom, 0, 0, 0);
+                                mom = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt.v, kh_[kc].v, mom, 0, 0, 0);
+                                // dL^T operand: row = channel n (rows >= 18 repeat row 17: their outputs are never read), K element j
+                                // of chunk kc = voxel 16 kc + 4 h + j (j < 4), 16 kc + 8 + 4 h + (j - 4) (j >= 4): two 16-byte reads
+                                const float *dc = s_dl + min(n, kC - 1) * kMPitch + 32 * b + 16 * kc + 4 * h;
+                                const float4 x0 = *reinterpret_cast<const float4 *>(dc), x1 = *reinterpret_cast<const float4 *>(dc + 8);
+                                const float xv[8] = {x0.x * dscale, x0.y * dscale, x0.z * dscale, x0.w * dscale,
+                                                     x1.x * dscale, x1.y * dscale, x1.z * dscale, x1.w * dscale};
+                                H8 ah, al;
+#pragma unroll
+                                for (int j = 0; j < 8; j += 2) {
+                                    const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(xv[j], xv[j + 1]);
+                                    float q0, q1;
+                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(hh), "v"(xv[j]));
+                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(hh), "v"(xv[j + 1]));
+                                    ah.p[j >> 1] = hh;
+                                    al.p[j >> 1] = __builtin_amdgcn_cvt_pkrtz(q0, q1);
+                                }
+                                dsm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, eh[kc].v, dsm, 0, 0, 0);
+                                dsm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, el[kc].v, dsm, 0, 0, 0);
+                                dsm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, eh[kc].v, dsm, 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);   // one block at a time: interleaved blocks do not fit the register file
+                        }
+                        // ---- the group's rows.  Lane (g, half 0) holds the ten moments (registers 0..9) and channels 0-3, 8-11, 16, 17
+                        // of dsem; lane (g, half 1) channels 4-7 and 12-15.
+                        {
+                            const float opa = r0.w;
+                            const double fs = __builtin_ldexp(1.0, dshift);            // undo the dL scale
+                            const double fm = __builtin_ldexp(1.0, dshift + sshift);   // ... and the semantics scale (moments only)
+                            float o[24];
+                            if (h == 0) {
+                                const double S0 = mom[0] * fm, S1x = mom[1] * fm, S1y = mom[2] * fm, S1z = mom[3] * fm;
+                                const double Sxx = mom[4] * fm, Syy = mom[5] * fm, Szz = mom[6] * fm, Sxy = mom[7] * fm, Syz = mom[8] * fm, Sxz = mom[9] * fm;
+                                // sums over voxels of K d and K d d^T, d = -(e + s u)
+                                const double D1x = -(ex * S0 + sx * S1x), D1y = -(ey * S0 + sy * S1y), D1z = -(ez * S0 + sz * S1z);
+                                const double D2xx = ex * ex * S0 + 2.0 * ex * sx * S1x + sx * sx * Sxx;
+                                const double D2yy = ey * ey * S0 + 2.0 * ey * sy * S1y + sy * sy * Syy;
+                                const double D2zz = ez * ez * S0 + 2.0 * ez * sz * S1z + sz * sz * Szz;
+                                const double D2xy = ex * ey * S0 + ex * sy * S1y + ey * sx * S1x + sx * sy * Sxy;
+                                const double D2yz = ey * ez * S0 + ey * sz * S1z + ez * sy * S1y + sy * sz * Syz;
+                                const double D2xz = ex * ez * S0 + ex * sz * S1z + ez * sx * S1x + sx * sz * Sxz;
+                                const double c0 = r1.x, c1 = r1.y, c2 = r1.z, c3 = r1.w, c4 = r2.x, c5 = r2.y, po = opa;
+                                // slots: 0..3 = sem 0-3 | 4..7 = sem 8-11 | 8,9 = sem 16,17 | 10..15 = cov | 16..18 = mean | 19 = opacity
+                                o[0] = (float)(po * dsm[0] * fs); o[1] = (float)(po * dsm[1] * fs); o[2] = (float)(po * dsm[2] * fs); o[3] = (float)(po * dsm[3] * fs);
+                                o[4] = (float)(po * dsm[4] * fs); o[5] = (float)(po * dsm[5] * fs); o[6] = (float)(po * dsm[6] * fs); o[7] = (float)(po * dsm[7] * fs);
+                                o[8] = (float)(po * dsm[8] * fs); o[9] = (float)(po * dsm[9] * fs);
+                                o[10] = (float)(-0.5 * po * D2xx); o[11] = (float)(-0.5 * po * D2yy); o[12] = (float)(-0.5 * po * D2zz);
+                                o[13] = (float)(-po * D2xy); o[14] = (float)(-po * D2yz); o[15] = (float)(-po * D2xz);
+                                o[16] = (float)(-po * (c0 * D1x + c3 * D1y + c5 * D1z));
+                                o[17] = (float)(-po * (c3 * D1x + c1 * D1y + c4 * D1z));
+                                o[18] = (float)(-po * (c5 * D1x + c4 * D1y + c2 * D1z));
+                                o[19] = (float)S0;
+                            } else {
+                                const double po = opa;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) o[k] = (float)(po * dsm[k] * fs);   // sem 4-7, 12-15
+#pragma unroll
+                                for (int k = 8; k < 20; ++k) o[k] = 0.f;
+                            }
+                            // row of (Gaussian, this double brick): first row from record dword 31 (half 1 fetched piece 7: e2.w)
+                            const uint32_t first_h1 = __float_as_uint(e2.w);
+                            const uint32_t first = (uint32_t)__builtin_amdgcn_ds_bpermute((n + 32) << 2, (int)first_h1);
+                            const uint32_t glo = __float_as_uint(r2.z), ghi = __float_as_uint(r2.w);
+                            const int bx0 = ux(glo) >> 2, by0 = uy(glo) >> 2, bz0 = uz(glo) >> 3;
+                            const int nby = ((uy(ghi) - 1) >> 2) - by0 + 1, nbz = ((uz(ghi) - 1) >> 3) - bz0 + 1;
+                            const int nbx = ((ux(ghi) - 1) >> 2) - bx0 + 1;
+                            const int idx = (((Xw >> 2) - bx0) * nby + ((Y0 >> 2) - by0)) * nbz + ((Zw >> 3) - bz0);
+                            const bool has_row = live && first != 0xFFFFFFFFu;
+                            if (has_row) {
+                                // SIX store instructions per group, whatever the lanes hold (the counted wait above relies on it):
+                                // two that both halves take part in, four of half 0
+                                float4 *row = reinterpret_cast<float4 *>(a.rows + ((size_t)first + (size_t)idx) * kBwdRowDwords);
+                                row[h] = make_float4(o[0], o[1], o[2], o[3]);
+                                row[2 + h] = make_float4(o[4], o[5], o[6], o[7]);
+                                if (h == 0) {
+                                    row[4] = make_float4(o[8], o[9], o[10], o[11]);
+                                    row[5] = make_float4(o[12], o[13], o[14], o[15]);
+                                    row[6] = make_float4(o[16], o[17], o[18], o[19]);
+                                    row[7] = make_float4(__uint_as_float(my_id), __uint_as_float((uint32_t)(nbx * nby * nbz)), __uint_as_float((uint32_t)idx), 0.f);
+                                }
+                            } else if (live) {
+                                // no rows for this Gaussian (the buffer was full): float atomics straight into the gradients
+                                float *sg_ = a.sem_grad + (size_t)kC * my_id;
+                                if (h == 0) {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(sg_ + k, o[k]); unsafeAtomicAdd(sg_ + 8 + k, o[4 + k]); }
+                                    unsafeAtomicAdd(sg_ + 16, o[8]); unsafeAtomicAdd(sg_ + 17, o[9]);
+#pragma unroll
+                                    for (int k = 0; k < 6; ++k) unsafeAtomicAdd(a.cov_grad + 6 * (size_t)my_id + k, o[10 + k]);
+#pragma unroll
+                                    for (int k = 0; k < 3; ++k) unsafeAtomicAdd(a.means_grad + 3 * (size_t)my_id + k, o[16 + k]);
+                                    unsafeAtomicAdd(a.opa_grad + my_id, o[19]);
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(sg_ + 4 + k, o[k]); unsafeAtomicAdd(sg_ + 12 + k, o[4 + k]); }
+                                }
+                            }
+                        }
+                        stores_behind = nnext > 0;   // (the request for the next group went out before these stores)
+                        have_next = have_next || last_group;
+                        qhead = (qhead + qn) & (kMQCap - 1);
+                        qlen -= qn;
+                        npend = nnext;
+                    }
+                }
+                if (last) break;
+                list_len = 0;
+            }
+#if GF_TIMELINE
+            tl[5] = wall_clock64();
+#endif
+            if (!have_next) {   // a unit without a single hit
+                if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed)::"memory");
+            } else {
+                // the claim went out before the last group's six row stores: its answer is there once at most six are outstanding
+                asm volatile("s_waitcnt vmcnt(6)" : "+v"(claimed)::"memory");
+            }
+            // the staged rows and the slot are dead: the next unit's row request may land in their place
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if GF_TIMELINE
+            tl[6] = wall_clock64();
+            if (a.timeline && lane == 0)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a.timeline[8 * (size_t)logical + k] = tl[k];
+#endif
+        } else {
+            if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed)::"memory");
+        }
+        local = __builtin_amdgcn_readfirstlane((int)claimed);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Adds a Gaussian's rows up.  Half a wave per Gaussian, lane = column of the 32-float row, eight rows in flight; the sums
+// are stored (the gradients were zeroed by gf_splat_bwd_zero_kernel and nothing else writes them, except for the Gaussians
+// without rows, which this kernel leaves alone).  Gaussians of the big list (more than kBwdBigRows rows) are summed by
+// the workgroups past the Gaussian range, 512 rows per workgroup, and combined with float atomics.
+struct BwdRowsArgs {
+    const float *records;
+    const float *rows;
+    float *means_grad, *opa_grad, *sem_grad, *cov_grad;
+    const uint32_t *alloc;
+    const int *big;
+    const uint32_t *state;
+    int P, gate, ngauss_blocks;
+};
+
+__device__ __forceinline__ void bwd_store_column(const BwdRowsArgs &a, int g, int col, float v, bool atomic)
+{
+    // row columns: 0..17 semantics (as the two halves wrote them: 0-3, 4-7, 8-11, 12-15, 16, 17), 18..23 covariance, 24..26 mean, 27 opacity
+    float *dst = col < 18 ? a.sem_grad + (size_t)kC * g + col
+               : col < 24 ? a.cov_grad + 6 * (size_t)g + (col - 18)
+               : col < 27 ? a.means_grad + 3 * (size_t)g + (col - 24)
+               : col == 27 ? a.opa_grad + g : nullptr;
+    if (!dst) return;
+    if (atomic) unsafeAtomicAdd(dst, v);
+    else *dst = v;
+}
+
+__global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
+{
+    if (a.gate && !state_is_matrix_core(a.state)) return;
+    const int tid = threadIdx.x, col = tid & 31, sub = tid >> 5;
+    auto box_rows = [&](int g, uint32_t &first) -> int {
+        const float4 r2 = *reinterpret_cast<const float4 *>(a.records + (size_t)g * kRecDwords + 8);
+        first = __float_as_uint(a.records[(size_t)g * kRecDwords + 31]);
+        const uint32_t glo = __float_as_uint(r2.z), ghi = __float_as_uint(r2.w);
+        if (!(ux(ghi) > ux(glo) && uy(ghi) > uy(glo) && uz(ghi) > uz(glo))) return 0;
+        return (((ux(ghi) - 1) >> 2) - (ux(glo) >> 2) + 1) * (((uy(ghi) - 1) >> 2) - (uy(glo) >> 2) + 1) *
+               (((uz(ghi) - 1) >> 3) - (uz(glo) >> 3) + 1);
+    };
+    if ((int)blockIdx.x < a.ngauss_blocks) {
+        const int g = blockIdx.x * 8 + sub;
+        if (g >= a.P) return;
+        uint32_t first;
+        const int cnt = box_rows(g, first);
+        if (cnt == 0 || first == 0xFFFFFFFFu || cnt > kBwdBigRows) return;
+        const float *base = a.rows + (size_t)first * kBwdRowDwords + col;
+        float acc = 0.f;
+        int r = 0;
+        for (; r + 8 <= cnt; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(r + k) * kBwdRowDwords];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = base[(size_t)min(r + k, cnt - 1) * kBwdRowDwords];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += (r + k < cnt) ? v[k] : 0.f;
+        }
+        bwd_store_column(a, g, col, acc, false);
+        return;
+    }
+    // ---- big Gaussians: work item = 512 rows of one of them
+    __shared__ float s_part[8][32];
+    const int nbig = min((int)a.alloc[1], kBwdBigCap);
+    int item = (int)blockIdx.x - a.ngauss_blocks;
+    const int stride = (int)gridDim.x - a.ngauss_blocks;
+    for (int e = 0; e < nbig; ++e) {
+        const int g = a.big[e];
+        uint32_t first;
+        const int cnt = box_rows(g, first);
+        const int parts = (cnt + 511) / 512;
+        while (item < parts) {
+            const int r0 = item * 512, r1 = min(cnt, r0 + 512);
+            const float *base = a.rows + ((size_t)first + r0) * kBwdRowDwords + col;
+            float acc = 0.f;
+            for (int r = sub; r0 + r < r1; r += 32) {   // eight half-waves, four rows in flight each
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = base[(size_t)min(r + 8 * k, r1 - r0 - 1) * kBwdRowDwords];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc += (r0 + r + 8 * k < r1) ? v[k] : 0.f;
+            }
+            s_part[sub][col] = acc;
+            __syncthreads();
+            if (sub == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += s_part[k][col];
+                bwd_store_column(a, g, col, t, true);
+            }
+            __syncthreads();
+            item += stride;
+        }
+        item -= parts;
+    }
+}
+
+}  // namespace gf
+
+namespace gf {
+
+static int bwd_mfma_grid(int nunits)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    const int per_xcd = (nunits + 7) / 8;
+    return 8 * std::min(per_xcd, std::max(1, 8 * cus / 8));
+}
+
+static unsigned long long *g_bwd_timeline = nullptr;
+
+// Launches the matrix-core backward (zero -> records pass -> gradient kernel -> row sums) on `stream`.
+// gate: 0 = unconditional, 1 = every kernel stands down unless the forward's state says "matrix cores" (the caller launches
+// the Gaussian-major kernels gated the other way), 2 = NaN gradients in that case (the caller asserted it).
+void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, int D, const float *pts, const int *points_int,
+                                const float *means3D, const int *means3D_int, const float *opacity, const float *semantics,
+                                const int *radii, const float *cov3D, const float *out_grad, float *means_grad,
+                                float *opa_grad, float *sem_grad, float *cov_grad, const uint32_t *state,
+                                const SplatWorkspace &ws, int gate, hipStream_t stream)
+{
+    BwdZeroArgs z{means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_alloc, state, P, gate};
+    hipLaunchKernelGGL(gf_splat_bwd_zero_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, z);
+    launch_prep_for_backward(radii_per_axis, P, N, H, W, D, pts, points_int, means3D, means3D_int, opacity, semantics, radii,
+                             cov3D, ws, stream);
+    BwdMArgs a;
+    a.pts = pts; a.records = ws.records; a.boxes = ws.boxes; a.bitmask = ws.bitmask; a.out_grad = out_grad; a.rows = ws.bwd_rows;
+    a.means_grad = means_grad; a.opa_grad = opa_grad; a.sem_grad = sem_grad; a.cov_grad = cov_grad; a.state = state;
+    a.tile_counters = ws.flags + 4608; a.alloc = ws.bwd_alloc; a.big = ws.bwd_big;
+    a.P = P; a.N = N; a.nwords = ws.nwords; a.nrow = ws.nrow; a.H = H; a.W = W; a.D = D; a.nsx = ws.nsx; a.nsy = ws.nsy;
+    a.gate = gate ? 1 : 0;
+    a.timeline = g_bwd_timeline;
+    const int nunits = ws.nsuper * 4 * ((D + 7) / 8);
+    hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel, dim3(bwd_mfma_grid(nunits)), dim3(64), 0, stream, a);
+    BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_alloc, ws.bwd_big, state, P, gate ? 1 : 0,
+                  (P + 7) / 8};
+    hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + 256), dim3(256), 0, stream, r);
+}
+
+}  // namespace gf
+
+// debug hook (not in the public header): per-unit timestamps of the gradient kernel
+extern "C" void gf_debug_set_bwd_timeline(void *dev_ptr) { gf::g_bwd_timeline = (unsigned long long *)dev_ptr; }

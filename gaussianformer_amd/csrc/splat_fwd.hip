@@ -53,10 +53,15 @@ struct PrepArgs {
     int P, N, H, W, D, nwords, nrow, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det, lattice;
     uint32_t *tile_counters;  // null, or the eight per-XCD tile counters of the matrix-core render kernel ...
     uint32_t tile_counter_init;  // ... and the value they start from (the workgroups per XCD: those tiles are taken)
+    uint32_t *unit_alloc;    // null (forward), or the matrix-core backward's row allocator: [0] cursor, [1] big-list length, [2] overflows
+    int *unit_big;           // ... its big list
+    uint32_t unit_cap;       // ... and the rows available
     uint32_t *range_flags;   // null, or [nwords + 4]: per wave of 64 Gaussians, bit 2 = a Gaussian's theta may leave the f16
                              // range, bit 3 = |opacity * semantics| may (matrix-core render kernel: both change per frame, so
                              // they are checked in the records pass on EVERY call, GF_PTS_ASSUME_DENSE included)
 };
+
+__device__ __forceinline__ int wave_inclusive_scan(int v);
 
 constexpr int kVerifyBlocks = 4096;    // verification waves; render thread t reads 16 verdicts
 constexpr int kPrepSuperChunk = 4096;  // bitmask words in LDS per pass of the prep kernel (32 KB)
@@ -84,6 +89,28 @@ __device__ __forceinline__ float prob_kdet(float c0, float c1, float c2, float c
     float deter, kdet;
     prob_det_kdet(c0, c1, c2, c3, c4, c5, exact, deter, kdet);
     return kdet;
+}
+
+// Range verdicts of the matrix-core render kernel for one Gaussian (bit 2: theta, bit 3: opacity * semantics; explained at
+// their use in gf_splat_prep_kernel).  lsx, lsy, lsz = |lattice steps|.
+__device__ __forceinline__ uint32_t range_bits_of(const float *c, const float *sm, float opa, int r0, int r1, int r2, int H, int W,
+                                                  int D, float lsx, float lsy, float lsz)
+{
+    const float ex = (float)(min(r0, H) + 3) * lsx, ey = (float)(min(r1, W) + 3) * lsy, ez = (float)(min(r2, D) + 5) * lsz;
+    const float bound = 0.7213475f * (fabsf(c[0]) + fabsf(c[1]) + fabsf(c[2])) * (ex * ex + ey * ey + ez * ez);
+    const float rx = 1.5f * lsx, ry = 1.5f * lsy, rz = 3.5f * lsz;
+    const float Q = fabsf(c[0]) * rx * rx + fabsf(c[1]) * ry * ry + fabsf(c[2]) * rz * rz +
+                    2.f * (fabsf(c[3]) * rx * ry + fabsf(c[4]) * ry * rz + fabsf(c[5]) * rx * rz);
+    // 0.72 (4.3 + sqrt Q)^2 < 1200  <=>  sqrt Q < 36.49  <=>  Q < 1331.4
+    float smax = 0.f;
+    bool snan = false;
+#pragma unroll
+    for (int j = 0; j < kC; ++j) {
+        const float v = fabsf(opa * sm[j]);
+        snan |= !(v == v);
+        smax = fmaxf(smax, v);
+    }
+    return ((!(bound < 3.0e4f) || !(Q < 1331.4f)) ? 4u : 0u) | ((snan || !(smax < 64.f)) ? 8u : 0u);
 }
 
 template <int WAVES>
@@ -146,8 +173,26 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 }
             }
         }
-        const unsigned long long any = __builtin_amdgcn_ballot_w64(bad), any2 = __builtin_amdgcn_ballot_w64(bad_lattice);
-        if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u);
+        // The range verdicts of the matrix-core kernel (see range_of below).  With the point scans running (GF_PTS_AUTO) they
+        // ride along here, beside the records pass instead of on its critical path (in the records pass they cost it 0.75 us at
+        // P = 25 601 and 2.8 us at P = 144 000); with GF_PTS_ASSUME_DENSE there are no verification waves and the records pass
+        // takes them (range_flags).
+        uint32_t rbits = 0u;
+        if (a.lattice) {
+            const float lx_ = fabsf((float)sx), ly_ = fabsf((float)sy), lz_ = fabsf((float)sz);
+            for (int g = vb * 64 + lane; g < a.P; g += kVerifyBlocks * 64) {
+                float c[6], sm[kC];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) c[j] = a.cov3D[6 * (size_t)g + j];
+#pragma unroll
+                for (int j = 0; j < kC; ++j) sm[j] = a.semantics[(size_t)kC * g + j];
+                rbits |= range_bits_of(c, sm, a.opacity[g], a.radii[a.per_axis ? 3 * g : g], a.radii[a.per_axis ? 3 * g + 1 : g],
+                                       a.radii[a.per_axis ? 3 * g + 2 : g], a.H, a.W, a.D, lx_, ly_, lz_);
+            }
+        }
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(bad), any2 = __builtin_amdgcn_ballot_w64(bad_lattice),
+                                 any3 = __builtin_amdgcn_ballot_w64((rbits & 4u) != 0u), any4 = __builtin_amdgcn_ballot_w64((rbits & 8u) != 0u);
+        if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u) | (any3 ? 4u : 0u) | (any4 ? 8u : 0u);
         return;
     }
     if (a.tile_counters && blockIdx.x == 0 && threadIdx.x < 8) a.tile_counters[64 * threadIdx.x] = a.tile_counter_init;
@@ -167,33 +212,22 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     //     centre (|u_i| <= rho = 1.5, 1.5, 3.5 steps), sqrt(e^T A e) <= 4.3 + sqrt(max_u u^T A u) and max_u u^T A u <= Q =
     //     sum_ij |A_ij| rho_i rho_j: the call stays on the matrix cores while 0.72 (4.3 + sqrt Q)^2 < 1200 (predicted error
     //     6e-5 of the weight; an isotropic Gaussian on the 0.5 m grid: sigma >= 0.056 m);
-    //   bit 3: S' = opacity * semantics is split into f16 hi + lo by truncation, which saturates at 65504.
+    //   bit 3: S' = opacity * semantics and the weights go to the matrix cores as f16 hi + lo, whose ABSOLUTE resolution is
+    //     2^-24 (truncation): a weight carries an absolute error of up to 6e-8 that S' multiplies, coherently over the
+    //     Gaussians of a voxel.  |S'| < 64 keeps a voxel with forty such Gaussians inside 1e-4 of max(1, |logit|) (measured:
+    //     one Gaussian with S' = 2.9e4 moved a logit by 1.7e-3; scaling S' down and the weights up per Gaussian moves the loss
+    //     to that Gaussian's small channels instead: 3e-4).  The nuScenes configs stay below 11.
     // (NaN-safe: a NaN bound is "bad".)
     uint32_t range_bits = 0u;
-    double lsx = 0, lsy = 0, lsz = 0;   // |lattice steps|
-    if (a.range_flags) {
-        const double p0x = a.pts[0], p0y = a.pts[1], p0z = a.pts[2];
-        lsx = a.H > 1 ? fabs((double)a.pts[3 * (size_t)a.W * a.D] - p0x) : 1.0;
-        lsy = a.W > 1 ? fabs((double)a.pts[3 * (size_t)a.D + 1] - p0y) : 1.0;
-        lsz = a.D > 1 ? fabs((double)a.pts[3 + 2] - p0z) : 1.0;
+    float lsx = 0.f, lsy = 0.f, lsz = 0.f;   // |lattice steps|  (fp32 throughout: the bounds are thresholds with a wide margin,
+    if (a.range_flags) {                      // and this sits on the records pass's critical path)
+        const float p0x = a.pts[0], p0y = a.pts[1], p0z = a.pts[2];
+        lsx = a.H > 1 ? fabsf(a.pts[3 * (size_t)a.W * a.D] - p0x) : 1.f;
+        lsy = a.W > 1 ? fabsf(a.pts[3 * (size_t)a.D + 1] - p0y) : 1.f;
+        lsz = a.D > 1 ? fabsf(a.pts[3 + 2] - p0z) : 1.f;
     }
     auto range_of = [&](const float *c, const float *sm, float opa, int r0, int r1, int r2) -> uint32_t {
-        const double ex = (min(r0, a.H) + 3) * lsx, ey = (min(r1, a.W) + 3) * lsy, ez = (min(r2, a.D) + 5) * lsz;
-        const double bound = 0.7213475204444817 * ((double)fabsf(c[0]) + fabsf(c[1]) + fabsf(c[2])) * (ex * ex + ey * ey + ez * ez);
-        const double rx = 1.5 * lsx, ry = 1.5 * lsy, rz = 3.5 * lsz;
-        const double Q = fabsf(c[0]) * rx * rx + fabsf(c[1]) * ry * ry + fabsf(c[2]) * rz * rz +
-                         2.0 * (fabsf(c[3]) * rx * ry + fabsf(c[4]) * ry * rz + fabsf(c[5]) * rx * rz);
-        const double sq = 4.3 + sqrt(Q);
-        const double near_bound = 0.7213475204444817 * sq * sq;
-        float smax = 0.f;
-        bool snan = false;
-#pragma unroll
-        for (int j = 0; j < kC; ++j) {
-            const float v = fabsf(opa * sm[j]);
-            snan |= !(v == v);
-            smax = fmaxf(smax, v);
-        }
-        return ((!(bound < 3.0e4) || !(near_bound < 1200.0)) ? 4u : 0u) | ((snan || !(smax < 3.0e4f)) ? 8u : 0u);
+        return range_bits_of(c, sm, opa, r0, r1, r2, a.H, a.W, a.D, lsx, lsy, lsz);
     };
     // Small P (one wave per workgroup): the kernel is a chain of memory round trips, so every input of
     // this lane's Gaussian is requested up front in straight-line code -- the box inputs first, they are
@@ -223,6 +257,33 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
     }
     const bool nonempty = valid && hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2];
+    // Matrix-core backward: the Gaussian's rows of the partial-gradient buffer, one per double brick (4 x 4 x 8 voxels) its box
+    // meets, row (bx, by, bz) of the box's brick range at  first + ((bx - bx0) nby + (by - by0)) nbz + (bz - bz0).  One
+    // returning atomic per wave of 64 Gaussians: which rows a Gaussian gets varies from run to run, what is written to them
+    // and the order they are summed in does not.
+    uint32_t unit_first = 0u;
+    if (a.unit_alloc) {
+        const int cnt = nonempty ? (((hi[0] - 1) >> 2) - (lo[0] >> 2) + 1) * (((hi[1] - 1) >> 2) - (lo[1] >> 2) + 1) *
+                                       (((hi[2] - 1) >> 3) - (lo[2] >> 3) + 1) : 0;
+        const int incl = wave_inclusive_scan(cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        uint32_t base = 0u;
+        if (lane == 0 && total) base = atomicAdd(a.unit_alloc, (uint32_t)total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        unit_first = base + (uint32_t)(incl - cnt);
+        if (cnt > 0) {
+            bool fits = (unsigned long long)unit_first + (unsigned)cnt <= (unsigned long long)a.unit_cap;
+            if (fits && cnt > kBwdBigRows) {
+                const uint32_t slot = atomicAdd(a.unit_alloc + 1, 1u);
+                if (slot < (uint32_t)kBwdBigCap) a.unit_big[slot] = g;
+                else fits = false;
+            }
+            if (!fits) {
+                unit_first = 0xFFFFFFFFu;   // no rows: this Gaussian's partial gradients are accumulated with atomics
+                atomicAdd(a.unit_alloc + 2, 1u);
+            }
+        }
+    }
     // supertile range touched by the box
     const int sx_lo = lo[0] / kSuper, sx_hi = nonempty ? (hi[0] - 1) / kSuper : -1;
     const int sy_lo = lo[1] / kSuper, sy_hi = nonempty ? (hi[1] - 1) / kSuper : -1;
@@ -262,7 +323,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             rec[4] = make_float4(sm[4], sm[5], sm[6], sm[7]);
             rec[5] = make_float4(sm[8], sm[9], sm[10], sm[11]);
             rec[6] = make_float4(sm[12], sm[13], sm[14], sm[15]);
-            rec[7] = make_float4(sm[16], sm[17], kdet, 0.f);
+            rec[7] = make_float4(sm[16], sm[17], kdet, __uint_as_float(unit_first));
         }
     } else {
         // ---- records, large P.  The 64 Gaussians of a wave are contiguous in every input array, so the
@@ -330,7 +391,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
             }
             row[30] = kdet;
-            row[31] = 0.f;
+            row[31] = __uint_as_float(unit_first);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -1043,6 +1104,20 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         vf = make_uint4(v0.x | v1.x | v2.x | v3.x, v0.y | v1.y | v2.y | v3.y, v0.z | v1.z | v2.z | v3.z,
                         v0.w | v1.w | v2.w | v3.w);
     }
+    // the records pass's range verdicts, requested in the same round trip as the words above: four clamped 16-byte reads per
+    // thread (4096 words: P <= 262 144) issued together; longer rows add a loop
+    uint32_t rangev = 0u;
+    if (a.range_flags) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.range_flags);
+        const int last = a.nrange4 - 1;
+        const uint4 q0 = rp[min(tid, last)], q1 = rp[min(tid + kBlock, last)], q2 = rp[min(tid + 2 * kBlock, last)],
+                    q3 = rp[min(tid + 3 * kBlock, last)];
+        rangev = q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x | q2.y | q2.z | q2.w | q3.x | q3.y | q3.z | q3.w;
+        for (int k = tid + 4 * kBlock; k < a.nrange4; k += kBlock) {
+            const uint4 t4 = rp[k];
+            rangev |= t4.x | t4.y | t4.z | t4.w;
+        }
+    }
     int local = (int)(blockIdx.x >> 3);
     int logical = xcd * per_xcd + local;
     int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
@@ -1060,15 +1135,9 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     }
     // ... and of its records pass (every call): bit 2 = a Gaussian's theta, bit 3 = its opacity * semantics may leave the f16 range
     int range_bits = 0;
-    if (a.range_flags) {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.range_flags);
-        uint32_t v = 0u;
-        for (int k = tid; k < a.nrange4; k += kBlock) {
-            const uint4 t4 = rp[k];
-            v |= t4.x | t4.y | t4.z | t4.w;
-        }
-        range_bits = (__syncthreads_or((v & 4u) != 0u) ? 4 : 0) | (__syncthreads_or((v & 8u) != 0u) ? 8 : 0);
-    }
+    if (a.verify_dense) rangev |= vf.x | vf.y | vf.z | vf.w;   // (the verification waves report the range bits themselves when they run)
+    if (a.range_flags || a.verify_dense)
+        range_bits = (__syncthreads_or((rangev & 4u) != 0u) ? 4 : 0) | (__syncthreads_or((rangev & 8u) != 0u) ? 8 : 0);
     const int nondense = verdict | range_bits;
     if (blockIdx.x == 0 && tid == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
@@ -1610,9 +1679,9 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
 //   [17232, 17744)  hit queue (ring of kQCap ids)
 //   [17744, 20480)  opacity * semantics of the current group, [channel][Gaussian]
 constexpr int kWList = 512;
-constexpr int kWRow = 618;
 constexpr int kWLdsDwords = 5120;
 static_assert(3072 + 2 * kWRow + kQCap + (kC + 1) * kSRow == kWLdsDwords, "LDS map of the wave-autonomous kernel");
+static_assert((kWRow + 4 + 3) / 4 <= 3 * 64, "the wave kernel reads its range verdicts with three 16-byte loads per lane");
 static_assert(2 * 64 * kC <= 1536 + 3 * kWList, "output staging fits over the slot and the list");
 
 __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(RenderArgs a)
@@ -1655,26 +1724,31 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             }
         }
     }
-    // verdicts of the prep launch (see gf_splat_render_mfma_kernel)
+    // verdicts of the prep launch (see gf_splat_render_mfma_kernel): the point scans' (GF_PTS_AUTO) and the records pass's range
+    // verdicts (every call, GF_PTS_ASSUME_DENSE included).  All loads first, then the ballots: ONE memory round trip.  (The range
+    // words: three clamped 16-byte reads per lane cover the <= 618 + 4 words of the rows this kernel takes -- no loop: as a loop
+    // every iteration was a round trip of its own at the start of every wave, +4.6 us per launch.)
     int verdict = 0;
-    if (a.verify_dense) {
-        const uint4 *vp = reinterpret_cast<const uint4 *>(a.verify_flags) + 16 * lane;
-        uint32_t v = 0u;
+    {
+        uint32_t v = 0u, rv = 0u;
+        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+        if (a.range_flags) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(a.range_flags);
+            const int last = a.nrange4 - 1;
+            r0 = rp[min(lane, last)]; r1 = rp[min(lane + 64, last)]; r2 = rp[min(lane + 128, last)];
+        }
+        if (a.verify_dense) {
+            const uint4 *vp = reinterpret_cast<const uint4 *>(a.verify_flags) + 16 * lane;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint4 t = vp[k];
-            v |= t.x | t.y | t.z | t.w;
+            for (int k = 0; k < 16; ++k) {
+                const uint4 t = vp[k];
+                v |= t.x | t.y | t.z | t.w;
+            }
         }
-        verdict = (__builtin_amdgcn_ballot_w64((v & 1u) != 0u) ? 1 : 0) | (__builtin_amdgcn_ballot_w64((v & 2u) != 0u) ? 2 : 0);
-    }
-    if (a.range_flags) {   // the records pass's range verdicts (every call, GF_PTS_ASSUME_DENSE included)
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.range_flags);
-        uint32_t v = 0u;
-        for (int k = lane; k < a.nrange4; k += 64) {
-            const uint4 t4 = rp[k];
-            v |= t4.x | t4.y | t4.z | t4.w;
-        }
-        verdict |= (__builtin_amdgcn_ballot_w64((v & 4u) != 0u) ? 4 : 0) | (__builtin_amdgcn_ballot_w64((v & 8u) != 0u) ? 8 : 0);
+        rv = r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w | r2.x | r2.y | r2.z | r2.w;
+        rv |= v;   // (the verification waves report the range bits themselves when they run)
+        verdict = (__builtin_amdgcn_ballot_w64((v & 1u) != 0u) ? 1 : 0) | (__builtin_amdgcn_ballot_w64((v & 2u) != 0u) ? 2 : 0) |
+                  (__builtin_amdgcn_ballot_w64((rv & 4u) != 0u) ? 4 : 0) | (__builtin_amdgcn_ballot_w64((rv & 8u) != 0u) ? 8 : 0);
     }
     if (blockIdx.x == 0 && lane == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
@@ -1990,7 +2064,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                         const bool last_group = final_batch && nnext == 0;
                         if (last_group && lane == 0)
                             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
-                        {
+                            {
                             const float opa = live ? r0.w : 0.f;
                             const float v[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
                             if (h == 0) {
@@ -2323,6 +2397,28 @@ static void launch_render_exp(int flags, bool dense_candidate, const RenderArgs 
     else launch_render<VARIANT, kExpFast, false>(dense_candidate, r, stream);
 }
 
+void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, int D, const float *pts, const int *points_int,
+                              const float *means3D, const int *means3D_int, const float *opacity, const float *semantics,
+                              const int *radii, const float *cov3D, const SplatWorkspace &ws, hipStream_t stream)
+{
+    PrepArgs pa;
+    pa.means3D = means3D; pa.means_int = means3D_int; pa.opacity = opacity; pa.semantics = semantics;
+    pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.pts = pts; pa.records = ws.records; pa.boxes = ws.boxes;
+    pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
+    pa.nwords = ws.nwords; pa.nrow = ws.nrow; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
+    const int prep_waves = P >= 65536 ? 4 : 1;
+    pa.variant = GF_SPLAT_BASE; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = 0;
+    pa.prescale = 0; pa.exact_det = 0; pa.lattice = 0;
+    pa.tile_counters = ws.flags + 4608;   // the backward kernel claims its units from the same eight per-XCD counters
+    pa.tile_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);
+    pa.range_flags = nullptr;
+    pa.unit_alloc = ws.bwd_alloc; pa.unit_big = ws.bwd_big; pa.unit_cap = ws.bwd_cap;
+    const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
+                            (prep_waves > 1 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
+    if (prep_waves == 1) hipLaunchKernelGGL(gf_splat_prep_kernel<1>, dim3(pa.nprep_blocks), dim3(64), prep_lds, stream, pa);
+    else hipLaunchKernelGGL(gf_splat_prep_kernel<4>, dim3(pa.nprep_blocks), dim3(256), prep_lds, stream, pa);
+}
+
 }  // namespace gf
 
 namespace gf { static unsigned long long *g_timeline = nullptr; static const int *g_tile_perm = nullptr; }
@@ -2398,8 +2494,9 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
     pa.lattice = (mfma && verify) ? 1 : 0;
     uint32_t *tile_counters = ws.flags + 4608;  // [64 x], x < 8: inside the 32 KB flag section, past the verdicts
+    pa.unit_alloc = nullptr; pa.unit_big = nullptr; pa.unit_cap = 0u;
     pa.tile_counters = mfma ? tile_counters : nullptr;
-    pa.range_flags = mfma ? ws.range_flags : nullptr;
+    pa.range_flags = (mfma && !verify) ? ws.range_flags : nullptr;   // (with the point scans running, their waves take the range verdicts)
     pa.tile_counter_init = !mfma ? 0u
                            : mfma_by_wave(ws.nrow) ? (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8)
                                                    : (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8);
@@ -2424,7 +2521,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
     ra.tile_counters = tile_counters;
-    ra.range_flags = mfma ? ws.range_flags : nullptr;
+    ra.range_flags = (mfma && !verify) ? ws.range_flags : nullptr;
     ra.nrange4 = (ws.nwords + 3) / 4;
     if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);

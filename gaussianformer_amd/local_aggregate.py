@@ -461,6 +461,8 @@ class LocalAggregator(_AggregatorBase):
         self.inv_softmax = inv_softmax
         self.check_inputs = check_inputs
         self._pc_min_host = [float(v) for v in pc_min]
+        self._grid_exact = None     # grid_is_exact_lattice(...) of this module's grid, judged on first use
+        self._registered = None     # register_grid()
 
     def register_grid(self, pts):
         """Optional: verify ONCE that ``pts [1, H*W*D, 3]`` (or ``[H*W*D, 3]``) is the dense grid -- point n in voxel n and an

@@ -62,7 +62,8 @@ extern "C" {
  * §3.2b; measured 1.7e-5 / 3.1e-5 from the reference's own kernels at gs25600 / gs144000, tolerance 1e-4).  This is
  * the DEFAULT whenever it applies: base variant, N == H*W*D without GF_PTS_GENERAL, no label epilogue, none of the
  * three exp-flavour flags and no GF_EXACT_FP32.  It needs pts to be an exact affine lattice of voxel centres and
- * operands inside the f16 range (|theta| < 3e4 by a per-Gaussian bound, |opacity * semantics| < 3e4).  The lattice is
+ * operands the split-f16 arithmetic carries to 1e-4 (per-Gaussian bounds on theta: |theta| < 3e4 and an accuracy bound on
+ * the bricks around the mean -- an isotropic Gaussian on a 0.5 m grid: sigma >= 0.056 m; |opacity * semantics| < 64).  The lattice is
  * verified on the device with GF_PTS_AUTO and asserted by the caller with GF_PTS_ASSUME_DENSE (a static property of the
  * grid); the two range conditions depend on each frame's Gaussians and are verified in the records pass of EVERY call,
  * whatever the pts flag.  A call that fails any verdict runs the arbitrary-points body instead (correct, ~7x slower;
@@ -93,8 +94,8 @@ size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D);
  *   [1] GF_PATH_* -- the body that rendered the forward (a GF_PATH_ARBITRARY on an N == H*W*D call is the slow
  *       fall-back of a failed verdict: visible to the caller after its next synchronisation)
  *   [2] verdict bits of the device-side checks: 1 = a point is not in its voxel, 2 = pts is not an exact affine
- *       lattice, 4 = a Gaussian's quadratic-form coefficients may leave the f16 range, 8 = a Gaussian's
- *       |opacity * semantics| may (4 and 8: matrix-core kernel only, checked on every call) */
+ *       lattice, 4 = a Gaussian's quadratic-form coefficients may leave the range the kernel is accurate in, 8 = a Gaussian's
+ *       |opacity * semantics| is 64 or more (4 and 8: matrix-core kernel only, checked on every call) */
 size_t gf_splat_state_bytes(void);
 
 /*

@@ -248,8 +248,9 @@ def _run_default(gpu, si, pi, mi, radii, cov6, flags=0):
 
 @pytest.mark.parametrize("assume_dense", [False, True])
 def test_mfma_large_semantics_fall_back(gpu, assume_dense):
-    """opacity * semantics beyond the f16 range (cvt_pkrtz saturates at 65 504) must not reach the split-f16
-    operands.  The records pass flags it (verdict bit 3) on EVERY call -- GF_PTS_ASSUME_DENSE skips the point scans, not
+    """a large opacity * semantics must not reach the split-f16 operands (cvt_pkrtz saturates at 65 504, and long
+    before that the 2^-24 absolute resolution of the f16 weights, multiplied by S', leaves the tolerance: measured 1.7e-3 at
+    S' = 2.9e4).  The records pass flags |S'| >= 64 (verdict bit 3) on EVERY call -- GF_PTS_ASSUME_DENSE skips the point scans, not
     the range verdicts -- and the arbitrary-points body renders the call: default flags, against the
     reference's own kernels."""
     from gaussianformer_amd import _lib
@@ -267,9 +268,9 @@ def test_mfma_large_semantics_fall_back(gpu, assume_dense):
     got, state = _run_default(gpu, si, pi, mi, radii, cov6, flags)
     assert state[1:] == [_lib.GF_PATH_ARBITRARY, 8]
     assert_logits_close(got, _reference_logits(si, pi, mi, radii, cov6), tol=1e-4)
-    # ... and just inside the bound the call stays on the matrix cores, still within the tolerance
+    # ... and just inside the bound (|opacity * semantics| < 64) the call stays on the matrix cores, still within the tolerance
     si.opacities[123] = np.float32(1.0)
-    si.semantics[123, 4] = np.float32(2.9e4)
+    si.semantics[123, 4] = np.float32(63.0)
     got, state = _run_default(gpu, si, pi, mi, radii, cov6, flags)
     assert state == [0, _lib.GF_PATH_MATRIX_CORE_WAVE, 0]
     assert_logits_close(got, _reference_logits(si, pi, mi, radii, cov6), tol=1e-4)
@@ -293,8 +294,8 @@ def test_mfma_adversarial_inputs_just_inside_the_verdicts(gpu, seed):
     """the default kernel's margin was measured on one seed of one distribution.  Here a third of the Gaussians
     sit JUST INSIDE the records pass's accuracy verdict (0.72 (4.3 + sqrt Q)^2 in [900, 1190) -- thinner than anything the
     nuScenes configs produce: isotropic sigma down to 0.057 m, one thin axis down to 0.02 m), with rotated covariances and
-    the largest radius the overflow bound admits, and the semantics span nine orders of magnitude (x 1e-6 ... x 1e3).  The
-    call must stay on the matrix cores and stay within 1e-4 (scaled) of the reference's own kernels."""
+    the largest radius the overflow bound admits, and the semantics span six orders of magnitude (x 1e-6 ... x 1, inside the
+    |opacity * semantics| < 64 verdict).  The call must stay on the matrix cores and stay within 1e-4 (scaled) of the reference's own kernels."""
     from gaussianformer_amd import _lib
     rng = np.random.default_rng(seed)
     si = make_splat_inputs("nuscenes_gs144000" if seed % 2 else "nuscenes_gs25600_solid", seed=seed, P=900, H=40, W=32, D=16)
@@ -325,7 +326,7 @@ def test_mfma_adversarial_inputs_just_inside_the_verdicts(gpu, seed):
         radii[g] = r
     b, n = _range_bounds(cov6, radii, si.H, si.W, si.D)
     assert (b < 3e4).all() and (n < 1200).all() and (n[pick] > 880).all()
-    scale = np.float32(10.0) ** rng.integers(-6, 4, size=(P, 1)).astype(np.float32)
+    scale = np.float32(10.0) ** rng.integers(-6, 1, size=(P, 1)).astype(np.float32)
     si.semantics = (si.semantics * scale).astype(np.float32)
     want = _reference_logits(si, pi, mi, radii, cov6)
     got, state = _run_default(gpu, si, pi, mi, radii, cov6)
@@ -333,7 +334,7 @@ def test_mfma_adversarial_inputs_just_inside_the_verdicts(gpu, seed):
     assert_logits_close(got, want, tol=1e-4)
     # one step over the accuracy bound: the verdict notices and the call is still right
     g = int(pick[0])
-    cov6[g] *= np.float32(1.25)
+    cov6[g] *= np.float32(2.0)
     assert _range_bounds(cov6[g][None], radii[g:g + 1], si.H, si.W, si.D)[1][0] > 1200
     got, state = _run_default(gpu, si, pi, mi, radii, cov6)
     assert state == [0, _lib.GF_PATH_ARBITRARY, 4]
