@@ -17,7 +17,8 @@
 //   1. exponent   D'[v,g] = phi(u_v) . theta(g) + box term -- the forward's four v_mfma_f32_32x32x16_f16 with the operands
 //                 SWAPPED (A = monomials / one-hot coordinates of the voxels, B = split theta of the Gaussians), so that the
 //                 result has lane = Gaussian, register = voxel: the B-operand layout of a contraction over voxels;
-//   2. T'[v,g]    nine v_mfma_f32_32x32x2_f32 (exact fp32): A = dL[v][c] straight from the staged rows, B = sem[g][c];
+//   2. T'[v,g]    six v_mfma_f32_32x32x16_f16 (K = 18 channels in two chunks; hi hi + hi lo + lo hi): A = dL[v][c] from the staged
+//                 rows, B = sem[g][c], both scaled by powers of two and split into f16 hi + lo;
 //   3. e = exp2(D'), K = e T'; both split into f16 hi + lo in registers (they ARE B operands already);
 //   4. moments    M += Phi^T (K_hi + K_lo): 4 MFMAs;   dsem  += dL^T (e_hi + e_lo), dL split hi + lo: 6 MFMAs.
 // Per Gaussian and double brick the 28 sums leave as ONE 128-byte row of a partial buffer (rows handed out by the records
@@ -30,6 +31,8 @@
 //
 // The kernel applies where the forward's matrix-core kernel does (dense exact lattice, theta in range: word 1 of the
 // forward's state block says a matrix-core body rendered the call) and to rows of <= kWRow bitmask words.
+#include <algorithm>
+
 #include "gf_common.hpp"
 
 #ifndef GF_TIMELINE
@@ -135,15 +138,12 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_zero_kernel(BwdZeroArgs a)
     if (blockIdx.x == 0 && threadIdx.x < 64) a.alloc[threadIdx.x] = 0u;
     if (a.gate == 1 && !state_is_matrix_core(a.state)) return;
     const float fill = (a.gate == 2 && !state_is_matrix_core(a.state)) ? __uint_as_float(0x7fc00000u) : 0.f;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.P) {
-        a.opa_grad[i] = fill;
-        a.means_grad[3 * (size_t)i] = fill; a.means_grad[3 * (size_t)i + 1] = fill; a.means_grad[3 * (size_t)i + 2] = fill;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a.cov_grad[6 * (size_t)i + k] = fill;
-#pragma unroll
-        for (int k = 0; k < kC; ++k) a.sem_grad[(size_t)kC * i + k] = fill;
-    }
+    // the four arrays as flat runs of floats, grid-strided (coalesced dword stores; the arrays need not be 16-byte aligned)
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t i = i0; i < (size_t)kC * a.P; i += stride) a.sem_grad[i] = fill;
+    for (size_t i = i0; i < (size_t)6 * a.P; i += stride) a.cov_grad[i] = fill;
+    for (size_t i = i0; i < (size_t)3 * a.P; i += stride) a.means_grad[i] = fill;
+    for (size_t i = i0; i < (size_t)a.P; i += stride) a.opa_grad[i] = fill;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -159,7 +159,8 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     if (a.gate && !state_is_matrix_core(a.state)) return;
 
     const int lane = threadIdx.x;
-    const int n = lane & 31, h = lane >> 5;
+    const int n_ = lane & 31, h_ = lane >> 5;
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     const int xcd = (int)(blockIdx.x & 7u);
     const int per_super = 4 * ((a.D + 7) >> 3);
     const int nunits = a.nsx * a.nsy * per_super;
@@ -177,61 +178,12 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     const double sy = a.W > 1 ? (double)cp[3 * (size_t)a.D + 1] - p0y : 1.0;
     const double sz = a.D > 1 ? (double)cp[3 + 2] - p0z : 1.0;
 
-    // A operands of the exponent MFMAs: monomials (phi) and one-hot coordinates (hot) of voxel n of each block.  The one-hot
-    // operand of half 0 (x, y) only depends on b & 1 and that of half 1 (z) on b >> 1: two registers sets, selected per block.
-    h8 phi[4], hotv[2];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const float ux_ = (float)(2 * (b & 1) + (n >> 4)) - 1.5f, uy_ = (float)((n >> 2) & 3) - 1.5f,
-                    uz_ = (float)(4 * (b >> 1) + (n & 3)) - 3.5f;
-        const float m0[8] = {1.f, ux_, uy_, uz_, ux_ * ux_, 0.f, 0.f, 0.f};
-        const float m1[8] = {uy_ * uy_, uz_ * uz_, ux_ * uy_, uy_ * uz_, ux_ * uz_, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) phi[b][j] = (_Float16)(h ? m1[j] : m0[j]);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {   // half 0: block parity k (lx = 2 k + (n >> 4)); half 1: z brick k (zz = 4 k + (n & 3))
-        const int lx = 2 * k + (n >> 4), ly = (n >> 2) & 3, zz = 4 * k + (n & 3);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) hotv[k][j] = (_Float16)((h ? zz == j : (j < 4 ? lx == j : ly == j - 4)) ? 1.f : 0.f);
-    }
-    // A operand of the moment MFMAs: row r = lane & 31 holds monomial m(r) for r in {0,1,2,3, 8,9,10,11, 16,17} (the rows half 0
-    // of a lane receives in registers 0..9 of the D fragment), K element j of chunk kc = voxel (q & 3) + 8 (q >> 2) + 4 h of the
-    // block, q = 8 kc + j -- the voxel that register q of the exponent fragment holds in this half: x index kc, y index
-    // h + 2 (j >> 2), z index j & 3.  A monomial is a product of per-axis powers, so the eight values of an operand are
-    // X(b & 1, kc) * Y(j >> 2) * Z(b >> 1, j & 3): twelve registers of factors instead of a 32-register table, four packed
-    // multiplies per operand (all values are small dyadic rationals: exact in f16).
-    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-    half2_t xy2[4][2], z2[2][2];   // xy2[2 (b & 1) + kc][jy] = (X Y, X Y);  z2[b >> 1][0 / 1] = (Z(z = 0), Z(1)) / (Z(2), Z(3))
-    {
-        const int mono = (n & 4) ? -1 : ((n & 3) + 4 * (n >> 3));   // rows 0-3 -> 0-3, 8-11 -> 4-7, 16,17 -> 8,9
-        const int pa[10] = {0, 1, 0, 0, 2, 0, 0, 1, 0, 1}, pb[10] = {0, 0, 1, 0, 0, 2, 0, 1, 1, 0}, pc[10] = {0, 0, 0, 1, 0, 0, 2, 0, 1, 1};
-        int ea = 0, eb = 0, ec = 0;
-#pragma unroll
-        for (int m = 0; m < 10; ++m) {
-            ea = mono == m ? pa[m] : ea; eb = mono == m ? pb[m] : eb; ec = mono == m ? pc[m] : ec;
-        }
-        const bool valid_row = mono >= 0 && mono < 10;
-        auto pw = [](float x, int e) { return e == 0 ? 1.f : (e == 1 ? x : x * x); };
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int jy = 0; jy < 2; ++jy) {
-                const float v = valid_row ? pw((float)t - 1.5f, ea) * pw((float)(h + 2 * jy) - 1.5f, eb) : 0.f;
-                xy2[t][jy] = (half2_t){(_Float16)v, (_Float16)v};
-            }
-#pragma unroll
-        for (int bz = 0; bz < 2; ++bz)
-#pragma unroll
-            for (int zp = 0; zp < 2; ++zp)
-                z2[bz][zp] = (half2_t){(_Float16)pw((float)(4 * bz + 2 * zp) - 3.5f, ec), (_Float16)pw((float)(4 * bz + 2 * zp + 1) - 3.5f, ec)};
-    }
-
     auto request_records_at = [&](int qh, int start, int count) {
-        const uint32_t id = q_id[(qh + start + (n < count ? n : 0)) & (kMQCap - 1)];
+        const uint32_t id = q_id[(qh + start + (n_ < count ? n_ : 0)) & (kMQCap - 1)];
         const char *rec = reinterpret_cast<const char *>(a.records + (size_t)id * kRecDwords);
-        // half 0: mean/opacity, cov, cov + box, semantics 0..11;  half 1: the same three, semantics 8..19 (+ first row)
-        const int o3 = (3 + 2 * h) * 16, o4 = (4 + 2 * h) * 16, o5 = (5 + 2 * h) * 16;
+        // both halves: mean / opacity, covariance, covariance + box, and piece 7 (semantics 16, 17; dword 31 = first row);
+        // half 0: semantics 0..7 (pieces 3, 4), half 1: semantics 8..15 (pieces 5, 6)
+        const int o3 = (3 + 2 * h_) * 16, o4 = (4 + 2 * h_) * 16, o5 = 7 * 16;
         char *dst = reinterpret_cast<char *>(slot);
         __builtin_amdgcn_global_load_lds((gptr)(rec), (lptr)(dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr)(rec + 16), (lptr)(dst + 1024), 16, 0, 0);
@@ -246,9 +198,34 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                 __builtin_amdgcn_global_load_lds((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
     };
 
+    // a unit's bitmask row and its 128 gradient rows, both by LDS-DMA: the rows as 36 four-byte gathers, one per (channel, half of
+    // the unit) -- lane = voxel in block order -- so that they land TRANSPOSED, [channel][voxel], with no register or VALU in
+    // between (a first version carried them through 36 registers and an LDS scatter: the registers spilled and a unit spent 23
+    // of its 41 us there).  ok[half] = the lane's voxel of that half lies inside the grid.
+    auto request_unit = [&](int s_, int Xw_, int Y0_, int Zw_, bool (&ok)[2]) {
+        request_row(a.bitmask + (size_t)s_ * a.nrow);
+        const int lx = 2 * (lane >> 5) + ((lane >> 4) & 1), ly = (lane >> 2) & 3;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int z = 4 * half + (lane & 3);
+            ok[half] = Xw_ + lx < a.H && Y0_ + ly < a.W && Zw_ + z < a.D;
+            const size_t vox = ok[half] ? ((size_t)(Xw_ + lx) * a.W + (Y0_ + ly)) * a.D + (Zw_ + z) : 0;
+            const float *src = a.out_grad + vox * kC;
+#pragma unroll
+            for (int ch = 0; ch < kC; ++ch) {
+                __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(s_dl + ch * kMPitch + 64 * half), 4, 0, 0);
+                // (one address register pair stepped from request to request: left alone hipcc forms all 36 addresses first -- 72
+                // registers, spilled -- and a spill reloaded behind these requests waits for every one of them)
+                src += 1;
+                asm volatile("" : "+v"(src));
+            }
+        }
+    };
+
     uint32_t *ctr = a.tile_counters + 64 * xcd;
     const int nchunk = (a.nwords + 63) >> 6;
     int local = (int)(blockIdx.x >> 3);
+    bool dl_ok[2] = {false, false};
     while (true) {  // units of this wave
         const int logical = xcd * per_xcd + local;
         if (!(local < per_xcd && logical < nunits)) break;
@@ -260,25 +237,10 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #if GF_TIMELINE
             unsigned long long tl[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
 #endif
-            // ---- the unit's bitmask row and its 128 gradient rows, both by LDS-DMA: the rows as 36 four-byte gathers, one per
-            // (channel, half of the unit) -- lane = voxel in block order -- so that they land TRANSPOSED, [channel][voxel], with
-            // no register or VALU in between (a first version carried them through 36 registers and an LDS scatter: the
-            // registers spilled and the unit spent 23 of its 41 us there)
-            request_row(a.bitmask + (size_t)s * a.nrow);
-            bool dl_ok[2];
-            {
-                const int lx = 2 * (lane >> 5) + ((lane >> 4) & 1), ly = (lane >> 2) & 3;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int z = 4 * half + (lane & 3);
-                    dl_ok[half] = Xw + lx < a.H && Y0 + ly < a.W && Zw + z < a.D;
-                    const size_t vox = dl_ok[half] ? ((size_t)(Xw + lx) * a.W + (Y0 + ly)) * a.D + (Zw + z) : 0;
-                    const float *src = a.out_grad + vox * kC;
-#pragma unroll
-                    for (int ch = 0; ch < kC; ++ch)
-                        __builtin_amdgcn_global_load_lds((gptr)(src + ch), (lptr)(s_dl + ch * kMPitch + 64 * half), 4, 0, 0);
-                }
-            }
+            // ---- the unit's bitmask row and gradient rows (request_unit)
+            // (Requesting them from the previous unit's last group, ahead of its row stores, was built and measured: the row wait
+            // disappears, but the 36 requests cost that group the same two microseconds of issue time -- 79 against 74 us.)
+            request_unit(s, Xw, Y0, Zw, dl_ok);
             // (36 requests were issued behind the row's: "at most 36 outstanding" = the row has landed)
             asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
 #if GF_TIMELINE
@@ -295,14 +257,19 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                 const int kw = nchunk;
                 unsigned long long wd[kWPer];
                 int mine = 0;
+                // (the ten LDS addresses are the same for every unit: hipcc hoists them out of the unit loop, they do not survive the
+                // loop's register pressure, and a spill reloaded here waits behind the 36 gather requests -- so they are formed here)
+                int wlane = lane;
+                asm volatile("" : "+v"(wlane));
+                const int wbase = kw * wlane;
 #pragma unroll
-                for (int k = 0; k < kWPer; ++k) wd[k] = s_row[min(kw * lane + k, kWRow - 1)];
+                for (int k = 0; k < kWPer; ++k) wd[k] = s_row[min(wbase + k, kWRow - 1)];
                 static_assert(kWPer == 10, "operand list below");
                 asm volatile("" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]), "+v"(wd[3]), "+v"(wd[4]), "+v"(wd[5]), "+v"(wd[6]), "+v"(wd[7]),
                              "+v"(wd[8]), "+v"(wd[9]));
 #pragma unroll
                 for (int k = 0; k < kWPer; ++k) {
-                    const int w = kw * lane + k;
+                    const int w = wbase + k;
                     wd[k] = (k < kw && w < a.nwords) ? wd[k] : 0ull;
                     mine += wd[k] != 0ull ? 1 : 0;
                 }
@@ -313,7 +280,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #pragma unroll
                     for (int k = 0; k < kWPer; ++k) {
                         if (wd[k] != 0ull) {
-                            s_dw[p] = (uint32_t)(kw * lane + k);
+                            s_dw[p] = (uint32_t)(wbase + k);
                             s_db[p] = wd[k];
                             ++p;
                         }
@@ -423,6 +390,61 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
             const int dex = min(254, max(5, (int)((__float_as_uint(dmax) >> 23) & 255u)));
             const float dscale = dmax > 0.f ? __uint_as_float((uint32_t)(258 - dex) << 23) : 1.f;   // 2^(131 - dex)
             const int dshift = dmax > 0.f ? dex - 131 : 0;   // true value = scaled value * 2^dshift
+            // ---- per-lane constant operands (monomials, one-hot coordinates, moment factors).  They do not depend on the unit, but
+            // formed once per kernel they stay live through the list phases above, which then spill -- and a spill reloaded behind
+            // the gather requests waits for every one of them.  Formed here, from opaque copies of the lane coordinates, they live
+            // only while the groups run (~100 VALU per unit).
+            int n = n_, h = h_;
+            asm volatile("" : "+v"(n), "+v"(h));
+            // A operands of the exponent MFMAs: monomials (phi) and one-hot coordinates (hot) of voxel n of each block.  The one-hot
+            // operand of half 0 (x, y) only depends on b & 1 and that of half 1 (z) on b >> 1: two registers sets, selected per block.
+            h8 phi[4], hotv[2];
+        #pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float ux_ = (float)(2 * (b & 1) + (n >> 4)) - 1.5f, uy_ = (float)((n >> 2) & 3) - 1.5f,
+                            uz_ = (float)(4 * (b >> 1) + (n & 3)) - 3.5f;
+                const float m0[8] = {1.f, ux_, uy_, uz_, ux_ * ux_, 0.f, 0.f, 0.f};
+                const float m1[8] = {uy_ * uy_, uz_ * uz_, ux_ * uy_, uy_ * uz_, ux_ * uz_, 0.f, 0.f, 0.f};
+        #pragma unroll
+                for (int j = 0; j < 8; ++j) phi[b][j] = (_Float16)(h ? m1[j] : m0[j]);
+            }
+        #pragma unroll
+            for (int k = 0; k < 2; ++k) {   // half 0: block parity k (lx = 2 k + (n >> 4)); half 1: z brick k (zz = 4 k + (n & 3))
+                const int lx = 2 * k + (n >> 4), ly = (n >> 2) & 3, zz = 4 * k + (n & 3);
+        #pragma unroll
+                for (int j = 0; j < 8; ++j) hotv[k][j] = (_Float16)((h ? zz == j : (j < 4 ? lx == j : ly == j - 4)) ? 1.f : 0.f);
+            }
+            // A operand of the moment MFMAs: row r = lane & 31 holds monomial m(r) for r in {0,1,2,3, 8,9,10,11, 16,17} (the rows half 0
+            // of a lane receives in registers 0..9 of the D fragment), K element j of chunk kc = voxel (q & 3) + 8 (q >> 2) + 4 h of the
+            // block, q = 8 kc + j -- the voxel that register q of the exponent fragment holds in this half: x index kc, y index
+            // h + 2 (j >> 2), z index j & 3.  A monomial is a product of per-axis powers, so the eight values of an operand are
+            // X(b & 1, kc) * Y(j >> 2) * Z(b >> 1, j & 3): twelve registers of factors instead of a 32-register table, four packed
+            // multiplies per operand (all values are small dyadic rationals: exact in f16).
+            
+            half2_t xy2[4][2], z2[2][2];   // xy2[2 (b & 1) + kc][jy] = (X Y, X Y);  z2[b >> 1][0 / 1] = (Z(z = 0), Z(1)) / (Z(2), Z(3))
+            {
+                const int mono = (n & 4) ? -1 : ((n & 3) + 4 * (n >> 3));   // rows 0-3 -> 0-3, 8-11 -> 4-7, 16,17 -> 8,9
+                const int pa[10] = {0, 1, 0, 0, 2, 0, 0, 1, 0, 1}, pb[10] = {0, 0, 1, 0, 0, 2, 0, 1, 1, 0}, pc[10] = {0, 0, 0, 1, 0, 0, 2, 0, 1, 1};
+                int ea = 0, eb = 0, ec = 0;
+        #pragma unroll
+                for (int m = 0; m < 10; ++m) {
+                    ea = mono == m ? pa[m] : ea; eb = mono == m ? pb[m] : eb; ec = mono == m ? pc[m] : ec;
+                }
+                const bool valid_row = mono >= 0 && mono < 10;
+                auto pw = [](float x, int e) { return e == 0 ? 1.f : (e == 1 ? x : x * x); };
+        #pragma unroll
+                for (int t = 0; t < 4; ++t)
+        #pragma unroll
+                    for (int jy = 0; jy < 2; ++jy) {
+                        const float v = valid_row ? pw((float)t - 1.5f, ea) * pw((float)(h + 2 * jy) - 1.5f, eb) : 0.f;
+                        xy2[t][jy] = (half2_t){(_Float16)v, (_Float16)v};
+                    }
+        #pragma unroll
+                for (int bz = 0; bz < 2; ++bz)
+        #pragma unroll
+                    for (int zp = 0; zp < 2; ++zp)
+                        z2[bz][zp] = (half2_t){(_Float16)pw((float)(4 * bz + 2 * zp) - 3.5f, ec), (_Float16)pw((float)(4 * bz + 2 * zp + 1) - 3.5f, ec)};
+            }
             const double Cx = p0x + ((double)Xw + 1.5) * sx, Cy = p0y + ((double)Y0 + 1.5) * sy, Cz = p0z + ((double)Zw + 3.5) * sz;
             bool have_next = false;
             bool stores_behind = false;   // the newest record request has a group's six row stores behind it
@@ -450,15 +472,19 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                         list_len += total;
                         ++c;
                     } else {
+                        // more candidates than the list holds: the chunk goes in by sixteen lane groups of four words (<= 256 = kMList
+                        // candidates each, so a group always fits an empty list -- with groups of eight words a crowded supertile never
+                        // got past its first group)
+                        static_assert(4 * 64 <= kMList, "a lane group of four words fits the empty list");
                         bool full = false;
-                        for (; sg < 8; ++sg) {
-                            const int e1 = __builtin_amdgcn_readlane(incl, 8 * sg + 7);
-                            const int e0 = sg ? __builtin_amdgcn_readlane(incl, 8 * sg - 1) : 0;
+                        for (; sg < 16; ++sg) {
+                            const int e1 = __builtin_amdgcn_readlane(incl, 4 * sg + 3);
+                            const int e0 = sg ? __builtin_amdgcn_readlane(incl, 4 * sg - 1) : 0;
                             if (list_len + (e1 - e0) > kMList) {
                                 full = true;
                                 break;
                             }
-                            if ((lane >> 3) == sg) pos = list_len + (incl - cnt) - e0;
+                            if ((lane >> 2) == sg) pos = list_len + (incl - cnt) - e0;
                             list_len += e1 - e0;
                         }
                         if (!full) {
@@ -538,24 +564,41 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                         const bool last_group = final_batch && nnext == 0;
                         if (last_group && lane == 0)
                             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
-                        // ---- B operand of the T contraction: semantics, nine channels per half (half 0: 0..8, half 1: 9..17), scaled
-                        // per Gaussian by a power of two to max |sem| in [0.5, 1)
-                        float sb[9];
+                        // ---- B operands of the T contraction, T'[v, g] = sum_c dL[v][c] sem[g][c] over K = 32 (two chunks): chunk 0 =
+                        // channels 8 h + j, chunk 1 = channels 16, 17 in elements 0, 1 of half 0.  The semantics are scaled per Gaussian
+                        // by a power of two to max |sem| in [0.5, 1) and split into f16 hi + lo.  (A first version ran this contraction as
+                        // nine exact-fp32 MFMAs per block: 576 dependent cycles per block against 192 here.)
+                        H8 b0h, b0l, b1h, b1l;
+                        int sshift = 0;
                         {
-                            const float lo9[9] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};    // half 0: pieces 3, 4, 5 = ch 0..11
-                            const float hi9[9] = {e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y};    // half 1: pieces 5, 6, 7 = ch 8..19
+                            float sv[10] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y};   // e0, e1: channels 8 h .. 8 h + 7; e2.xy: 16, 17
+                            float smax = 0.f;
 #pragma unroll
-                            for (int j = 0; j < 9; ++j) sb[j] = live ? (h ? hi9[j] : lo9[j]) : 0.f;
+                            for (int j = 0; j < 10; ++j) {
+                                sv[j] = live ? sv[j] : 0.f;
+                                smax = fmaxf(smax, fabsf(sv[j]));
+                            }
+                            smax = fmaxf(smax, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, smax))));
+                            const int sex = min(252, (int)((__float_as_uint(smax) >> 23) & 255u));
+                            const float sscale = smax > 0.f ? __uint_as_float((uint32_t)(253 - sex) << 23) : 1.f;   // 2^(126 - sex)
+                            sshift = smax > 0.f ? sex - 126 : 0;   // true semantics = operand * 2^sshift
+#pragma unroll
+                            for (int j = 0; j < 10; ++j) sv[j] *= sscale;
+                            if (h) { sv[8] = 0.f; sv[9] = 0.f; }
+                            const fp16x2 zz = __builtin_amdgcn_cvt_pkrtz(0.f, 0.f);
+#pragma unroll
+                            for (int j = 0; j < 10; j += 2) {
+                                const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(sv[j], sv[j + 1]);
+                                float q0, q1;
+                                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(hh), "v"(sv[j]));
+                                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(hh), "v"(sv[j + 1]));
+                                const fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(q0, q1);
+                                if (j < 8) { b0h.p[j >> 1] = hh; b0l.p[j >> 1] = ll; }
+                                else { b1h.p[0] = hh; b1l.p[0] = ll; }
+                            }
+#pragma unroll
+                            for (int j = 1; j < 4; ++j) { b1h.p[j] = zz; b1l.p[j] = zz; }
                         }
-                        float smax = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 9; ++j) smax = fmaxf(smax, fabsf(sb[j]));
-                        smax = fmaxf(smax, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, smax))));
-                        const int sex = min(252, (int)((__float_as_uint(smax) >> 23) & 255u));
-                        const float sscale = smax > 0.f ? __uint_as_float((uint32_t)(253 - sex) << 23) : 1.f;
-                        const int sshift = smax > 0.f ? sex - 126 : 0;   // true semantics = operand * 2^sshift
-#pragma unroll
-                        for (int j = 0; j < 9; ++j) sb[j] = (sb[j] * sscale) * dscale;   // T' = T 2^-(sshift + dshift); two exact steps (the product of the scales may overflow)
                         // ---- B operands of the exponent: theta in fp64, three f16 terms (the forward's A operands)
                         H8 t1, t2, t3;
                         double ex = 0, ey = 0, ez = 0;
@@ -594,28 +637,59 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                         for (int q = 0; q < 16; ++q) { mom[q] = 0.f; dsm[q] = 0.f; }
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
-                            // one-hot operand of this block: half 0 takes set b & 1, half 1 set b >> 1
-                            const int sel = h ? (b >> 1) : (b & 1);
+                            // one-hot operand of this block: half 0 takes set b & 1, half 1 set b >> 1 (selected register by register:
+                            // indexing the two sets with a per-lane index sends them through scratch memory)
+                            typedef int i32x4 __attribute__((ext_vector_type(4)));
+                            const i32x4 hv0 = __builtin_bit_cast(i32x4, hotv[0]), hv1 = __builtin_bit_cast(i32x4, hotv[1]);
+                            i32x4 hs;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) hs[j] = (b == 0) ? hv0[j] : (b == 3) ? hv1[j] : ((b == 1) == (h != 0)) ? hv0[j] : hv1[j];
                             H8 hot;
+                            hot.v = __builtin_bit_cast(h8, hs);
+                            // T'[v, g]: A = this block's gradient rows (lane = voxel, chunk 0 = channels 8 h + j, chunk 1 = channels 16, 17),
+                            // scaled and split hi + lo; six MFMAs (lo hi + hi lo + hi hi per chunk)
+                            f32x16 T;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const H8 v0 = {hotv[0]}, v1 = {hotv[1]};
-                                hot.p[j] = sel ? v1.p[j] : v0.p[j];
+                            for (int q = 0; q < 16; ++q) T[q] = 0.f;
+                            {
+                                const float *dlp = s_dl + (8 * h) * kMPitch + 32 * b + n;
+                                float av[10];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) av[j] = dlp[j * kMPitch];
+                                av[8] = s_dl[16 * kMPitch + 32 * b + n];
+                                av[9] = s_dl[17 * kMPitch + 32 * b + n];
+                                asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]), "+v"(av[8]), "+v"(av[9]));
+#pragma unroll
+                                for (int j = 0; j < 10; ++j) av[j] *= dscale;
+                                if (h) { av[8] = 0.f; av[9] = 0.f; }
+                                H8 a0h, a0l, a1h, a1l;
+                                const fp16x2 zz = __builtin_amdgcn_cvt_pkrtz(0.f, 0.f);
+#pragma unroll
+                                for (int j = 0; j < 10; j += 2) {
+                                    const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(av[j], av[j + 1]);
+                                    float q0, q1;
+                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(hh), "v"(av[j]));
+                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(hh), "v"(av[j + 1]));
+                                    const fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(q0, q1);
+                                    if (j < 8) { a0h.p[j >> 1] = hh; a0l.p[j >> 1] = ll; }
+                                    else { a1h.p[0] = hh; a1l.p[0] = ll; }
+                                }
+#pragma unroll
+                                for (int j = 1; j < 4; ++j) { a1h.p[j] = zz; a1l.p[j] = zz; }
+                                T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l.v, b0h.v, T, 0, 0, 0);
+                                T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h.v, b0l.v, T, 0, 0, 0);
+                                T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l.v, b1h.v, T, 0, 0, 0);
+                                T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h.v, b1l.v, T, 0, 0, 0);
+                                T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h.v, b1h.v, T, 0, 0, 0);
+                                T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h.v, b0h.v, T, 0, 0, 0);
                             }
-                            f32x16 d, T;
+                            f32x16 d;
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) { d[q] = 0.f; T[q] = 0.f; }
+                            for (int q = 0; q < 16; ++q) d[q] = 0.f;
                             d = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[b], t3.v, d, 0, 0, 0);
                             d = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[b], t2.v, d, 0, 0, 0);
                             d = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[b], t1.v, d, 0, 0, 0);
                             d = __builtin_amdgcn_mfma_f32_32x32x16_f16(hot.v, tb.v, d, 0, 0, 0);
-                            // T'[v, g] = sum_c dL[v][c] sem[g][c]: MFMA j multiplies channel j (half 0) and 9 + j (half 1)
-                            const float *dlp = s_dl + (9 * h) * kMPitch + 32 * b + n;
-                            float av[9];
-#pragma unroll
-                            for (int j = 0; j < 9; ++j) av[j] = dlp[j * kMPitch];
-#pragma unroll
-                            for (int j = 0; j < 9; ++j) T = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], sb[j], T, 0, 0, 0);
                             f32x16 e, K;
 #pragma unroll
                             for (int q = 0; q < 16; ++q) e[q] = __builtin_amdgcn_exp2f(d[q]);
@@ -691,9 +765,8 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #pragma unroll
                                 for (int k = 8; k < 20; ++k) o[k] = 0.f;
                             }
-                            // row of (Gaussian, this double brick): first row from record dword 31 (half 1 fetched piece 7: e2.w)
-                            const uint32_t first_h1 = __float_as_uint(e2.w);
-                            const uint32_t first = (uint32_t)__builtin_amdgcn_ds_bpermute((n + 32) << 2, (int)first_h1);
+                            // row of (Gaussian, this double brick): first row from record dword 31 (piece 7: e2.w in both halves)
+                            const uint32_t first = __float_as_uint(e2.w);
                             const uint32_t glo = __float_as_uint(r2.z), ghi = __float_as_uint(r2.w);
                             const int bx0 = ux(glo) >> 2, by0 = uy(glo) >> 2, bz0 = uz(glo) >> 3;
                             const int nby = ((uy(ghi) - 1) >> 2) - by0 + 1, nbz = ((uz(ghi) - 1) >> 3) - bz0 + 1;
@@ -767,7 +840,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
-// Adds a Gaussian's rows up.  Half a wave per Gaussian, lane = column of the 32-float row, eight rows in flight; the sums
+// Adds a Gaussian's rows up.  Half a wave per Gaussian, lane = column of the 32-float row, sixteen rows in flight; the sums
 // are stored (the gradients were zeroed by gf_splat_bwd_zero_kernel and nothing else writes them, except for the Gaussians
 // without rows, which this kernel leaves alone).  Gaussians of the big list (more than kBwdBigRows rows) are summed by
 // the workgroups past the Gaussian range, 512 rows per workgroup, and combined with float atomics.
@@ -813,20 +886,13 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
         if (cnt == 0 || first == 0xFFFFFFFFu || cnt > kBwdBigRows) return;
         const float *base = a.rows + (size_t)first * kBwdRowDwords + col;
         float acc = 0.f;
-        int r = 0;
-        for (; r + 8 <= cnt; r += 8) {
-            float v[8];
+        // sixteen rows in flight (a Gaussian has 13.5 rows on average: most are summed after one round trip); always the same order
+        for (int r = 0; r < cnt; r += 16) {
+            float v[16];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(r + k) * kBwdRowDwords];
+            for (int k = 0; k < 16; ++k) v[k] = base[(size_t)min(r + k, cnt - 1) * kBwdRowDwords];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc += v[k];
-        }
-        {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = base[(size_t)min(r + k, cnt - 1) * kBwdRowDwords];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc += (r + k < cnt) ? v[k] : 0.f;
+            for (int k = 0; k < 16; ++k) acc += (r + k < cnt) ? v[k] : 0.f;
         }
         bwd_store_column(a, g, col, acc, false);
         return;
@@ -895,7 +961,7 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
                                 const SplatWorkspace &ws, int gate, hipStream_t stream)
 {
     BwdZeroArgs z{means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_alloc, state, P, gate};
-    hipLaunchKernelGGL(gf_splat_bwd_zero_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, z);
+    hipLaunchKernelGGL(gf_splat_bwd_zero_kernel, dim3(std::min(1024, (kC * P + 255) / 256)), dim3(256), 0, stream, z);
     launch_prep_for_backward(radii_per_axis, P, N, H, W, D, pts, points_int, means3D, means3D_int, opacity, semantics, radii,
                              cov3D, ws, stream);
     BwdMArgs a;

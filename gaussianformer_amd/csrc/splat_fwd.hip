@@ -91,6 +91,8 @@ __device__ __forceinline__ float prob_kdet(float c0, float c1, float c2, float c
     return kdet;
 }
 
+constexpr float kSemRangeMax = 64.f;   // |opacity * semantics| below this stays on the matrix cores
+
 // Range verdicts of the matrix-core render kernel for one Gaussian (bit 2: theta, bit 3: opacity * semantics; explained at
 // their use in gf_splat_prep_kernel).  lsx, lsy, lsz = |lattice steps|.
 __device__ __forceinline__ uint32_t range_bits_of(const float *c, const float *sm, float opa, int r0, int r1, int r2, int H, int W,
@@ -110,7 +112,7 @@ __device__ __forceinline__ uint32_t range_bits_of(const float *c, const float *s
         snan |= !(v == v);
         smax = fmaxf(smax, v);
     }
-    return ((!(bound < 3.0e4f) || !(Q < 1331.4f)) ? 4u : 0u) | ((snan || !(smax < 64.f)) ? 8u : 0u);
+    return ((!(bound < 3.0e4f) || !(Q < 1331.4f)) ? 4u : 0u) | ((snan || !(smax < kSemRangeMax)) ? 8u : 0u);
 }
 
 template <int WAVES>
@@ -180,14 +182,34 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         uint32_t rbits = 0u;
         if (a.lattice) {
             const float lx_ = fabsf((float)sx), ly_ = fabsf((float)sy), lz_ = fabsf((float)sz);
+#pragma nounroll
             for (int g = vb * 64 + lane; g < a.P; g += kVerifyBlocks * 64) {
-                float c[6], sm[kC];
+                // (written for few registers -- the kernel's register count must stay the records pass's: the semantics in two
+                // batches of nine with a running maximum, not as an 18-element array)
+                const float *cv = a.cov3D + 6 * (size_t)g;
+                const float *sp = a.semantics + (size_t)kC * g;
+                const float opa = a.opacity[g];
+                const int r0 = a.radii[a.per_axis ? 3 * g : g], r1 = a.radii[a.per_axis ? 3 * g + 1 : g], r2 = a.radii[a.per_axis ? 3 * g + 2 : g];
+                float c[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) c[j] = a.cov3D[6 * (size_t)g + j];
+                for (int j = 0; j < 6; ++j) c[j] = cv[j];
+                const float zero[kC] = {0.f};
+                rbits |= range_bits_of(c, zero, 0.f, r0, r1, r2, a.H, a.W, a.D, lx_, ly_, lz_) & 4u;
+                float smax = 0.f;
+                bool snan = false;
+#pragma nounroll
+                for (int j0 = 0; j0 < kC; j0 += 9) {
+                    float t[9];
 #pragma unroll
-                for (int j = 0; j < kC; ++j) sm[j] = a.semantics[(size_t)kC * g + j];
-                rbits |= range_bits_of(c, sm, a.opacity[g], a.radii[a.per_axis ? 3 * g : g], a.radii[a.per_axis ? 3 * g + 1 : g],
-                                       a.radii[a.per_axis ? 3 * g + 2 : g], a.H, a.W, a.D, lx_, ly_, lz_);
+                    for (int k = 0; k < 9; ++k) t[k] = sp[j0 + k];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float v = fabsf(opa * t[k]);
+                        snan |= !(v == v);
+                        smax = fmaxf(smax, v);
+                    }
+                }
+                rbits |= (snan || !(smax < kSemRangeMax)) ? 8u : 0u;
             }
         }
         const unsigned long long any = __builtin_amdgcn_ballot_w64(bad), any2 = __builtin_amdgcn_ballot_w64(bad_lattice),

@@ -309,6 +309,17 @@ class _LocalAggregate(torch.autograd.Function):
         logits, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, pts, points_int, means3D, means3D_int,
                                                opacities, semantics, radii, cov3D, H, W, D, flags=flags)
         ctx.dims = (H, W, D)
+        ctx.fwd_flags = flags
+        # Which body rendered the call is only known on the device (word 1 of the state block).  The backward has a kernel for
+        # either answer; launched without knowing, both pipelines go out, each gated on that word.  So the three words are copied
+        # to pinned host memory behind an event -- never waited for: by the time the backward runs the copy has usually landed
+        # and exactly one pipeline is launched (not while a HIP graph is being captured: no host allocation there).
+        ctx.state_host = ctx.state_event = None
+        if any(ctx.needs_input_grad) and not torch.cuda.is_current_stream_capturing():
+            ctx.state_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+            ctx.state_host.copy_(state[:12].view(torch.int32), non_blocking=True)
+            ctx.state_event = torch.cuda.Event()
+            ctx.state_event.record(torch.cuda.current_stream(pts.device))
         ctx.save_for_backward(state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii)
         return logits
 
@@ -316,8 +327,18 @@ class _LocalAggregate(torch.autograd.Function):
     def backward(ctx, out_grad):
         H, W, D = ctx.dims
         state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii = ctx.saved_tensors
+        # GF_EXACT_FP32: the Gaussian-major exact kernels (what an exact forward is paired with); GF_MFMA_SPLAT: the matrix-core
+        # backward, asserted from the forward's own state words; neither: both pipelines, gated on the device
+        if ctx.fwd_flags & _lib.GF_EXACT_FP32:
+            bflags = _lib.GF_EXACT_FP32
+        elif ctx.state_event is not None and ctx.state_event.query():
+            words = ctx.state_host.tolist()
+            on_matrix_cores = words[0] == 0 and words[1] in (_lib.GF_PATH_MATRIX_CORE, _lib.GF_PATH_MATRIX_CORE_WAVE)
+            bflags = _lib.GF_MFMA_SPLAT if on_matrix_cores else _lib.GF_EXACT_FP32
+        else:
+            bflags = _lib.GF_PTS_AUTO
         mg, og, sg, cg = splat_backward(_lib.GF_SPLAT_BASE, pts, points_int, means3D, means3D_int, opacities,
-                                        semantics, radii, cov3D, H, W, D, out_grad, state=state)
+                                        semantics, radii, cov3D, H, W, D, out_grad, state=state, flags=bflags)
         # grads for (means3D, opacities, semantics, cov3D) only -- :91-104.  The reference returns the opacity
         # gradient as [P] whatever the input's shape; a [P,1] opacity that requires grad would be rejected by
         # autograd there, so it is reshaped here.
@@ -447,7 +468,9 @@ class LocalAggregator(_AggregatorBase):
     (``grid_is_exact_lattice``: no device work, no synchronisation), so that a grid that is not (e.g. a 0.4 m cell) goes
     straight to the exact-fp32 kernel; the device verdict still guards every call -- ``True`` = request it
     regardless of that check (the device verdict still guards every call), ``False`` = always the exact-fp32 kernel
-    (``GF_EXACT_FP32``: ~2e-6 from the reference).  The backward is the same exact-fp32 kernel in every case."""
+    (``GF_EXACT_FP32``: ~2e-6 from the reference).  The backward follows the forward: after a matrix-core forward the
+    voxel-major matrix-core backward (``splat_bwd_mfma.hip``, gradients ~1e-5 from the reference, bound 1e-3), after an exact
+    forward the exact Gaussian-major kernels."""
 
     def __init__(self, scale_multiplier, H, W, D, pc_min, grid_size, inv_softmax=False, check_inputs=True, matrix_cores=None):
         super().__init__()

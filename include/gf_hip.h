@@ -132,6 +132,18 @@ int gf_splat_forward(int variant, int radii_per_axis, int flags, int P, int N, i
  * bin_logits_grad/density_grad may be NULL (treated as zero).  Gradient outputs
  * (means3D_grad [P,3], opacity_grad [P], semantics_grad [P,18], cov3D_grad [P,6]) are
  * written in full.
+ *
+ * Two implementations.  (1) The Gaussian-major exact-fp32 kernels (every variant, arbitrary points; gradients ~1e-6 of the
+ * tensor's maximum from the reference's own kernels).  (2) For the base variant after a forward that one of the matrix-core
+ * kernels rendered (word 1 of `state`) and bitmask rows of <= 618 words (P <= 39 552): the voxel-major matrix-core backward --
+ * every double brick loads its gradient rows once, the sums over voxels are contractions on the MFMAs (split-f16 operands,
+ * fp32 accumulate, an exact-fp32 MFMA for sum_c dL sem), per-(Gaussian, brick) partial rows are added up in a fixed order
+ * (~1e-5 from the reference; tolerance 1e-3).  Which one applies is device-side knowledge, so by default BOTH pipelines are
+ * launched, each gated on the state block (the one that stands down costs its empty launches).  flags:
+ *   GF_EXACT_FP32   (1) only.
+ *   GF_MFMA_SPLAT   (2) only: the caller has seen the state block and asserts a matrix-core forward; if the state block says
+ *                   otherwise every gradient comes out NaN (never silently wrong).  Ignored where (2) does not apply.
+ *   GF_PTS_ASSUME_DENSE / GF_PTS_GENERAL as in the forward (they select (1)'s body; (2) takes its verdict from `state`).
  */
 int gf_splat_backward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
                       int W, int D, const float *pts, const int *points_int,

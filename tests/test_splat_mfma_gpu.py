@@ -212,9 +212,10 @@ def test_mfma_module_keyword_and_autograd(gpu):
     assert float(((outs[0] - outs[1]).abs() / outs[0].abs().clamp(min=1.0)).max()) <= 1e-4
     assert not torch.equal(outs[0], outs[1])                       # it really is the other kernel
     for a, b in zip(*grads):
-        # the backward does not depend on the forward kernel (boxes split over several waves combine with float atomics:
-        # equal up to summation order)
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()))
+        # the backward follows the forward: the exact Gaussian-major kernels after the exact forward, the voxel-major
+        # matrix-core backward after the matrix-core forward (~1e-5 of the tensor's maximum apart; the bound against the
+        # reference is 1e-3)
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
 
 
 # ---- round 4: the verdicts of the records pass (every call) and inputs at the edge of what stays on the matrix cores
