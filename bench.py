@@ -514,7 +514,38 @@ def main():
                 assert out["check_bit_identical_to_single_device"]
             return out
 
+        def frame_sharded():
+            # one END-TO-END inference frame with the anchors split over the ranks: the configuration in which
+            # N GPUs can win -- the per-anchor encoder work shards without a collective -- next to the 1-GPU `frames_per_s`
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_frame
+
+            def gather(t, dim):
+                t = t.contiguous()
+                if world == 1:
+                    return t
+                parts = [torch.empty_like(t) for _ in range(world)]
+                if shared_gpu:
+                    hp = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+                    dist.all_gather(hp, t.cpu())
+                    parts = [h.to(dev) for h in hp]
+                else:
+                    dist.all_gather(parts, t)
+                return torch.cat(parts, dim=dim)
+
+            def reduce_sum(t):
+                if world > 1:
+                    all_reduce(t)
+                return t
+            out = {}
+            for cfg, nf in (("nuscenes_gs25600_solid", 10), ("nuscenes_gs144000", 4)):
+                out[cfg] = bench_frame.run_sharded(cfg, rank, world, gather, reduce_sum, barrier, max_over_ranks, frames=nf, warmup=2,
+                                                   device=str(dev), check=os.environ.get("GF_BENCH_CHECK") == "1")
+            out["unit"] = "ms per frame (slowest rank)"
+            return out
+
         extra("kernel_only", kernel_only)
+        extra("frame_sharded", frame_sharded)
         extra("gs144000", gs144000)
         extra("reduce_scatter_labels", rs_labels)
         extra("slab_partition", lambda: slab(args.config))

@@ -56,6 +56,7 @@ struct PrepArgs {
     uint32_t *unit_alloc;    // null (forward), or the matrix-core backward's row allocator: [0] cursor, [1] big-list length, [2] overflows
     int *unit_big;           // ... its big list
     uint32_t unit_cap;       // ... and the rows available
+    int range_theta_here;    // 1: the records pass checks theta as well as opacity * semantics (no verification waves: GF_PTS_ASSUME_DENSE)
     uint32_t *range_flags;   // null, or [nwords + 4]: per wave of 64 Gaussians, bit 2 = a Gaussian's theta may leave the f16
                              // range, bit 3 = |opacity * semantics| may (matrix-core render kernel: both change per frame, so
                              // they are checked in the records pass on EVERY call, GF_PTS_ASSUME_DENSE included)
@@ -175,46 +176,28 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 }
             }
         }
-        // The range verdicts of the matrix-core kernel (see range_of below).  With the point scans running (GF_PTS_AUTO) they
-        // ride along here, beside the records pass instead of on its critical path (in the records pass they cost it 0.75 us at
-        // P = 25 601 and 2.8 us at P = 144 000); with GF_PTS_ASSUME_DENSE there are no verification waves and the records pass
-        // takes them (range_flags).
+        // The theta range verdict of the matrix-core kernel (see range_of below).  With the point scans running (GF_PTS_AUTO) it
+        // rides along here, beside the records pass instead of on its critical path (there it needs the lattice steps -- a
+        // dependent round trip: +0.75 us at P = 25 601, +2.8 us at P = 144 000); with GF_PTS_ASSUME_DENSE there are no
+        // verification waves and the records pass takes it.  The opacity * semantics verdict is always the records pass's: its
+        // lanes hold those values in registers anyway.
         uint32_t rbits = 0u;
         if (a.lattice) {
             const float lx_ = fabsf((float)sx), ly_ = fabsf((float)sy), lz_ = fabsf((float)sz);
 #pragma nounroll
             for (int g = vb * 64 + lane; g < a.P; g += kVerifyBlocks * 64) {
-                // (written for few registers -- the kernel's register count must stay the records pass's: the semantics in two
-                // batches of nine with a running maximum, not as an 18-element array)
                 const float *cv = a.cov3D + 6 * (size_t)g;
-                const float *sp = a.semantics + (size_t)kC * g;
-                const float opa = a.opacity[g];
                 const int r0 = a.radii[a.per_axis ? 3 * g : g], r1 = a.radii[a.per_axis ? 3 * g + 1 : g], r2 = a.radii[a.per_axis ? 3 * g + 2 : g];
                 float c[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) c[j] = cv[j];
                 const float zero[kC] = {0.f};
                 rbits |= range_bits_of(c, zero, 0.f, r0, r1, r2, a.H, a.W, a.D, lx_, ly_, lz_) & 4u;
-                float smax = 0.f;
-                bool snan = false;
-#pragma nounroll
-                for (int j0 = 0; j0 < kC; j0 += 9) {
-                    float t[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) t[k] = sp[j0 + k];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const float v = fabsf(opa * t[k]);
-                        snan |= !(v == v);
-                        smax = fmaxf(smax, v);
-                    }
-                }
-                rbits |= (snan || !(smax < kSemRangeMax)) ? 8u : 0u;
             }
         }
         const unsigned long long any = __builtin_amdgcn_ballot_w64(bad), any2 = __builtin_amdgcn_ballot_w64(bad_lattice),
-                                 any3 = __builtin_amdgcn_ballot_w64((rbits & 4u) != 0u), any4 = __builtin_amdgcn_ballot_w64((rbits & 8u) != 0u);
-        if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u) | (any3 ? 4u : 0u) | (any4 ? 8u : 0u);
+                                 any3 = __builtin_amdgcn_ballot_w64((rbits & 4u) != 0u);
+        if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u) | (any3 ? 4u : 0u);
         return;
     }
     if (a.tile_counters && blockIdx.x == 0 && threadIdx.x < 8) a.tile_counters[64 * threadIdx.x] = a.tile_counter_init;
@@ -242,7 +225,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     // (NaN-safe: a NaN bound is "bad".)
     uint32_t range_bits = 0u;
     float lsx = 0.f, lsy = 0.f, lsz = 0.f;   // |lattice steps|  (fp32 throughout: the bounds are thresholds with a wide margin,
-    if (a.range_flags) {                      // and this sits on the records pass's critical path)
+    if (a.range_flags && a.range_theta_here) {   // and this sits on the records pass's critical path; zero steps = theta not checked here)
         const float p0x = a.pts[0], p0y = a.pts[1], p0z = a.pts[2];
         lsx = a.H > 1 ? fabsf(a.pts[3 * (size_t)a.W * a.D] - p0x) : 1.f;
         lsy = a.W > 1 ? fabsf(a.pts[3 * (size_t)a.D + 1] - p0y) : 1.f;
@@ -2433,7 +2416,7 @@ void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, in
     pa.prescale = 0; pa.exact_det = 0; pa.lattice = 0;
     pa.tile_counters = ws.flags + 4608;   // the backward kernel claims its units from the same eight per-XCD counters
     pa.tile_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);
-    pa.range_flags = nullptr;
+    pa.range_flags = nullptr; pa.range_theta_here = 0;
     pa.unit_alloc = ws.bwd_alloc; pa.unit_big = ws.bwd_big; pa.unit_cap = ws.bwd_cap;
     const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
                             (prep_waves > 1 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
@@ -2518,7 +2501,8 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     uint32_t *tile_counters = ws.flags + 4608;  // [64 x], x < 8: inside the 32 KB flag section, past the verdicts
     pa.unit_alloc = nullptr; pa.unit_big = nullptr; pa.unit_cap = 0u;
     pa.tile_counters = mfma ? tile_counters : nullptr;
-    pa.range_flags = (mfma && !verify) ? ws.range_flags : nullptr;   // (with the point scans running, their waves take the range verdicts)
+    pa.range_flags = mfma ? ws.range_flags : nullptr;
+    pa.range_theta_here = (mfma && !verify) ? 1 : 0;   // (with the point scans running, their waves take the theta verdict)
     pa.tile_counter_init = !mfma ? 0u
                            : mfma_by_wave(ws.nrow) ? (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8)
                                                    : (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8);
@@ -2543,7 +2527,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
     ra.raw_numerator = (flags & GF_PROB_NUMERATOR) ? 1 : 0;
     ra.tile_counters = tile_counters;
-    ra.range_flags = (mfma && !verify) ? ws.range_flags : nullptr;
+    ra.range_flags = mfma ? ws.range_flags : nullptr;
     ra.nrange4 = (ws.nwords + 3) / 4;
     if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);

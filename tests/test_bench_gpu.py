@@ -57,6 +57,15 @@ def test_bench_two_rank_strong_scaling_path(gpu):
     assert b["kernel_only"]["ms_per_step"] <= b["ms_per_step"]
     g = b["gs144000"]
     assert "error" not in g and g["kernel_only_ms_per_step"] > 0 and "144000" in g["config"]
+    fs = b["frame_sharded"]
+    assert "error" not in fs, fs
+    for cfg in ("nuscenes_gs25600_solid", "nuscenes_gs144000"):
+        for head in ("slab", "allreduce"):
+            r = fs[cfg][head]
+            assert r["ms_per_frame"] > 0
+            # the anchor-sharded frame labels the grid like the single-GPU frame (GEMM tilings change with the row count: a few
+            # last-bit ties may flip)
+            assert r["labels_equal_single_gpu_fraction"] >= 0.999, (cfg, head, r)
     for key in ("slab_partition", "slab_partition_gs144000"):
         sp = b[key]
         assert "error" not in sp, sp

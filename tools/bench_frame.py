@@ -208,6 +208,56 @@ class Frame(nn.Module):
         logits = self.aggregator.forward_from_rotations(pts, means, opa.squeeze(-1), sem, scales, rots)
         return occupancy_labels(logits)
 
+    @torch.no_grad()
+    def forward_sharded(self, anchor, feat, maps, pm, wh, pts, rank, world, gather, reduce_sum, splat="slab"):
+        """The same frame with the ANCHOR SET split over `world` ranks (the reference runs replicas only, train.py:41-43).
+        Rank r owns anchors [lo, hi): key points, projection + masked softmax, deformable aggregation, FFN, norms and
+        refinement are per-anchor work on its slice against the replicated feature pyramid -- no collective.  The sparse
+        convolution needs every anchor's neighbours: features and anchors are all-gathered (`gather(t, dim)` -> the
+        concatenation over ranks) and the convolution runs replicated on the whole set, each rank keeping its slice.  Head:
+        the ranks' Gaussians are all-gathered (116 B each) and the grid is rendered either by x-slabs (`splat="slab"`:
+        every rank its band of voxel rows from all Gaussians, labels all-gathered) or by Gaussian shards + one all-reduce
+        of the logits (`splat="allreduce"`, `reduce_sum(t)`).  Returns the labels of the whole grid on every rank."""
+        from gaussianformer_amd.deformable_aggregation import DeformableAggregationFunction as DAF
+        from gaussianformer_amd.head import occupancy_labels
+        from gaussianformer_amd.sharded import shard_bounds, slab_bounds
+        A = anchor.shape[1]
+        lo, hi = shard_bounds(A, rank, world)
+        anchor, feat = anchor[:, lo:hi].contiguous(), feat[:, lo:hi].contiguous()
+        table = DAF.feature_maps_format(maps)
+        embed = self.anchor_encoder(anchor)
+        for op, layer in zip(self.order, self.layers):
+            if op == "deformable":
+                feat = layer(feat, anchor, embed, table, pm, wh)
+            elif op == "spconv":
+                full = layer(gather(feat, 1), gather(anchor, 1))
+                feat = full[:, lo:hi].contiguous()
+            elif op == "refine":
+                anchor = layer(feat, anchor, embed)
+                embed = self.anchor_encoder(anchor)
+            else:
+                feat = layer(feat)
+        anchor_all = gather(anchor, 1)
+        means, scales, rots, opa, sem = self.gaussians(anchor_all)     # (the appended empty Gaussian once, on the gathered set)
+        if splat == "slab":
+            x0, x1 = slab_bounds(self.aggregator.H, rank, world)
+            plane = self.aggregator.W * self.aggregator.D
+            from gaussianformer_amd.gaussian_prepare import covariance_inverse
+            cov = covariance_inverse(scales, rots)
+            logits = self.aggregator.forward_slab(x0, x1, pts, means, opa.squeeze(-1), sem, scales, cov)
+            labels = occupancy_labels(logits)
+            bounds = [slab_bounds(self.aggregator.H, r, world) for r in range(world)]
+            tallest = max(b - a for a, b in bounds) * plane
+            mine = labels.new_zeros(tallest)
+            mine[:labels.shape[0]] = labels
+            buf = gather(mine[None], 0).reshape(world, tallest)
+            return torch.cat([buf[r, :(b - a) * plane] for r, (a, b) in enumerate(bounds)])
+        P = means.shape[1]
+        glo, ghi = shard_bounds(P, rank, world)
+        logits = self.aggregator.forward_from_rotations(pts, means[:, glo:ghi], opa.squeeze(-1)[:, glo:ghi], sem[:, glo:ghi],
+                                                         scales[:, glo:ghi], rots[:, glo:ghi]).contiguous()
+        return occupancy_labels(reduce_sum(logits))
+
     def check(self):
         """After a synchronisation: did every rulebook of the last frame fit its capacity?"""
         for m in self.layers:
@@ -275,6 +325,42 @@ def run(config="nuscenes_gs25600_solid", frames=10, warmup=3, device="cuda:0", g
         except Exception as exc:   # capture support is an extra; never lose the eager figure
             out["frames_per_s_graph"] = None
             out["graph_error"] = f"{type(exc).__name__}: {exc}"[:300]
+    return out
+
+
+def run_sharded(config, rank, world, gather, reduce_sum, barrier, max_over_ranks, frames=6, warmup=2, device="cuda:0", check=False):
+    """ms per frame of the anchor-sharded frame (slowest rank), both head variants; with `check`, the fraction of voxels
+    whose label equals the single-GPU frame's (GEMM tilings differ with the row count, so last-bit ties may flip)."""
+    from gaussianformer_amd.synthetic import DAF_LEVELS, voxel_centres
+    dev = torch.device(device)
+    torch.manual_seed(0)
+    model = Frame(config).to(dev).eval()
+    A = model.cfg["anchors"]
+    anchor = torch.randn(1, A, model.anchor_dim, device=dev)
+    feat = torch.randn(1, A, EMBED, device=dev)
+    maps = [torch.randn(1, CAMS, EMBED, h, w, device=dev) for h, w in DAF_LEVELS]
+    pm, wh = cameras(dev)
+    pts = torch.from_numpy(voxel_centres(200, 200, 16, 0.5, np.asarray(PC_RANGE[:3], dtype=np.float32))).to(dev)[None]
+    out = {"config": config, "anchors": A, "anchors_per_rank": A // world, "world": world,
+           "scope": "one inference frame, anchors sharded over the ranks: per-anchor encoder work on the shard (replicated pyramid, no "
+                    "collective), sparse convolution replicated on the all-gathered set, head by x-slabs (labels all-gathered) or by "
+                    "Gaussian shards + all-reduce of the logits"}
+    for splat in ("slab", "allreduce"):
+        step = lambda: model.forward_sharded(anchor, feat, maps, pm, wh, pts, rank, world, gather, reduce_sum, splat=splat)
+        for _ in range(warmup):
+            labels = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            labels = step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0) / frames
+        out[splat] = {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt}
+        if check:
+            want = model(anchor, feat, maps, pm, wh, pts)
+            out[splat]["labels_equal_single_gpu_fraction"] = float((labels == want).float().mean())
+    model.check()
     return out
 
 
