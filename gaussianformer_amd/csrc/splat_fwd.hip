@@ -382,9 +382,13 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             float4 *rec = reinterpret_cast<float4 *>(row);
             const float opa_g = a.opacity[g];
             rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], opa_g);
-            if (a.range_flags)
-                range_bits = range_of(row + kRecCov, row + kRecSem, opa_g, a.radii[a.per_axis ? 3 * g : g],
-                                      a.radii[a.per_axis ? 3 * g + 1 : g], a.radii[a.per_axis ? 3 * g + 2 : g]);
+            if (a.range_flags) {
+                int rr0 = 0, rr1 = 0, rr2 = 0;
+                if (a.range_theta_here) {   // (the radii only enter the theta bound)
+                    rr0 = a.radii[a.per_axis ? 3 * g : g]; rr1 = a.radii[a.per_axis ? 3 * g + 1 : g]; rr2 = a.radii[a.per_axis ? 3 * g + 2 : g];
+                }
+                range_bits = range_of(row + kRecCov, row + kRecSem, opa_g, rr0, rr1, rr2);
+            }
             if (a.prescale) {
                 // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
                 // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
@@ -1689,6 +1693,10 @@ static_assert(3072 + 2 * kWRow + kQCap + (kC + 1) * kSRow == kWLdsDwords, "LDS m
 static_assert((kWRow + 4 + 3) / 4 <= 3 * 64, "the wave kernel reads its range verdicts with three 16-byte loads per lane");
 static_assert(2 * 64 * kC <= 1536 + 3 * kWList, "output staging fits over the slot and the list");
 
+// LABELS: the head epilogue (gf_splat_forward_labels, argmax mode): the labels are taken from the staged rows -- the very fp32
+// values that would be stored -- and, without out_logits, the 46 MB of logits are never written.  A separate instantiation: the
+// default kernel's code is unchanged.
+template <bool LABELS>
 __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(RenderArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_u[kWLdsDwords];
@@ -1761,7 +1769,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
         a.state[2] = (uint32_t)verdict;
     }
     if (verdict) {
-        general_body<GF_SPLAT_BASE, kExpComp, false>(a);
+        general_body<GF_SPLAT_BASE, kExpComp, LABELS>(a);
         return;
     }
 
@@ -2208,6 +2216,29 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                     *reinterpret_cast<float2 *>(row + 10 + 4 * h) = make_float2(acc[b][6], acc[b][7]);
                     if (h == 0) *reinterpret_cast<float2 *>(row + 16) = make_float2(acc[b][8], acc[b][9]);
                 }
+                auto labels_from_stage = [&]() {
+                    // two rows per lane: row r = brick (r >> 6), voxel (lx, ly, lz) = (l >> 4, (l >> 2) & 3, l & 3) of the brick
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int l = lane;
+                        const float *row = stage + (64 * half + l) * kC;
+                        float best = row[0];
+                        int arg = 0;
+#pragma unroll
+                        for (int ch = 1; ch < kC; ++ch) {
+                            const float v = row[ch];
+                            if (v > best) { best = v; arg = ch; }
+                        }
+                        const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zw + 4 * half + (l & 3);
+                        if (cx < a.H && cy < a.W && cz < a.D) a.out_labels[((size_t)cx * a.W + cy) * a.D + cz] = arg;
+                    }
+                };
+                if (LABELS) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    labels_from_stage();
+                }
+                if (!LABELS || a.out_logits) {
                 // float4 i = lane + 64 j (j < 5) of a brick's 16 runs x 18: run i / 18 = column (run >> 2, run & 3), piece i % 18; the
                 // upper brick's rows lie 4 voxels = 72 floats further on.  Ten 32-bit element offsets from the uniform base, all
                 // computed first (hipcc makes a store's address registers wait for the store to COMPLETE before they are rewritten).
@@ -2228,7 +2259,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                     }
                 }
                 // (a unit inside the grid issues all ten store instructions: the count the next unit's row wait relies on)
-                nst = (Xw + 4 <= a.H && Y0 + 4 <= a.W && Zw + 8 <= a.D) ? 10 : -1;
+                nst = ((!LABELS) && Xw + 4 <= a.H && Y0 + 4 <= a.W && Zw + 8 <= a.D) ? 10 : -1;
                 asm volatile("" : "+v"(off[0]), "+v"(off[1]), "+v"(off[2]), "+v"(off[3]), "+v"(off[4]), "+v"(off[5]), "+v"(off[6]),
                              "+v"(off[7]), "+v"(off[8]), "+v"(off[9]));
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2244,6 +2275,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                     if (okbits & (1u << it))
                         __builtin_nontemporal_store((nt4v){val[it].x, val[it].y, val[it].z, val[it].w}, (nt4 *)(obase + off[it]));
                 }
+                }
             } else {
                 // depths that are not a multiple of 4 (no reference config): the staged rows leave element by element
 #pragma unroll
@@ -2257,10 +2289,26 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                for (int i = lane; i < 2 * 64 * kC; i += 64) {
-                    const int half = i / (64 * kC), l = (i % (64 * kC)) / kC, ch = i % kC;
-                    const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zw + 4 * half + (l & 3);
-                    if (cx < a.H && cy < a.W && cz < a.D) a.out_logits[(((size_t)cx * a.W + cy) * a.D + cz) * kC + ch] = stage[i];
+                if (!LABELS || a.out_logits)
+                    for (int i = lane; i < 2 * 64 * kC; i += 64) {
+                        const int half = i / (64 * kC), l = (i % (64 * kC)) / kC, ch = i % kC;
+                        const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zw + 4 * half + (l & 3);
+                        if (cx < a.H && cy < a.W && cz < a.D) a.out_logits[(((size_t)cx * a.W + cy) * a.D + cz) * kC + ch] = stage[i];
+                    }
+                if (LABELS) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int l = lane;
+                        const float *row = stage + (64 * half + l) * kC;
+                        float best = row[0];
+                        int arg = 0;
+                        for (int ch = 1; ch < kC; ++ch) {
+                            const float v = row[ch];
+                            if (v > best) { best = v; arg = ch; }
+                        }
+                        const int cx = Xw + (l >> 4), cy = Y0 + ((l >> 2) & 3), cz = Zw + 4 * half + (l & 3);
+                        if (cx < a.H && cy < a.W && cz < a.D) a.out_labels[((size_t)cx * a.W + cy) * a.D + cz] = arg;
+                    }
                 }
             }
             // the staged rows have been read (their stores are under way): the next unit may write the slot and the list again
@@ -2351,8 +2399,10 @@ static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stre
     hipEvent_t ev0, ev1;
     const bool prof = profile_slot(&ev0, &ev1);
     if (prof) (void)hipEventRecord(ev0, stream);
-    if (mfma_by_wave(r.nrow))
-        hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
+    if (mfma_by_wave(r.nrow) && r.out_labels)
+        hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<true>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
+    else if (mfma_by_wave(r.nrow))
+        hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<false>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
     else
         hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
     if (prof) (void)hipEventRecord(ev1, stream);
@@ -2492,7 +2542,9 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     const int prep_waves = P >= 65536 ? 4 : 1;
     pa.variant = variant; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = verify ? 1 : 0;
     // matrix-core kernel: the default wherever it applies (include/gf_hip.h, GF_MFMA_SPLAT / GF_EXACT_FP32)
-    const bool mfma_ok = variant == GF_SPLAT_BASE && dense_candidate && !lab.labels && P > 0;
+    // (the label epilogue -- argmax mode -- is built into the wave-autonomous kernel only: rows of <= kWRow words)
+    const bool mfma_ok = variant == GF_SPLAT_BASE && dense_candidate && P > 0 &&
+                         (!lab.labels || (lab.mode == GF_LABELS_ARGMAX && mfma_by_wave(ws.nrow)));
     const bool mfma = mfma_ok && ((flags & GF_MFMA_SPLAT) ||
                                   !(flags & (GF_EXACT_FP32 | GF_FAST_EXP | GF_LIBM_EXP | GF_COMP_EXP)));
     pa.prescale = (!mfma && exp_flavour(variant, flags) == kExpFast) ? 1 : 0;  // the matrix-core kernel scales in fp64 itself

@@ -128,17 +128,22 @@ def test_fused_label_epilogue_matches_separate_kernels(config, per_axis, dense):
     t = to_dev(dev, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
     prob = si.variant == "prob"
     variant = _lib.GF_SPLAT_PROB if prob else _lib.GF_SPLAT_BASE
-    # the label epilogue lives in the exact-fp32 kernels: compare with the same kernels' separate forward
-    logits, bl, de, pr, _ = splat_forward(variant, *t, si.H, si.W, si.D, flags=_lib.GF_EXACT_FP32)
-    for kw in ([dict()] if not prob else [dict(threshold=0.3), dict(combine_geosem=True)]):
-        want = occupancy_labels(logits, bin_logits=bl, empty_label=17, **kw)
-        got = splat_forward_labels(variant, *t, si.H, si.W, si.D, **kw)
-        assert torch.equal(got, want), kw
-        outs = splat_forward_labels(variant, *t, si.H, si.W, si.D, keep_logits=True, **kw)
-        bits = lambda x: x.view(torch.int32)   # bitwise: the prob config can produce NaN (negative fp32 determinant)
-        assert torch.equal(outs[0], want) and torch.equal(bits(outs[1]), bits(logits))
-        if prob:
-            assert all(torch.equal(bits(a), bits(b)) for a, b in zip(outs[2:], (bl, de, pr)))
+    # the label epilogue lives in the exact-fp32 kernels and, for the base head on the dense grid, in the wave-autonomous
+    # matrix-core kernel (the default): each compared with the same kernel's separate forward, labels AND logits bit for bit
+    flag_sets = [_lib.GF_EXACT_FP32] + ([0] if (not prob and dense) else [])
+    for fl in flag_sets:
+        logits, bl, de, pr, state = splat_forward(variant, *t, si.H, si.W, si.D, flags=fl)
+        if fl == 0:
+            assert state.view(torch.int32)[1].item() == _lib.GF_PATH_MATRIX_CORE_WAVE
+        for kw in ([dict()] if not prob else [dict(threshold=0.3), dict(combine_geosem=True)]):
+            want = occupancy_labels(logits, bin_logits=bl, empty_label=17, **kw)
+            got = splat_forward_labels(variant, *t, si.H, si.W, si.D, flags=fl, **kw)
+            assert torch.equal(got, want), (fl, kw)
+            outs = splat_forward_labels(variant, *t, si.H, si.W, si.D, keep_logits=True, flags=fl, **kw)
+            bits = lambda x: x.view(torch.int32)   # bitwise: the prob config can produce NaN (negative fp32 determinant)
+            assert torch.equal(outs[0], want) and torch.equal(bits(outs[1]), bits(logits))
+            if prob:
+                assert all(torch.equal(bits(a), bits(b)) for a, b in zip(outs[2:], (bl, de, pr)))
 
 
 @pytest.mark.gpu

@@ -27,6 +27,14 @@ if dist == "projected":
     A = pts // 9
     lo = torch.tensor(bench_frame.PC_RANGE[:3]); hi = torch.tensor(bench_frame.PC_RANGE[3:])
     centre = lo + (hi - lo) * torch.rand(1, A, 3, generator=g)
+    if os.environ.get("GF_DAF_MORTON") == "1":
+        # anchors in Morton order of their (x, y) cell (2 m cells): neighbouring anchors then sample neighbouring pixels
+        cell = ((centre[0, :, :2] - lo[:2]) / 2.0).long().clamp(0, 63)
+        def spread(v):
+            v = (v | (v << 8)) & 0x00FF00FF; v = (v | (v << 4)) & 0x0F0F0F0F; v = (v | (v << 2)) & 0x33333333; v = (v | (v << 1)) & 0x55555555
+            return v
+        key = spread(cell[:, 0]) | (spread(cell[:, 1]) << 1)
+        centre = centre[:, torch.argsort(key)]
     offs = torch.tensor(bench_frame.FIX_SCALE + [[0.3, 0.3, 0.0], [-0.3, 0.3, 0.0]]) * 0.35
     kp = (centre[:, :, None] + offs[None, None]).to(dev)
     pm, wh = bench_frame.cameras(dev)
