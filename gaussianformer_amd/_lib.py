@@ -53,6 +53,7 @@ SIGNATURES = {
     "gf_daf_prepare_backward": (_i, [_i] * 6 + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare": (_i, [_i] * 4 + [_vp, _f, _f, _i, _i] + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare_backward": (_i, [_i] * 2 + [_vp] * 5 + [_vp]),
+    "gf_gaussian_pack": (_i, [_i] * 7 + [_vp] * 14 + [_vp]),
     "gf_key_points": (_i, [_i] * 4 + [_vp] * 4 + [_f] * 3 + [_i, _vp, _vp]),
     "gf_key_points_backward": (_i, [_i] * 4 + [_vp] * 4 + [_f] * 3 + [_i] + [_vp] * 3 + [_vp]),
     "gf_profile_enable": (_i, [_i]),

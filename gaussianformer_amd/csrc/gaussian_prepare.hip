@@ -166,7 +166,87 @@ __global__ __launch_bounds__(256) void gf_gaussian_prepare_bwd_kernel(PrepareArg
     *reinterpret_cast<float4 *>(a.rot_grad + 4 * (size_t)g) = out;
 }
 
+// ---------------------------------------------------------------------------------------
+// The tensor surgery of prepare_gaussian_args ahead of the covariance (model/head/gaussian_head.py:88-109) in one launch:
+// the zero column of the semantics (last, or first for the kitti datasets), the appended "empty" Gaussian (mean, scale,
+// rotation, semantics = empty_scalar at empty_label, opacity 1) or, for the prob head, the softmax over the 17 classes.
+// The reference strings eight torch.cat / softmax kernels here.  One thread per output Gaussian.
+struct PackArgs {
+    const float *means, *scales, *rotations, *sem, *opa;   // [P,3] [P,3] [P,4] [P,Cin] [P] (opa may be null: ones)
+    const float *empty_scalar;                              // device, 1 float (with_empty)
+    float *means_o, *scales_o, *rot_o, *sem_o, *opa_o;      // [P+E,...]; sem_o [P+E,Cout]
+    float empty_mean[3], empty_scale[3], empty_rot[4];
+    int P, Cin, Cout, zero_first, with_empty, softmax, empty_label;
+};
+
+__global__ __launch_bounds__(256) void gf_gaussian_pack_kernel(PackArgs a)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int Pout = a.P + (a.with_empty ? 1 : 0);
+    if (g >= Pout) return;
+    float *so = a.sem_o + (size_t)a.Cout * g;
+    if (g == a.P) {   // the empty Gaussian
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { a.means_o[3 * (size_t)g + k] = a.empty_mean[k]; a.scales_o[3 * (size_t)g + k] = a.empty_scale[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.rot_o[4 * (size_t)g + k] = a.empty_rot[k];
+        const float es = a.empty_scalar[0];
+        for (int c = 0; c < a.Cout; ++c) so[c] = c == a.empty_label ? 0.f + es : 0.f;   // (empty_sem is zeros "+=" the scalar)
+        a.opa_o[g] = 1.f;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.means_o[3 * (size_t)g + k] = a.means[3 * (size_t)g + k]; a.scales_o[3 * (size_t)g + k] = a.scales[3 * (size_t)g + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.rot_o[4 * (size_t)g + k] = a.rotations[4 * (size_t)g + k];
+    a.opa_o[g] = a.opa ? a.opa[g] : 1.f;
+    const float *si = a.sem + (size_t)a.Cin * g;
+    const int shift = (a.Cout > a.Cin && a.zero_first) ? 1 : 0;
+    if (a.softmax) {
+        // torch.softmax over the Cin classes: exp(x - max) / sum, fp32
+        float mx = si[0];
+        for (int c = 1; c < a.Cin; ++c) mx = fmaxf(mx, si[c]);
+        float sum = 0.f;
+        for (int c = 0; c < a.Cin; ++c) sum += expf(si[c] - mx);
+        for (int c = 0; c < a.Cin; ++c) so[c + shift] = expf(si[c] - mx) / sum;
+    } else {
+        for (int c = 0; c < a.Cin; ++c) so[c + shift] = si[c];
+    }
+    if (a.Cout > a.Cin) so[a.zero_first ? 0 : a.Cout - 1] = 0.f;
+}
+
 }  // namespace gf
+
+extern "C" int gf_gaussian_pack(int P, int Cin, int Cout, int zero_first, int with_empty, int softmax, int empty_label,
+                                const float *means3D, const float *scales, const float *rotations, const float *semantics,
+                                const float *opacities, const float *empty_mean, const float *empty_scale,
+                                const float *empty_rot, const float *empty_scalar, float *means_out, float *scales_out,
+                                float *rotations_out, float *semantics_out, float *opacities_out, void *stream_)
+{
+    using namespace gf;
+    hipStream_t stream = (hipStream_t)stream_;
+    GF_CHECK_ARG(P >= 0 && Cin > 0 && (Cout == Cin || Cout == Cin + 1), "bad sizes (Cout is Cin or Cin + 1)");
+    GF_CHECK_ARG(!(with_empty && softmax), "the empty Gaussian and the softmax belong to different heads");
+    GF_CHECK_ARG(!with_empty || (empty_mean && empty_scale && empty_rot && empty_scalar && empty_label >= 0 && empty_label < Cout),
+                 "with_empty needs the empty Gaussian's parameters");
+    const int Pout = P + (with_empty ? 1 : 0);
+    if (Pout == 0) return GF_OK;
+    GF_CHECK_ARG((P == 0 || (means3D && scales && rotations && semantics)) && means_out && scales_out && rotations_out &&
+                     semantics_out && opacities_out, "null pointer");
+    PackArgs a{};
+    a.means = means3D; a.scales = scales; a.rotations = rotations; a.sem = semantics; a.opa = opacities;
+    a.empty_scalar = empty_scalar; a.means_o = means_out; a.scales_o = scales_out; a.rot_o = rotations_out;
+    a.sem_o = semantics_out; a.opa_o = opacities_out;
+    if (with_empty) {
+        for (int k = 0; k < 3; ++k) { a.empty_mean[k] = empty_mean[k]; a.empty_scale[k] = empty_scale[k]; }
+        for (int k = 0; k < 4; ++k) a.empty_rot[k] = empty_rot[k];
+    }
+    a.P = P; a.Cin = Cin; a.Cout = Cout; a.zero_first = zero_first; a.with_empty = with_empty; a.softmax = softmax;
+    a.empty_label = empty_label;
+    hipLaunchKernelGGL(gf_gaussian_pack_kernel, dim3((Pout + 255) / 256), dim3(256), 0, stream, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
 
 extern "C" int gf_gaussian_prepare(int P, int H, int W, int D, const float *pc_min, float grid_size,
                                    float scale_multiplier, int radii_mode, int radii_min,

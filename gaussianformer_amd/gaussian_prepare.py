@@ -118,6 +118,52 @@ def covariance_inverse(scales, rotations, packed=False):
     return cov.reshape(*lead, 6) if packed else cov.reshape(*lead, 3, 3)
 
 
+class _GaussianPack(torch.autograd.Function):
+    """``gf_gaussian_pack``: zero column / appended empty Gaussian / softmax of ``prepare_gaussian_args``
+    (gaussian_head.py:88-109) in one launch for batch size 1; the gradients are slices (and the softmax rule)."""
+
+    @staticmethod
+    def forward(ctx, means, scales, rotations, sem, opa, empty_scalar, empty_host, cout, zero_first, with_empty, softmax,
+                empty_label):
+        _lib.require_gpu(means, scales, rotations, sem, opa, empty_scalar)
+        lib = _lib.load()
+        import ctypes
+        m, s_, q, se = _c(means[0]), _c(scales[0]), _c(rotations[0]), _c(sem[0])
+        o = None if opa is None else _c(opa[0].reshape(-1))
+        P, cin = m.shape[0], se.shape[1]
+        Pout = P + (1 if with_empty else 0)
+        dev = m.device
+        outs = [torch.empty(Pout, k, dtype=f32, device=dev) for k in (3, 3, 4, cout)] + [torch.empty(Pout, dtype=f32, device=dev)]
+        host = [None, None, None]
+        if with_empty:
+            host = [(ctypes.c_float * len(v))(*v) for v in empty_host]
+        es = None if empty_scalar is None else _c(empty_scalar)
+        with torch.cuda.device(dev):
+            rc = lib.gf_gaussian_pack(P, cin, cout, int(zero_first), int(with_empty), int(softmax), int(empty_label),
+                                      _lib.ptr(m), _lib.ptr(s_), _lib.ptr(q), _lib.ptr(se), _lib.ptr(o),
+                                      *[None if h is None else ctypes.cast(h, ctypes.c_void_p) for h in host], _lib.ptr(es),
+                                      *[_lib.ptr(t) for t in outs], _lib.current_stream(dev))
+        _lib.check(rc, "gf_gaussian_pack")
+        ctx.meta = (P, cin, cout, zero_first, with_empty, softmax, empty_label, opa is not None and opa.requires_grad,
+                    None if opa is None else opa.shape)
+        if softmax:
+            ctx.save_for_backward(outs[3])
+        return tuple(t[None] for t in outs[:4]) + (outs[4][None, :, None],)
+
+    @staticmethod
+    def backward(ctx, gm, gs, gq, gsem, gopa):
+        P, cin, cout, zero_first, with_empty, softmax, empty_label, opa_grad, opa_shape = ctx.meta
+        shift = 1 if (cout > cin and zero_first) else 0
+        g_sem_in = gsem[:, :P, shift:shift + cin]
+        if softmax:
+            (y_full,) = ctx.saved_tensors
+            y = y_full[None, :P, shift:shift + cin]
+            g_sem_in = y * (g_sem_in - (y * g_sem_in).sum(dim=-1, keepdim=True))
+        g_es = gsem[0, P, empty_label].reshape(1) if with_empty else None
+        g_opa = gopa[:, :P].reshape(opa_shape) if opa_grad else None
+        return gm[:, :P], gs[:, :P], gq[:, :P], g_sem_in, g_opa, g_es, None, None, None, None, None, None
+
+
 class GaussianArgs(nn.Module):
     """``GaussianHead.prepare_gaussian_args`` as a stand-alone module: same constructor keys,
     buffers and parameter (``empty_scalar``, ``empty_mean`` ... model/head/gaussian_head.py:41-51)
@@ -135,6 +181,7 @@ class GaussianArgs(nn.Module):
             self.register_buffer('empty_rot', torch.tensor([1., 0., 0., 0.])[None, None, :])
             self.register_buffer('empty_sem', torch.zeros(self.num_classes)[None, None, :])
             self.register_buffer('empty_opa', torch.ones(1)[None, None, :])
+        self._empty_host = None
         self.with_emtpy = with_empty  # (sic) attribute name of the reference
         self.dataset_type = dataset_type
         self.empty_label = empty_label
@@ -144,9 +191,29 @@ class GaussianArgs(nn.Module):
         reference's ``gaussians`` namedtuple, gaussian_head.py:83-87)."""
         sem = semantics
         origi_opa = opacities
+        kitti = 'kitti' in self.dataset_type
+        if means.is_cuda and means.shape[0] == 1 and (self.with_emtpy or self.use_localaggprob):
+            # one launch (gf_gaussian_pack) instead of the reference's zeros_like + six torch.cat (or softmax + cat)
+            assert sem.shape[-1] == self.num_classes - 1
+            opa_in = None if (origi_opa is None or origi_opa.numel() == 0) else origi_opa
+            empty_host = None
+            if self.with_emtpy:
+                if self._empty_host is None:   # the buffers are constants of the head: read once
+                    self._empty_host = [self.empty_mean.flatten().tolist(), self.empty_scale.flatten().tolist(),
+                                        self.empty_rot.flatten().tolist()]
+                empty_host = self._empty_host
+            means, scales, rotations, sem, origi_opa = _GaussianPack.apply(
+                means, scales, rotations, sem, opa_in, self.empty_scalar if self.with_emtpy else None, empty_host,
+                self.num_classes, kitti, self.with_emtpy, not self.with_emtpy, self.empty_label)
+            return means, origi_opa, sem, scales, covariance_inverse(scales, rotations)
+        return self._forward_torch(means, scales, rotations, sem, origi_opa)
+
+    def _forward_torch(self, means, scales, rotations, sem, origi_opa):
+        """The reference's op sequence (gaussian_head.py:88-119 with the device-side Sigma^-1): batch sizes above 1, CPU
+        tensors of the configuration tests, and the checker of the fused path (tests/test_prepare.py)."""
+        kitti = 'kitti' in self.dataset_type
         if origi_opa is None or origi_opa.numel() == 0:
             origi_opa = torch.ones_like(sem[..., :1], requires_grad=False)
-        kitti = 'kitti' in self.dataset_type
         if self.with_emtpy:
             assert sem.shape[-1] == self.num_classes - 1
             zero = torch.zeros_like(sem[..., :1])

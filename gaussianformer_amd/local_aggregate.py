@@ -315,7 +315,7 @@ class _LocalAggregate(torch.autograd.Function):
         # to pinned host memory behind an event -- never waited for: by the time the backward runs the copy has usually landed
         # and exactly one pipeline is launched (not while a HIP graph is being captured: no host allocation there).
         ctx.state_host = ctx.state_event = None
-        if any(ctx.needs_input_grad) and not torch.cuda.is_current_stream_capturing():
+        if any(ctx.needs_input_grad) and state.is_cuda and not torch.cuda.is_current_stream_capturing():
             ctx.state_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
             ctx.state_host.copy_(state[:12].view(torch.int32), non_blocking=True)
             ctx.state_event = torch.cuda.Event()

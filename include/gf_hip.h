@@ -196,6 +196,23 @@ int gf_gaussian_prepare(int P, int H, int W, int D, const float *pc_min, float g
                         void *stream);
 
 /*
+ * The tensor surgery of prepare_gaussian_args ahead of the covariance, one launch.
+ * Replaces  GaussianHead.prepare_gaussian_args   model/head/gaussian_head.py:88-109
+ *             (zeros column + torch.cat for the semantics, the appended "empty" Gaussian -- five torch.cat --, or the
+ *              softmax + zero column of the prob head)
+ *   means3D/scales [P,3], rotations [P,4], semantics [P,Cin], opacities [P] or NULL (= ones)       -> device
+ *   empty_mean[3], empty_scale[3], empty_rot[4]                                                       -> HOST (buffers of the head)
+ *   empty_scalar                                                                                      -> device, 1 float (a parameter)
+ *   outputs [P + with_empty, ...], semantics_out [.., Cout] with Cout = Cin or Cin + 1: the extra (zero) column is the last
+ *   one, or the first with zero_first (the kitti datasets); softmax = 1 applies torch.softmax over the Cin inputs first.
+ */
+int gf_gaussian_pack(int P, int Cin, int Cout, int zero_first, int with_empty, int softmax, int empty_label,
+                     const float *means3D, const float *scales, const float *rotations, const float *semantics,
+                     const float *opacities, const float *empty_mean, const float *empty_scale,
+                     const float *empty_rot, const float *empty_scalar, float *means_out, float *scales_out,
+                     float *rotations_out, float *semantics_out, float *opacities_out, void *stream);
+
+/*
  * Gradient of Sigma^-1 with respect to scales [P,3] and (un-normalised) rotations [P,4]: what
  * autograd computes through gaussian_head.py:108-119.  cov_grad is [P,6] (gradient of the packed
  * entries, as gf_splat_backward's cov3D_grad) or, with grad_is_full, an arbitrary [P,9].

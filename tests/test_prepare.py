@@ -193,3 +193,41 @@ def test_gaussian_args_module_and_fused_aggregator(gpu):
     assert cov.shape == (1, P + 1, 3, 3)
     rel = (cov.double().cpu() - A).abs().amax(dim=(-1, -2)) / A.abs().amax(dim=(-1, -2))
     assert rel.max() <= 4e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flavour", ["empty_nusc", "empty_kitti", "prob_nusc", "prob_kitti", "empty_no_opacity"])
+def test_gaussian_pack_matches_the_reference_op_sequence(gpu, flavour):
+    """``gf_gaussian_pack`` (one launch) against the reference's zeros_like / torch.cat / softmax sequence
+    (gaussian_head.py:88-109, kept as ``GaussianArgs._forward_torch``): outputs bit for bit (softmax: 1e-6), gradients of
+    every leaf including ``empty_scalar``."""
+    from gaussianformer_amd.gaussian_prepare import GaussianArgs
+    rng = np.random.default_rng(7)
+    P = 333
+    kitti = flavour.endswith("kitti")
+    prob = flavour.startswith("prob")
+    args = GaussianArgs(num_classes=18, with_empty=not prob, use_localaggprob=prob, empty_label=0 if kitti else 17,
+                        dataset_type="kitti360" if kitti else "nusc",
+                        empty_args=dict(mean=[0.0, 0.0, -1.0], scale=[100.0, 100.0, 8.0])).to(gpu)
+    t = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(gpu)
+    base = [t(1, P, 3), t(1, P, 3).abs() + 0.1, t(1, P, 4), t(1, P, 17), torch.rand(1, P, 1, device=gpu)]
+    if flavour == "empty_no_opacity":
+        base[4] = torch.empty(1, P, 0, device=gpu)
+    outs, grads = [], []
+    for fused in (True, False):
+        leaves = [x.clone().requires_grad_(x.numel() > 0) for x in base]
+        if args.with_emtpy:
+            args.empty_scalar.grad = None
+        res = args(*leaves) if fused else args._forward_torch(*leaves)
+        means, opa, sem, scales, cov = res
+        g = torch.Generator(device="cpu").manual_seed(5)
+        loss = sum((x * torch.randn(x.shape, generator=g).to(gpu)).sum() for x in (means, opa, sem, scales, cov) if x.requires_grad)
+        loss.backward()
+        outs.append([x.detach() for x in res])
+        grads.append([x.grad for x in leaves if x.requires_grad] + ([args.empty_scalar.grad.clone()] if args.with_emtpy else []))
+    for a, b in zip(*outs):
+        assert a.shape == b.shape
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7) if prob else torch.equal(a, b)
+    assert len(grads[0]) == len(grads[1])
+    for a, b in zip(*grads):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)

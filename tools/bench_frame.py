@@ -160,8 +160,7 @@ class Frame(nn.Module):
         # constants as buffers (no host-to-device copy inside the frame: the frame can be captured as a HIP graph)
         self.register_buffer("pc_lo", torch.tensor(PC_RANGE[:3]), persistent=False)
         self.register_buffer("pc_span", torch.tensor(PC_RANGE[3:]) - torch.tensor(PC_RANGE[:3]), persistent=False)
-        e = torch.zeros(1, 1, 18); e[..., 17] = 10.0
-        self.register_buffer("empty_sem", e, persistent=False)
+        self.register_buffer("empty_scalar", torch.full((1,), 10.0), persistent=False)
         self.register_buffer("empty_mean", torch.tensor([[[0.0, 0.0, -1.0]]]), persistent=False)
         self.register_buffer("empty_scale", torch.tensor([[[100.0, 100.0, 8.0]]]), persistent=False)
         self.register_buffer("empty_rot", torch.tensor([[[1.0, 0.0, 0.0, 0.0]]]), persistent=False)
@@ -179,13 +178,11 @@ class Frame(nn.Module):
         else:
             opa = torch.ones_like(anchor[..., :1])
         sem = anchor[..., k:]
-        if c["with_empty"]:   # gaussian_head.py:90-102
-            sem = torch.cat([F.softplus(sem), torch.zeros_like(sem[..., :1])], dim=-1)
-            means = torch.cat([means, self.empty_mean], dim=1)
-            scales = torch.cat([scales, self.empty_scale], dim=1)
-            rots = torch.cat([rots, self.empty_rot], dim=1)
-            sem = torch.cat([sem, self.empty_sem], dim=1)
-            opa = torch.cat([opa, opa.new_ones(1, 1, 1)], dim=1)
+        if c["with_empty"]:   # gaussian_head.py:90-102: zero column + the appended empty Gaussian, one launch (gf_gaussian_pack)
+            from gaussianformer_amd.gaussian_prepare import _GaussianPack
+            means, scales, rots, sem, opa = _GaussianPack.apply(
+                means, scales, rots, F.softplus(sem), opa, self.empty_scalar, [[0.0, 0.0, -1.0], [100.0, 100.0, 8.0], [1.0, 0.0, 0.0, 0.0]],
+                18, False, True, False, 17)
         return means, scales, rots, opa, sem
 
     @torch.no_grad()
