@@ -148,7 +148,10 @@ class _GaussianPack(torch.autograd.Function):
                     None if opa is None else opa.shape)
         if softmax:
             ctx.save_for_backward(outs[3])
-        return tuple(t[None] for t in outs[:4]) + (outs[4][None, :, None],)
+        res = tuple(t[None] for t in outs[:4]) + (outs[4][None, :, None],)
+        if opa is None:
+            ctx.mark_non_differentiable(res[4])   # all ones, as the reference's torch.ones_like
+        return res
 
     @staticmethod
     def backward(ctx, gm, gs, gq, gsem, gopa):

@@ -221,7 +221,8 @@ def test_gaussian_pack_matches_the_reference_op_sequence(gpu, flavour):
         res = args(*leaves) if fused else args._forward_torch(*leaves)
         means, opa, sem, scales, cov = res
         g = torch.Generator(device="cpu").manual_seed(5)
-        loss = sum((x * torch.randn(x.shape, generator=g).to(gpu)).sum() for x in (means, opa, sem, scales, cov) if x.requires_grad)
+        weights = [torch.randn(x.shape, generator=g).to(gpu) for x in (means, opa, sem, scales, cov)]
+        loss = sum((x * w).sum() for x, w in zip((means, opa, sem, scales, cov), weights) if x.requires_grad)
         loss.backward()
         outs.append([x.detach() for x in res])
         grads.append([x.grad for x in leaves if x.requires_grad] + ([args.empty_scalar.grad.clone()] if args.with_emtpy else []))

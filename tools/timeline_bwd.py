@@ -30,6 +30,8 @@ lib.gf_debug_set_bwd_timeline(tl.data_ptr())
 run(); torch.cuda.synchronize()
 lib.gf_debug_set_bwd_timeline(None)
 T = tl.cpu().numpy().reshape(nu, 8).astype(np.float64)
+os.makedirs("gpurun_out", exist_ok=True)
+np.save(f"gpurun_out/timeline_bwd_{config}.npy", tl.cpu().numpy().reshape(nu, 8))
 T = T[T[:, 0] > 0]
 groups = T[:, 7].copy()
 t0 = T[:, 0].min()
