@@ -17,7 +17,9 @@ constexpr int kRecDwords = 32;       // packed per-Gaussian record, 128 B
 constexpr int kWRow = 618;           // bitmask row words (P <= 39 552) the wave-autonomous matrix-core kernels (forward and backward) hold in LDS
 constexpr int kBwdRowDwords = 32;    // matrix-core backward: one 128-B row of partial gradients per (Gaussian, double brick)
 constexpr int kBwdBigRows = 512;     // ... a Gaussian with more rows than this is summed by whole workgroups (big list)
-constexpr int kBwdBigCap = 1024;     // ... entries of that list
+constexpr int kBwdBigCap = 1024;     // ... waves of 64 Gaussians the layout words provide for (>= kWRow)
+constexpr int kGenWord = 8100;       // generation word of a workspace: index into its flag section -- the same word whatever the call's
+                                     // shape; every launch that rewrites the records (or the sections they share with other shapes) bumps it
 
 // record layout (dwords)
 //  0..2 mean xyz | 3 opacity | 4..9 cov (xx,yy,zz,xy,yz,xz) | 10 box lo | 11 box hi (excl.)
@@ -50,8 +52,7 @@ struct SplatWorkspace {
     uint32_t *sort_hist;    // [64][ceil(P/256)] + [64] backward: per-(cell, block) counts -> offsets, cell totals
     float *dotlg;           // [N]  prob backward: sum_c dL/dlogits[n][c] * logits[n][c]
     uint32_t *range_flags;  // [nwords + 4] forward, matrix-core kernel: per 64 Gaussians, 4 = theta range, 8 = opacity * semantics range
-    uint32_t *bwd_alloc;    // [64]  matrix-core backward: [0] row cursor, [1] big-list length, [2] Gaussians without rows (atomics instead)
-    int *bwd_big;           // [kBwdBigCap] matrix-core backward: Gaussians with more than kBwdBigRows rows
+    uint32_t *bwd_wave_total;  // [kBwdBigCap] matrix-core backward: rows needed by each wave of 64 Gaussians (bit 31: one needs > kBwdBigRows)
     float *bwd_rows;        // [bwd_cap][32] matrix-core backward: partial gradients per (Gaussian, double brick)
     uint32_t bwd_cap;       // rows available (0: the shape does not take the matrix-core backward)
     int nwords, nrow, nsx, nsy, nsuper;
@@ -91,8 +92,7 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
         const long long cap = ws.nrow <= kWRow ? 16ll * P + 2 * nunits + 1024 : 0;
         ws.bwd_cap = (uint32_t)(cap < (1ll << 31) ? cap : (1ll << 31) - 1);
     }
-    ws.bwd_alloc = (uint32_t *)(p + off); off += 256;
-    ws.bwd_big = (int *)(p + off); off += align256((size_t)kBwdBigCap * 4);
+    ws.bwd_wave_total = (uint32_t *)(p + off); off += align256((size_t)kBwdBigCap * 4);
     ws.bwd_rows = (float *)(p + off); off += align256((size_t)ws.bwd_cap * kBwdRowDwords * 4);
     ws.total_bytes = off;
     return ws;
@@ -132,16 +132,17 @@ __device__ __forceinline__ void prob_det_kdet(float c0, float c1, float c2, floa
 // the partial-gradient buffer (record dword 31; splat_bwd_mfma.hip).  Launches one kernel on `stream`.
 void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, int D, const float *pts, const int *points_int,
                               const float *means3D, const int *means3D_int, const float *opacity, const float *semantics,
-                              const int *radii, const float *cov3D, const SplatWorkspace &ws, hipStream_t stream);
+                              const int *radii, const float *cov3D, const uint32_t *state, const SplatWorkspace &ws, hipStream_t stream);
 
-// The matrix-core backward of the base variant (splat_bwd_mfma.hip): zero -> records pass -> gradient kernel -> row sums.
+// The matrix-core backward of the base variant (splat_bwd_mfma.hip): [records pass ->] set-up -> gradient kernel -> row sums.
+// records_asserted: 1 = no records pass; every kernel checks the workspace's generation against the state block's instead.
 // gate: 0 = unconditional; 1 = stands down unless the forward's state block says a matrix-core body rendered the call;
 // 2 = writes NaN gradients in that case.
 void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, int D, const float *pts, const int *points_int,
                                 const float *means3D, const int *means3D_int, const float *opacity, const float *semantics,
                                 const int *radii, const float *cov3D, const float *out_grad, float *means_grad,
                                 float *opa_grad, float *sem_grad, float *cov_grad, const uint32_t *state,
-                                const SplatWorkspace &ws, int gate, hipStream_t stream);
+                                const SplatWorkspace &ws, int gate, int records_asserted, hipStream_t stream);
 
 // ---- error reporting ----------------------------------------------------------------
 void set_error(const char *fmt, ...);

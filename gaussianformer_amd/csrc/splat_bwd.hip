@@ -57,6 +57,7 @@ struct BwdArgs {
     int *seg;             // [P][8] (input index, volume, box lo[3], box hi[3]) at each sorted position: one scalar fetch per segment
     uint32_t *sort_hist;  // [kSortCells][nblk]
     float *dotlg;         // prob only, [N]: sum_c out_grad[n][c] * logits[n][c]
+    uint32_t *gen_word;   // the workspace's generation word (gf_common.hpp, kGenWord)
     int P, N, H, W, D, per_axis, force_general, assume_dense, nblk, exact_det;
     int gate;   // 1: every kernel of this (Gaussian-major) pipeline stands down when the forward's state block says a matrix-core
                 // body rendered the call -- the matrix-core backward (splat_bwd_mfma.hip), launched beside it, takes the call then
@@ -173,6 +174,8 @@ __device__ __forceinline__ int sort_cell(const BwdArgs &a, int g)
 __global__ __launch_bounds__(256) void gf_bwd_vol_kernel(BwdArgs a)
 {
     if (gated_off(a)) return;
+    // this pipeline's scratch may lie over another call shape's records in the same workspace: new generation
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.gen_word = *a.gen_word + 1u;
     __shared__ uint32_t s_hist[kSortCells];
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (threadIdx.x < kSortCells) s_hist[threadIdx.x] = 0u;
@@ -719,6 +722,7 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     a.assume_dense = (!a.force_general && (flags & GF_PTS_ASSUME_DENSE)) ? 1 : 0;
     a.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
     a.gate = 0;
+    a.gen_word = ws.flags + kGenWord;
 
     // The matrix-core backward (splat_bwd_mfma.hip) takes the calls the forward's matrix-core kernels rendered -- word 1 of
     // the state block, which only the device knows.  Default: BOTH pipelines are launched, each gated on that word (the
@@ -729,8 +733,12 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
                                !(flags & GF_EXACT_FP32) && getenv("GF_BWD_EXACT") == nullptr;
     if (mfma_eligible) {
         const int gate = (flags & GF_MFMA_SPLAT) ? 2 : 1;
+        // GF_RECORDS_VALID: the caller vouches that `workspace` has not been used since the forward that wrote `state` -- its
+        // records, boxes and bitmask are taken as they are (checked on the device: generation word; NaN gradients if not so).
+        // Without the flag the records pass is launched and stands down by itself in that case.
         launch_splat_backward_mfma(a.per_axis, P, N, H, W, D, pts, points_int, means3D, means3D_int, opacity, semantics, radii, cov3D,
-                                   logits_grad, means3D_grad, opacity_grad, semantics_grad, cov3D_grad, a.state, ws, gate, stream);
+                                   logits_grad, means3D_grad, opacity_grad, semantics_grad, cov3D_grad, a.state, ws, gate,
+                                   (flags & GF_RECORDS_VALID) ? 1 : 0, stream);
         if (gate == 2) {
             GF_CHECK_LAUNCH();
             return GF_OK;

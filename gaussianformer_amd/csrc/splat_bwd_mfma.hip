@@ -60,10 +60,10 @@ struct BwdMArgs {
     float *means_grad, *opa_grad, *sem_grad, *cov_grad;
     const uint32_t *state;       // the forward's state block
     uint32_t *tile_counters;     // [64 x]: next unclaimed unit of XCD x
-    const uint32_t *alloc;       // [0] rows handed out, [1] big-list length
-    const int *big;              // big list
+    const uint32_t *gen_word;    // the workspace's generation word
     int P, N, nwords, nrow, H, W, D, nsx, nsy;
-    int gate;                    // 1: run only if the forward's state says "matrix cores"; 2: write NaN gradients otherwise
+    int gate;                    // 1: run only if the forward's state says "matrix cores" (2: the set-up kernel wrote NaN gradients otherwise)
+    int records_asserted;        // 1: no records pass ran -- stand down unless the workspace still holds the forward's (generation)
     unsigned long long *timeline;  // debug (GF_TIMELINE builds): 8 stamps per unit
 };
 
@@ -125,25 +125,73 @@ __device__ __forceinline__ bool state_is_matrix_core(const uint32_t *state)
 }
 
 // ---------------------------------------------------------------------------------------
-// zeroes the four gradient outputs and the row allocator (one launch ahead of the records pass)
-struct BwdZeroArgs {
+__device__ __forceinline__ bool records_still_there(const uint32_t *state, const uint32_t *gen_word)
+{
+    return state[3] == *gen_word && (state[4] & 1u) != 0u;
+}
+
+// ---------------------------------------------------------------------------------------
+// One launch ahead of the gradient kernel: zeroes the four gradient outputs, arms the per-XCD unit counters and turns the
+// records pass's row layout (per wave of 64 Gaussians: rows needed; per Gaussian: offset inside its wave, record dword 30) into
+// every Gaussian's first row (record dword 31; 0xFFFFFFFF = the buffer has no room: atomics instead).  Repeating it gives the
+// same words, so a second backward of the same forward finds the records as it needs them.
+struct BwdSetupArgs {
     float *means_grad, *opa_grad, *sem_grad, *cov_grad;
-    uint32_t *alloc;
+    float *records;
+    const uint32_t *wave_total;
+    uint32_t *gen_word;
+    uint32_t *tile_counters;
     const uint32_t *state;
-    int P, gate;
+    uint32_t tile_counter_init, cap;
+    int P, gate, records_asserted;
 };
 
-__global__ __launch_bounds__(256) void gf_splat_bwd_zero_kernel(BwdZeroArgs a)
+__global__ __launch_bounds__(256) void gf_splat_bwd_setup_kernel(BwdSetupArgs a)
 {
-    if (blockIdx.x == 0 && threadIdx.x < 64) a.alloc[threadIdx.x] = 0u;
-    if (a.gate == 1 && !state_is_matrix_core(a.state)) return;
-    const float fill = (a.gate == 2 && !state_is_matrix_core(a.state)) ? __uint_as_float(0x7fc00000u) : 0.f;
+    const bool mc = state_is_matrix_core(a.state);
+    if (a.gate == 1 && !mc) return;
+    // a caller's assertion that does not hold (not a matrix-core forward, or the workspace has been used since) gives NaN, not
+    // wrong numbers
+    const bool bad = (a.gate == 2 && !mc) || (a.records_asserted && !records_still_there(a.state, a.gen_word));
+    const float fill = bad ? __uint_as_float(0x7fc00000u) : 0.f;
     // the four arrays as flat runs of floats, grid-strided (coalesced dword stores; the arrays need not be 16-byte aligned)
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     for (size_t i = i0; i < (size_t)kC * a.P; i += stride) a.sem_grad[i] = fill;
     for (size_t i = i0; i < (size_t)6 * a.P; i += stride) a.cov_grad[i] = fill;
     for (size_t i = i0; i < (size_t)3 * a.P; i += stride) a.means_grad[i] = fill;
     for (size_t i = i0; i < (size_t)a.P; i += stride) a.opa_grad[i] = fill;
+    if (bad) return;
+    if (blockIdx.x == 0 && threadIdx.x < 8) a.tile_counters[64 * threadIdx.x] = a.tile_counter_init;
+    // (the records pass ran just now, because the generations differed: the workspace no longer holds what any earlier
+    // forward's state block describes.  Nobody else reads the word in this launch.)
+    if (!a.records_asserted && blockIdx.x == 0 && threadIdx.x == 0 && !records_still_there(a.state, a.gen_word))
+        *a.gen_word = *a.gen_word + 1u;
+    // ---- first rows: workgroup b has Gaussians [256 b, 256 b + 256) = waves 4 b .. 4 b + 3 of the records pass
+    const int nblk = (a.P + 255) >> 8;
+    if ((int)blockIdx.x >= nblk) return;
+    __shared__ uint32_t s_sum[4];
+    const int tid = threadIdx.x, w0 = 4 * (int)blockIdx.x, nw = (a.P + 63) >> 6;
+    uint32_t before = 0u;
+    for (int w = tid; w < w0; w += 256) before += a.wave_total[w] & 0x7FFFFFFFu;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off, 64);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = before;
+    __syncthreads();
+    uint32_t base = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    const int wv = tid >> 6;
+    uint32_t mine = 0u;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = w0 + k < nw ? (a.wave_total[w0 + k] & 0x7FFFFFFFu) : 0u;
+        if (k < wv) base += t;
+        if (k == wv) mine = t;
+    }
+    const int g = 256 * (int)blockIdx.x + tid;
+    if (g < a.P) {
+        // (a wave's rows are taken or left as a whole)
+        const bool fits = (unsigned long long)base + mine <= (unsigned long long)a.cap;
+        uint32_t *rec = reinterpret_cast<uint32_t *>(a.records + (size_t)g * kRecDwords);
+        rec[31] = fits ? base + rec[30] : 0xFFFFFFFFu;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -157,6 +205,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     uint32_t *q_id = s_u + 1536 + 3 * kMList + kC * kMPitch;
 
     if (a.gate && !state_is_matrix_core(a.state)) return;
+    if (a.records_asserted && !records_still_there(a.state, a.gen_word)) return;
 
     const int lane = threadIdx.x;
     const int n_ = lane & 31, h_ = lane >> 5;
@@ -848,10 +897,10 @@ struct BwdRowsArgs {
     const float *records;
     const float *rows;
     float *means_grad, *opa_grad, *sem_grad, *cov_grad;
-    const uint32_t *alloc;
-    const int *big;
+    const uint32_t *wave_total;   // records pass: rows per wave of 64 Gaussians, bit 31 = the wave has a Gaussian of more than kBwdBigRows rows
+    const uint32_t *gen_word;
     const uint32_t *state;
-    int P, gate, ngauss_blocks;
+    int P, gate, ngauss_blocks, records_asserted;
 };
 
 __device__ __forceinline__ void bwd_store_column(const BwdRowsArgs &a, int g, int col, float v, bool atomic)
@@ -869,6 +918,7 @@ __device__ __forceinline__ void bwd_store_column(const BwdRowsArgs &a, int g, in
 __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
 {
     if (a.gate && !state_is_matrix_core(a.state)) return;
+    if (a.records_asserted && !records_still_there(a.state, a.gen_word)) return;
     const int tid = threadIdx.x, col = tid & 31, sub = tid >> 5;
     auto box_rows = [&](int g, uint32_t &first) -> int {
         const float4 r2 = *reinterpret_cast<const float4 *>(a.records + (size_t)g * kRecDwords + 8);
@@ -897,39 +947,67 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
         bwd_store_column(a, g, col, acc, false);
         return;
     }
-    // ---- big Gaussians: work item = 512 rows of one of them
+    // ---- big Gaussians: work item = 512 rows of one of them.  Every workgroup of this range walks the flagged waves and their
+    // Gaussians in the same (ascending) order and takes the items that fall to it.
     __shared__ float s_part[8][32];
-    const int nbig = min((int)a.alloc[1], kBwdBigCap);
+    __shared__ int s_wave[kBwdBigCap], s_cnt[64];
+    __shared__ uint32_t s_first[64];
+    __shared__ int s_nwave;
+    const int nw = (a.P + 63) >> 6;
+    if (tid < 64) {   // wave 0: flagged waves, compacted in order
+        int n = 0;
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            const bool f = w0 + tid < nw && (a.wave_total[w0 + tid] >> 31) != 0u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+            if (f) s_wave[n + __builtin_popcountll(m & ((1ull << tid) - 1ull))] = w0 + tid;
+            n += __builtin_popcountll(m);
+        }
+        if (tid == 0) s_nwave = n;
+    }
+    __syncthreads();
+    const int nflag = s_nwave;
     int item = (int)blockIdx.x - a.ngauss_blocks;
     const int stride = (int)gridDim.x - a.ngauss_blocks;
-    for (int e = 0; e < nbig; ++e) {
-        const int g = a.big[e];
-        uint32_t first;
-        const int cnt = box_rows(g, first);
-        const int parts = (cnt + 511) / 512;
-        while (item < parts) {
-            const int r0 = item * 512, r1 = min(cnt, r0 + 512);
-            const float *base = a.rows + ((size_t)first + r0) * kBwdRowDwords + col;
-            float acc = 0.f;
-            for (int r = sub; r0 + r < r1; r += 32) {   // eight half-waves, four rows in flight each
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = base[(size_t)min(r + 8 * k, r1 - r0 - 1) * kBwdRowDwords];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc += (r0 + r + 8 * k < r1) ? v[k] : 0.f;
-            }
-            s_part[sub][col] = acc;
-            __syncthreads();
-            if (sub == 0) {
-                float t = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) t += s_part[k][col];
-                bwd_store_column(a, g, col, t, true);
-            }
-            __syncthreads();
-            item += stride;
+    for (int e = 0; e < nflag; ++e) {
+        __syncthreads();
+        if (tid < 64) {
+            const int gq = 64 * s_wave[e] + tid;
+            uint32_t first = 0xFFFFFFFFu;
+            const int cnt = gq < a.P ? box_rows(gq, first) : 0;
+            s_cnt[tid] = first == 0xFFFFFFFFu ? 0 : cnt;   // (no rows: the gradient kernel used atomics)
+            s_first[tid] = first;
         }
-        item -= parts;
+        __syncthreads();
+        for (int j = 0; j < 64; ++j) {
+            const int cnt = s_cnt[j];
+            if (cnt <= kBwdBigRows) continue;
+            const int g = 64 * s_wave[e] + j;
+            const uint32_t first = s_first[j];
+            const int parts = (cnt + 511) / 512;
+            while (item < parts) {
+                const int r0 = item * 512, r1 = min(cnt, r0 + 512);
+                const float *base = a.rows + ((size_t)first + r0) * kBwdRowDwords + col;
+                float acc = 0.f;
+                for (int r = sub; r0 + r < r1; r += 32) {   // eight half-waves, four rows in flight each
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = base[(size_t)min(r + 8 * k, r1 - r0 - 1) * kBwdRowDwords];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc += (r0 + r + 8 * k < r1) ? v[k] : 0.f;
+                }
+                s_part[sub][col] = acc;
+                __syncthreads();
+                if (sub == 0) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t += s_part[k][col];
+                    bwd_store_column(a, g, col, t, true);
+                }
+                __syncthreads();
+                item += stride;
+            }
+            item -= parts;
+        }
     }
 }
 
@@ -958,23 +1036,29 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
                                 const float *means3D, const int *means3D_int, const float *opacity, const float *semantics,
                                 const int *radii, const float *cov3D, const float *out_grad, float *means_grad,
                                 float *opa_grad, float *sem_grad, float *cov_grad, const uint32_t *state,
-                                const SplatWorkspace &ws, int gate, hipStream_t stream)
+                                const SplatWorkspace &ws, int gate, int records_asserted, hipStream_t stream)
 {
-    BwdZeroArgs z{means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_alloc, state, P, gate};
-    hipLaunchKernelGGL(gf_splat_bwd_zero_kernel, dim3(std::min(1024, (kC * P + 255) / 256)), dim3(256), 0, stream, z);
-    launch_prep_for_backward(radii_per_axis, P, N, H, W, D, pts, points_int, means3D, means3D_int, opacity, semantics, radii,
-                             cov3D, ws, stream);
+    uint32_t *gen_word = ws.flags + kGenWord;
+    // the records pass, unless the caller vouches for the forward's; it stands down by itself if the workspace still holds them
+    if (!records_asserted)
+        launch_prep_for_backward(radii_per_axis, P, N, H, W, D, pts, points_int, means3D, means3D_int, opacity, semantics, radii,
+                                 cov3D, state, ws, stream);
+    const int nunits = ws.nsuper * 4 * ((D + 7) / 8);
+    const int grid = bwd_mfma_grid(nunits);
+    BwdSetupArgs z{means_grad, opa_grad, sem_grad, cov_grad, ws.records, ws.bwd_wave_total, gen_word, ws.flags + 4608, state,
+                   (uint32_t)(grid / 8), ws.bwd_cap, P, gate, records_asserted};
+    hipLaunchKernelGGL(gf_splat_bwd_setup_kernel, dim3(std::max((P + 255) / 256, std::min(1024, (kC * P + 255) / 256))), dim3(256), 0,
+                       stream, z);
     BwdMArgs a;
     a.pts = pts; a.records = ws.records; a.boxes = ws.boxes; a.bitmask = ws.bitmask; a.out_grad = out_grad; a.rows = ws.bwd_rows;
     a.means_grad = means_grad; a.opa_grad = opa_grad; a.sem_grad = sem_grad; a.cov_grad = cov_grad; a.state = state;
-    a.tile_counters = ws.flags + 4608; a.alloc = ws.bwd_alloc; a.big = ws.bwd_big;
+    a.tile_counters = ws.flags + 4608; a.gen_word = gen_word;
     a.P = P; a.N = N; a.nwords = ws.nwords; a.nrow = ws.nrow; a.H = H; a.W = W; a.D = D; a.nsx = ws.nsx; a.nsy = ws.nsy;
-    a.gate = gate ? 1 : 0;
+    a.gate = gate ? 1 : 0; a.records_asserted = records_asserted;
     a.timeline = g_bwd_timeline;
-    const int nunits = ws.nsuper * 4 * ((D + 7) / 8);
-    hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel, dim3(bwd_mfma_grid(nunits)), dim3(64), 0, stream, a);
-    BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_alloc, ws.bwd_big, state, P, gate ? 1 : 0,
-                  (P + 7) / 8};
+    hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel, dim3(grid), dim3(64), 0, stream, a);
+    BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, gen_word, state, P, gate ? 1 : 0,
+                  (P + 7) / 8, records_asserted};
     hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + 256), dim3(256), 0, stream, r);
 }
 

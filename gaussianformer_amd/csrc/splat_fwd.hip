@@ -53,9 +53,10 @@ struct PrepArgs {
     int P, N, H, W, D, nwords, nrow, nsx, nsy, per_axis, variant, nprep_blocks, verify, prescale, exact_det, lattice;
     uint32_t *tile_counters;  // null, or the eight per-XCD tile counters of the matrix-core render kernel ...
     uint32_t tile_counter_init;  // ... and the value they start from (the workgroups per XCD: those tiles are taken)
-    uint32_t *unit_alloc;    // null (forward), or the matrix-core backward's row allocator: [0] cursor, [1] big-list length, [2] overflows
-    int *unit_big;           // ... its big list
-    uint32_t unit_cap;       // ... and the rows available
+    uint32_t *unit_totals;   // null, or [nwords]: rows of the matrix-core backward's partial-gradient buffer the wave's 64 Gaussians
+                             // need (bit 31: one of them needs more than kBwdBigRows); record dword 30 = the Gaussian's offset in its wave
+    uint32_t *gen_word;      // null, or the workspace's generation word: bumped by every launch that rewrites the records
+    const uint32_t *gate_state;  // null, or (backward) the forward's state block: stand down if the workspace still holds its records
     int range_theta_here;    // 1: the records pass checks theta as well as opacity * semantics (no verification waves: GF_PTS_ASSUME_DENSE)
     uint32_t *range_flags;   // null, or [nwords + 4]: per wave of 64 Gaussians, bit 2 = a Gaussian's theta may leave the f16
                              // range, bit 3 = |opacity * semantics| may (matrix-core render kernel: both change per frame, so
@@ -126,6 +127,14 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     // LDS is sized at launch: [min(#supertiles, chunk)][WAVES] words.
     extern __shared__ unsigned long long s_bits[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.gate_state) {
+        // backward: the records of the forward that wrote this state block are still in the workspace (same generation) --
+        // nothing to redo; or that forward was not rendered on the matrix cores -- the Gaussian-major kernels need no records
+        const bool mc = a.gate_state[0] == 0u && (a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE || a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE_WAVE);
+        if (!mc || (a.gate_state[3] == *a.gen_word && (a.gate_state[4] & 1u))) return;
+    } else if (a.gen_word && blockIdx.x == 0 && threadIdx.x == 0) {
+        *a.gen_word = *a.gen_word + 1u;   // (any start value will do: the word only has to change)
+    }
     const int chunk = kPrepSuperChunk / WAVES;  // supertiles per LDS pass
     const int bits_words = min(chunk, a.nsx * a.nsy) * WAVES;  // bitmask words in LDS; record images follow
     auto wg_sync = [&]() {
@@ -262,32 +271,18 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
     }
     const bool nonempty = valid && hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2];
-    // Matrix-core backward: the Gaussian's rows of the partial-gradient buffer, one per double brick (4 x 4 x 8 voxels) its box
-    // meets, row (bx, by, bz) of the box's brick range at  first + ((bx - bx0) nby + (by - by0)) nbz + (bz - bz0).  One
-    // returning atomic per wave of 64 Gaussians: which rows a Gaussian gets varies from run to run, what is written to them
-    // and the order they are summed in does not.
+    // Matrix-core backward: a Gaussian owns one row of the partial-gradient buffer per double brick (4 x 4 x 8 voxels) its box
+    // meets, row (bx, by, bz) of the box's brick range at  first + ((bx - bx0) nby + (by - by0)) nbz + (bz - bz0).  Here: the
+    // Gaussian's offset inside its wave of 64 (record dword 30) and the wave's total; the backward's set-up kernel turns the
+    // totals into `first` (record dword 31).  No atomics, no counter to reset: the rows a Gaussian gets are the same every run.
     uint32_t unit_first = 0u;
-    if (a.unit_alloc) {
+    if (a.unit_totals) {
         const int cnt = nonempty ? (((hi[0] - 1) >> 2) - (lo[0] >> 2) + 1) * (((hi[1] - 1) >> 2) - (lo[1] >> 2) + 1) *
                                        (((hi[2] - 1) >> 3) - (lo[2] >> 3) + 1) : 0;
         const int incl = wave_inclusive_scan(cnt);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        uint32_t base = 0u;
-        if (lane == 0 && total) base = atomicAdd(a.unit_alloc, (uint32_t)total);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        unit_first = base + (uint32_t)(incl - cnt);
-        if (cnt > 0) {
-            bool fits = (unsigned long long)unit_first + (unsigned)cnt <= (unsigned long long)a.unit_cap;
-            if (fits && cnt > kBwdBigRows) {
-                const uint32_t slot = atomicAdd(a.unit_alloc + 1, 1u);
-                if (slot < (uint32_t)kBwdBigCap) a.unit_big[slot] = g;
-                else fits = false;
-            }
-            if (!fits) {
-                unit_first = 0xFFFFFFFFu;   // no rows: this Gaussian's partial gradients are accumulated with atomics
-                atomicAdd(a.unit_alloc + 2, 1u);
-            }
-        }
+        unit_first = (uint32_t)(incl - cnt);
+        const bool any_big = __builtin_amdgcn_ballot_w64(cnt > kBwdBigRows) != 0ull;
+        if (lane == 63) a.unit_totals[word] = (uint32_t)incl | (any_big ? 0x80000000u : 0u);
     }
     // supertile range touched by the box
     const int sx_lo = lo[0] / kSuper, sx_hi = nonempty ? (hi[0] - 1) / kSuper : -1;
@@ -328,7 +323,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             rec[4] = make_float4(sm[4], sm[5], sm[6], sm[7]);
             rec[5] = make_float4(sm[8], sm[9], sm[10], sm[11]);
             rec[6] = make_float4(sm[12], sm[13], sm[14], sm[15]);
-            rec[7] = make_float4(sm[16], sm[17], kdet, __uint_as_float(unit_first));
+            rec[7] = make_float4(sm[16], sm[17], a.unit_totals ? __uint_as_float(unit_first) : kdet, __uint_as_float(0xFFFFFFFFu));
         }
     } else {
         // ---- records, large P.  The 64 Gaussians of a wave are contiguous in every input array, so the
@@ -399,8 +394,8 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             } else {
                 rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
             }
-            row[30] = kdet;
-            row[31] = __uint_as_float(unit_first);
+            row[30] = a.unit_totals ? __uint_as_float(unit_first) : kdet;
+            row[31] = __uint_as_float(0xFFFFFFFFu);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -482,7 +477,17 @@ struct RenderArgs {
     uint32_t *tile_counters;  // matrix-core kernel: next unclaimed tile of XCD x at [64 x] (one cache line each)
     const uint32_t *range_flags;  // matrix-core kernels: the records pass's range verdicts, nrange4 16-byte pieces (null = none)
     int nrange4;
+    uint32_t rows_valid;  // state word 4: bit 0 = the records pass laid out the matrix-core backward's rows (record dword 30)
 };
+
+// Words 3 and 4 of the state block: the workspace's generation (gf_splat_prep_kernel bumped it) and whether the records carry
+// the backward's row offsets.  gf_splat_backward compares the generation with the workspace's: equal = the forward's records,
+// boxes and bitmask are still there and the records pass is not repeated.
+__device__ __forceinline__ void stamp_state(const RenderArgs &a)
+{
+    a.state[3] = a.verify_flags[kGenWord - 64];   // (verify_flags = flags + 64)
+    a.state[4] = a.rows_valid;
+}
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
 constexpr int kListCap = 4608;  // tile list entries (Gaussian ids, 4 B each) held in LDS
@@ -732,6 +737,7 @@ __global__ __launch_bounds__(kBlock) void gf_splat_render_general_kernel(RenderA
         a.state[0] = 1u;
         a.state[1] = GF_PATH_ARBITRARY;
         a.state[2] = 0u;
+        stamp_state(a);
     }
     general_body<VARIANT, EXP, LABELS>(a);
 }
@@ -793,6 +799,7 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
         a.state[0] = nondense ? 1u : 0u;
         a.state[1] = nondense ? GF_PATH_ARBITRARY : GF_PATH_EXACT_TILE;
         a.state[2] = nondense ? 1u : 0u;
+        stamp_state(a);
     }
     if (nondense) {
         general_body<VARIANT, EXP, LABELS>(a);
@@ -1151,6 +1158,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     if (blockIdx.x == 0 && tid == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
         a.state[1] = nondense ? GF_PATH_ARBITRARY : GF_PATH_MATRIX_CORE;
+        stamp_state(a);
     }
     if (blockIdx.x == 0 && a.state && a.verify_dense) {
         // the exact verdict bits, for the caller's diagnostics
@@ -1767,6 +1775,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
         a.state[0] = (verdict & 1) ? 1u : 0u;
         a.state[1] = verdict ? GF_PATH_ARBITRARY : GF_PATH_MATRIX_CORE_WAVE;
         a.state[2] = (uint32_t)verdict;
+        stamp_state(a);
     }
     if (verdict) {
         general_body<GF_SPLAT_BASE, kExpComp, LABELS>(a);
@@ -2454,7 +2463,7 @@ static void launch_render_exp(int flags, bool dense_candidate, const RenderArgs 
 
 void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, int D, const float *pts, const int *points_int,
                               const float *means3D, const int *means3D_int, const float *opacity, const float *semantics,
-                              const int *radii, const float *cov3D, const SplatWorkspace &ws, hipStream_t stream)
+                              const int *radii, const float *cov3D, const uint32_t *state, const SplatWorkspace &ws, hipStream_t stream)
 {
     PrepArgs pa;
     pa.means3D = means3D; pa.means_int = means3D_int; pa.opacity = opacity; pa.semantics = semantics;
@@ -2464,10 +2473,9 @@ void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, in
     const int prep_waves = P >= 65536 ? 4 : 1;
     pa.variant = GF_SPLAT_BASE; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = 0;
     pa.prescale = 0; pa.exact_det = 0; pa.lattice = 0;
-    pa.tile_counters = ws.flags + 4608;   // the backward kernel claims its units from the same eight per-XCD counters
-    pa.tile_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);
+    pa.tile_counters = nullptr; pa.tile_counter_init = 0u;   // (the backward's set-up kernel arms the unit counters)
     pa.range_flags = nullptr; pa.range_theta_here = 0;
-    pa.unit_alloc = ws.bwd_alloc; pa.unit_big = ws.bwd_big; pa.unit_cap = ws.bwd_cap;
+    pa.unit_totals = ws.bwd_wave_total; pa.gen_word = ws.flags + kGenWord; pa.gate_state = state;
     const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
                             (prep_waves > 1 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
     if (prep_waves == 1) hipLaunchKernelGGL(gf_splat_prep_kernel<1>, dim3(pa.nprep_blocks), dim3(64), prep_lds, stream, pa);
@@ -2551,7 +2559,10 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
     pa.lattice = (mfma && verify) ? 1 : 0;
     uint32_t *tile_counters = ws.flags + 4608;  // [64 x], x < 8: inside the 32 KB flag section, past the verdicts
-    pa.unit_alloc = nullptr; pa.unit_big = nullptr; pa.unit_cap = 0u;
+    // the matrix-core backward's row layout rides along (a scan per wave of 64 Gaussians): a backward that finds the workspace
+    // untouched (generation word) then skips its own records pass
+    pa.unit_totals = (mfma && ws.bwd_cap > 0u && !lab.labels) ? ws.bwd_wave_total : nullptr;
+    pa.gen_word = ws.flags + kGenWord; pa.gate_state = nullptr;
     pa.tile_counters = mfma ? tile_counters : nullptr;
     pa.range_flags = mfma ? ws.range_flags : nullptr;
     pa.range_theta_here = (mfma && !verify) ? 1 : 0;   // (with the point scans running, their waves take the theta verdict)
@@ -2581,6 +2592,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.tile_counters = tile_counters;
     ra.range_flags = mfma ? ws.range_flags : nullptr;
     ra.nrange4 = (ws.nwords + 3) / 4;
+    ra.rows_valid = pa.unit_totals ? 1u : 0u;
     if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);
     else if (variant == GF_SPLAT_BASE)

@@ -25,6 +25,7 @@ class _Workspace:
     accumulate a megabyte-plus per stream ever used, and a recycled stream handle meets at worst its own old buffer."""
     MAX_STREAMS = 8
     _cache = {}
+    _uses = 0
 
     @classmethod
     def get(cls, device, nbytes):
@@ -35,7 +36,16 @@ class _Workspace:
         cls._cache[key] = buf              # most recently used last
         while len(cls._cache) > cls.MAX_STREAMS:
             cls._cache.pop(next(iter(cls._cache)))
+        cls._uses += 1
         return buf
+
+    @classmethod
+    def stamp(cls, device):
+        """(stream's buffer, number of hand-outs so far): equal stamps = nobody has been given a workspace in between, so the
+        buffer still holds what the last call left in it (``GF_RECORDS_VALID``; the library checks it again on the device)."""
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+        buf = cls._cache.get(key)
+        return (key, None if buf is None else buf.data_ptr(), cls._uses)
 
 
 _lattice_cache = {}
@@ -315,9 +325,10 @@ class _LocalAggregate(torch.autograd.Function):
         # to pinned host memory behind an event -- never waited for: by the time the backward runs the copy has usually landed
         # and exactly one pipeline is launched (not while a HIP graph is being captured: no host allocation there).
         ctx.state_host = ctx.state_event = None
+        ctx.ws_stamp = _Workspace.stamp(pts.device) if state.is_cuda else None
         if any(ctx.needs_input_grad) and state.is_cuda and not torch.cuda.is_current_stream_capturing():
-            ctx.state_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
-            ctx.state_host.copy_(state[:12].view(torch.int32), non_blocking=True)
+            ctx.state_host = torch.empty(5, dtype=torch.int32, pin_memory=True)
+            ctx.state_host.copy_(state[:20].view(torch.int32), non_blocking=True)
             ctx.state_event = torch.cuda.Event()
             ctx.state_event.record(torch.cuda.current_stream(pts.device))
         ctx.save_for_backward(state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii)
@@ -335,6 +346,10 @@ class _LocalAggregate(torch.autograd.Function):
             words = ctx.state_host.tolist()
             on_matrix_cores = words[0] == 0 and words[1] in (_lib.GF_PATH_MATRIX_CORE, _lib.GF_PATH_MATRIX_CORE_WAVE)
             bflags = _lib.GF_MFMA_SPLAT if on_matrix_cores else _lib.GF_EXACT_FP32
+            # the forward's records pass laid out the backward's rows as well (word 4); if nobody has been handed this stream's
+            # workspace since, the backward does not repeat that pass
+            if on_matrix_cores and (words[4] & 1) and ctx.ws_stamp == _Workspace.stamp(out_grad.device):
+                bflags |= _lib.GF_RECORDS_VALID
         else:
             bflags = _lib.GF_PTS_AUTO
         mg, og, sg, cg = splat_backward(_lib.GF_SPLAT_BASE, pts, points_int, means3D, means3D_int, opacities,

@@ -74,6 +74,13 @@ extern "C" {
 /* Forward on the exact-fp32 VALU tile kernel (2.3e-6 / 1.0e-6 from the reference; ascending-Gaussian summation order,
  * bit-identical between the dense and the arbitrary-points bodies): the default until ABI version 1. */
 #define GF_EXACT_FP32 256
+/* gf_splat_backward only: the caller vouches that no other gf_splat_* call has used `workspace` since the forward that wrote
+ * `state` (and that the inputs are the ones that forward saw).  The forward's records pass lays out everything the matrix-core
+ * backward needs, so that pass is then not launched again (about 11 us at P = 25 601).  Checked on the device: the
+ * workspace carries a generation word (bumped by every call that rewrites it) and the state block a copy of it (word 3); if
+ * they differ the gradients are NaN, never wrong.  Without the flag the pass is launched and stands down by itself when
+ * the generations agree (an empty launch).  Ignored where the matrix-core backward does not apply. */
+#define GF_RECORDS_VALID 512
 
 /* values of word 1 of the state block after gf_splat_forward: which body rendered the call */
 #define GF_PATH_EXACT_TILE 0     /* exact-fp32 tile kernel (dense grid) */

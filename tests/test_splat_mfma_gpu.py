@@ -3,6 +3,7 @@ through the C ABI: same bound as the default kernel against the CPU oracle / the
 the device-side lattice check, and the fallbacks."""
 import numpy as np
 import pytest
+import torch
 
 import oracle
 from gaussianformer_amd.synthetic import make_splat_inputs
@@ -379,3 +380,74 @@ def test_registered_grid_skips_the_scan_and_keeps_the_verdicts(gpu):
     assert agg.register_grid(shifted) in (True, False)           # (either verdict is fine; the call must be right)
     again = agg(shifted, *args)
     assert torch.isfinite(again).all()
+
+
+def _bwd(gpu, si, t, state, g, flags=0):
+    from util import hip_splat_backward
+    return hip_splat_backward(gpu, si, t, state, None, g, flags=flags)
+
+
+@pytest.mark.gpu
+def test_backward_takes_the_forward_records_when_the_workspace_still_holds_them(gpu):
+    """The forward's records pass lays out the matrix-core backward's rows; the backward repeats that pass only if the workspace
+    has been used since (generation word, checked on the device).  Every combination gives the same bits: default flags after the
+    forward (the pass stands down), after another call of a different shape has overwritten the workspace (the pass runs), twice
+    in a row, and with GF_RECORDS_VALID (no pass launched)."""
+    from gaussianformer_amd import _lib
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=21, P=1500, H=40, W=36, D=16)
+    other = make_splat_inputs("nuscenes_gs25600_solid", seed=22, P=700, H=24, W=28, D=8)
+    pi, mi, radii, cov6 = prep(si)
+    g = np.random.default_rng(5).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
+    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    words = state.view(torch.int32)[:5].tolist()
+    assert words[1] == _lib.GF_PATH_MATRIX_CORE_WAVE and (words[4] & 1) == 1
+    base = _bwd(gpu, si, t, state, g)                                    # records still there
+    ref = oracle.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D, g)
+    for a, b in zip(base, ref):
+        assert np.abs(a - b.reshape(a.shape)).max() <= 1e-4 * max(np.abs(b).max(), 1e-30)
+    again = _bwd(gpu, si, t, state, g)                                   # a second backward of the same forward
+    asserted = _bwd(gpu, si, t, state, g, flags=_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID)
+    for a, b, c in zip(base, again, asserted):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    # another shape through the same workspace: its sections lie over this forward's records
+    hip_splat_forward(gpu, other, *prep(other))
+    redo = _bwd(gpu, si, t, state, g)
+    for a, b in zip(base, redo):
+        assert np.array_equal(a, b)
+    # ... and a caller who vouches for records that are gone gets NaN, not numbers
+    hip_splat_forward(gpu, other, *prep(other))
+    wrong = _bwd(gpu, si, t, state, g, flags=_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID)
+    assert all(np.isnan(a).all() for a in wrong)
+    # the exact pipeline of another shape uses the workspace too
+    _, t2, state2, _ = hip_splat_forward(gpu, other, *prep(other), flags=_lib.GF_EXACT_FP32)
+    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    g2 = np.random.default_rng(6).standard_normal((other.pts.shape[0], 18)).astype(np.float32)
+    _bwd(gpu, other, t2, state2, g2, flags=_lib.GF_EXACT_FP32)
+    after = _bwd(gpu, si, t, state, g)
+    for a, b in zip(base, after):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["several_whole_grid", "buffer_full"])
+def test_backward_rows_of_whole_grid_gaussians_and_of_a_full_buffer(gpu, case):
+    """The row layout without atomics at its edges: Gaussians with more rows than one workgroup sums (648 double bricks each,
+    summed by the workgroups past the Gaussian range), and a buffer that has no room for most waves' rows (those Gaussians fall
+    back to atomics) -- many large Gaussians on a small grid."""
+    from gaussianformer_amd.synthetic import cov_inverse
+    if case == "several_whole_grid":
+        si = make_splat_inputs("nuscenes_gs25600_solid", seed=23, P=20, H=72, W=72, D=16)
+        si.scales[3] = si.scales[11] = si.scales[12] = 60.0
+    else:
+        si = make_splat_inputs("nuscenes_gs25600_solid", seed=24, P=900, H=72, W=72, D=16)
+        si.scales[:-1] = np.maximum(si.scales[:-1], 2.5)   # boxes of ~ 30 voxels a side: > 100 rows per Gaussian, 16 provided
+    quats = np.tile(np.array([[1.0, 0.0, 0.0, 0.0]]), (si.scales.shape[0], 1))
+    si.cov3D = cov_inverse(si.scales, quats).astype(np.float32)
+    pi, mi, radii, cov6 = prep(si)
+    g = np.random.default_rng(7).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
+    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    got = _bwd(gpu, si, t, state, g)
+    ref = oracle.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D, g)
+    for a, b in zip(got, ref):
+        assert np.isfinite(a).all()
+        assert np.abs(a - b.reshape(a.shape)).max() <= 2e-4 * max(np.abs(b).max(), 1e-30)
