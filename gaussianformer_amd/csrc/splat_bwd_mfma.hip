@@ -69,11 +69,13 @@ struct BwdMArgs {
 
 constexpr int kMList = 256;      // candidate list entries (ids, packed box lo, packed box hi) in LDS
 constexpr int kMQCap = 128;      // hit queue (ring)
-constexpr int kMPitch = 132;     // floats per channel row of the staged dL: [18][132], column = block * 32 + voxel in block
-// LDS map (dwords): [0, 1536) record slot (six 1 KB pieces per group) | [1536, 2304) list | [2304, 4680) dL | [4680, 4808) queue.
+constexpr int kMPitch16 = 136;   // halves per channel row of the staged dL: two f16 arrays (hi, lo) [18][136], column = block * 32 + voxel in block
+constexpr int kMDlDwords = kC * kMPitch16;   // both arrays: 2 x 18 x 136 halves
+static_assert(128 * kC <= kMDlDwords, "the 128 fp32 rows land in the same area before they are split");
+// LDS map (dwords): [0, 1536) record slot (six 1 KB pieces per group) | [1536, 2304) list | [2304, 4752) dL | [4752, 4880) queue.
 // The unit's bitmask row lands at [768, 768 + 2 kWRow): the upper half of the slot and most of the list, both idle until the
 // row has been read into registers; the dense-word compaction borrows [0, 768).
-constexpr int kMLdsDwords = 1536 + 3 * kMList + kC * kMPitch + kMQCap;
+constexpr int kMLdsDwords = 1536 + 3 * kMList + kMDlDwords + kMQCap;
 constexpr int kMRowAt = 768;
 static_assert(kMRowAt + 2 * kWRow <= 1536 + 3 * kMList, "the bitmask row fits over the slot's upper half and the list");
 static_assert(3 * kMList <= kMRowAt, "the dense-word compaction borrows the lower half of the record slot");
@@ -202,7 +204,8 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     uint32_t *s_lg = s_u + 1536, *s_blo = s_u + 1536 + kMList, *s_bhi = s_u + 1536 + 2 * kMList;
     float *s_dl = reinterpret_cast<float *>(s_u + 1536 + 3 * kMList);
     unsigned long long *s_row = reinterpret_cast<unsigned long long *>(s_u + kMRowAt);
-    uint32_t *q_id = s_u + 1536 + 3 * kMList + kC * kMPitch;
+    uint32_t *q_id = s_u + 1536 + 3 * kMList + kMDlDwords;
+    _Float16 *s_dh = reinterpret_cast<_Float16 *>(s_dl), *s_dq = s_dh + kC * kMPitch16;   // hi and lo terms, [channel][voxel]
 
     if (a.gate && !state_is_matrix_core(a.state)) return;
     if (a.records_asserted && !records_still_there(a.state, a.gen_word)) return;
@@ -241,40 +244,47 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
         __builtin_amdgcn_global_load_lds((gptr)(rec + o4), (lptr)(dst + 4096), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr)(rec + o5), (lptr)(dst + 5120), 16, 0, 0);
     };
-    auto request_row = [&](const unsigned long long *bm) {
+    // (wl = an opaque copy of the lane index: formed from `lane` itself, the per-lane address parts are hoisted out of the unit loop,
+    // do not survive its register pressure, and a spill reloaded here waits -- vmcnt(0) -- for the previous unit's row stores
+    // or, worse, for the requests just issued)
+    auto request_row = [&](const unsigned long long *bm, int wl) {
         for (int i = 0; 128 * i < a.nrow; ++i)
-            if (128 * i + 2 * lane < a.nrow)
-                __builtin_amdgcn_global_load_lds((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
+            if (128 * i + 2 * wl < a.nrow)
+                __builtin_amdgcn_global_load_lds((gptr)(bm + 128 * i + 2 * wl), (lptr)(s_row + 128 * i), 16, 0, 0);
     };
 
-    // a unit's bitmask row and its 128 gradient rows, both by LDS-DMA: the rows as 36 four-byte gathers, one per (channel, half of
-    // the unit) -- lane = voxel in block order -- so that they land TRANSPOSED, [channel][voxel], with no register or VALU in
-    // between (a first version carried them through 36 registers and an LDS scatter: the registers spilled and a unit spent 23
-    // of its 41 us there).  ok[half] = the lane's voxel of that half lies inside the grid.
-    auto request_unit = [&](int s_, int Xw_, int Y0_, int Zw_, bool (&ok)[2]) {
-        request_row(a.bitmask + (size_t)s_ * a.nrow);
-        const int lx = 2 * (lane >> 5) + ((lane >> 4) & 1), ly = (lane >> 2) & 3;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int z = 4 * half + (lane & 3);
-            ok[half] = Xw_ + lx < a.H && Y0_ + ly < a.W && Zw_ + z < a.D;
-            const size_t vox = ok[half] ? ((size_t)(Xw_ + lx) * a.W + (Y0_ + ly)) * a.D + (Zw_ + z) : 0;
-            const float *src = a.out_grad + vox * kC;
-#pragma unroll
-            for (int ch = 0; ch < kC; ++ch) {
-                __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(s_dl + ch * kMPitch + 64 * half), 4, 0, 0);
-                // (one address register pair stepped from request to request: left alone hipcc forms all 36 addresses first -- 72
-                // registers, spilled -- and a spill reloaded behind these requests waits for every one of them)
-                src += 1;
-                asm volatile("" : "+v"(src));
-            }
+    // a unit's bitmask row and its 128 gradient rows, both by LDS-DMA.  The rows of a voxel column (8 consecutive z) are 576
+    // contiguous bytes: the unit is sixteen such runs, fetched as 16-byte pieces in address order -- nine requests of 64 pieces
+    // (D even: every run starts on a 16-byte boundary; otherwise 36 requests of 64 dwords) -- and they land as they lie in memory,
+    // [column = 4 lx + ly][z][channel].  (The first versions gathered them transposed, one dword per lane and request: 36
+    // requests of 64 scattered dwords each cost a unit ~2 us of address processing.)  Pieces of columns outside the grid, or
+    // past the end of the array, are read from a clamped address and cleared when the rows are split.
+    const bool dl_by16 = (a.D & 1) == 0;
+    const size_t dl_last = (size_t)a.N * kC - (dl_by16 ? 4 : 1);   // (a 16-byte piece never straddles the end: an even number of rows is valid)
+    auto request_unit = [&](int s_, int Xw_, int Y0_, int Zw_) {
+        int wl = lane;
+        asm volatile("" : "+v"(wl));
+        request_row(a.bitmask + (size_t)s_ * a.nrow, wl);
+        const int per_col = dl_by16 ? 36 : 144, step_off = dl_by16 ? 28 : 64, step_col = dl_by16 ? 1 : 0, fl = dl_by16 ? 4 : 1;
+        int col = wl >= per_col ? 1 : 0, off = wl - col * per_col;
+        const int nreq = dl_by16 ? 9 : 36;
+#pragma nounroll
+        for (int i = 0; i < nreq; ++i) {
+            const int cx = Xw_ + (col >> 2), cy = Y0_ + (col & 3);
+            const bool ok = cx < a.H && cy < a.W;
+            const size_t vox = ok ? ((size_t)cx * a.W + cy) * a.D + Zw_ : 0;
+            const size_t fo = min(vox * kC + (size_t)(off * fl), dl_last);
+            const float *src = a.out_grad + fo;
+            if (dl_by16) __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(s_dl + 256 * i), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(s_dl + 64 * i), 4, 0, 0);
+            col += step_col; off += step_off;
+            if (off >= per_col) { off -= per_col; col += 1; }
         }
     };
 
     uint32_t *ctr = a.tile_counters + 64 * xcd;
     const int nchunk = (a.nwords + 63) >> 6;
     int local = (int)(blockIdx.x >> 3);
-    bool dl_ok[2] = {false, false};
     while (true) {  // units of this wave
         const int logical = xcd * per_xcd + local;
         if (!(local < per_xcd && logical < nunits)) break;
@@ -289,9 +299,10 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
             // ---- the unit's bitmask row and gradient rows (request_unit)
             // (Requesting them from the previous unit's last group, ahead of its row stores, was built and measured: the row wait
             // disappears, but the 36 requests cost that group the same two microseconds of issue time -- 79 against 74 us.)
-            request_unit(s, Xw, Y0, Zw, dl_ok);
-            // (36 requests were issued behind the row's: "at most 36 outstanding" = the row has landed)
-            asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+            request_unit(s, Xw, Y0, Zw);
+            // (9 or 36 requests were issued behind the row's: "at most that many outstanding" = the row has landed)
+            if (dl_by16) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
 #if GF_TIMELINE
             tl[1] = wall_clock64();
 #endif
@@ -409,27 +420,30 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // ---- the gradient rows have landed (wait for everything: the dense path below has no request of its own in flight);
-            // columns of voxels outside the grid (partial units) are cleared, then the unit's largest |dL| gives the power of two
-            // that brings the f16 operands made from these rows to [16, 32)
+            // ---- the gradient rows have landed (wait for everything: the dense path below has no request of its own in flight).
+            // Lane l takes voxels l and l + 64 of the landing order (column = 4 lx + ly, then z): 18 contiguous floats each.  Voxels
+            // outside the grid (partial units) count as zero; the unit's largest |dL| gives the power of two that brings the f16
+            // operands made from these rows to [16, 32); the scaled values are split into f16 hi + lo ONCE, here, and written back
+            // over the landing area as two arrays [channel][voxel in block order] -- the groups read MFMA operands from them
+            // without touching a VALU (splitting per group and block was 312 of a group's ~1 070 VALU instructions).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             float dmax = 0.f;
+            float v[2 * kC];
             {
-                const bool partial = !(Xw + 4 <= a.H && Y0 + 4 <= a.W && Zw + 8 <= a.D);
-                if (partial) {
+                int wl = lane;
+                asm volatile("" : "+v"(wl));
+                const int ly_ = (wl >> 3) & 3, z_ = wl & 7;
 #pragma unroll
-                    for (int half = 0; half < 2; ++half)
-                        if (!dl_ok[half])
+                for (int half = 0; half < 2; ++half) {
+                    const int lx_ = (wl >> 5) + 2 * half;
+                    const bool ok = Xw + lx_ < a.H && Y0 + ly_ < a.W && Zw + z_ < a.D;
+                    const float *rowp = s_dl + (64 * half + wl) * kC;
+                    const float4 q0 = *reinterpret_cast<const float4 *>(rowp), q1 = *reinterpret_cast<const float4 *>(rowp + 4);
+                    const float4 q2 = *reinterpret_cast<const float4 *>(rowp + 8), q3 = *reinterpret_cast<const float4 *>(rowp + 12);
+                    const float2 q4 = *reinterpret_cast<const float2 *>(rowp + 16);
+                    const float w[kC] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
 #pragma unroll
-                            for (int ch = 0; ch < kC; ++ch) s_dl[ch * kMPitch + 64 * half + lane] = 0.f;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                float v[2 * kC];
-#pragma unroll
-                for (int ch = 0; ch < kC; ++ch) {
-                    v[2 * ch] = s_dl[ch * kMPitch + lane];
-                    v[2 * ch + 1] = s_dl[ch * kMPitch + 64 + lane];
+                    for (int ch = 0; ch < kC; ++ch) v[2 * ch + half] = ok ? w[ch] : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < 2 * kC; ++k) dmax = fmaxf(dmax, fabsf(v[k]));
@@ -439,6 +453,30 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
             const int dex = min(254, max(5, (int)((__float_as_uint(dmax) >> 23) & 255u)));
             const float dscale = dmax > 0.f ? __uint_as_float((uint32_t)(258 - dex) << 23) : 1.f;   // 2^(131 - dex)
             const int dshift = dmax > 0.f ? dex - 131 : 0;   // true value = scaled value * 2^dshift
+            {
+                // (every lane has its 36 values in registers: the landing area may be overwritten)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                int wl = lane;
+                asm volatile("" : "+v"(wl));
+                // block-order column of voxel (lx, ly, z): block = (lx >> 1) + 2 (z >> 2), voxel in block = 16 (lx & 1) + 4 ly + (z & 3)
+                const int colv = 32 * (2 * ((wl >> 2) & 1)) + 16 * ((wl >> 5) & 1) + 4 * ((wl >> 3) & 3) + (wl & 3);
+                _Float16 *ph = s_dh + colv, *pq = s_dq + colv;
+#pragma unroll
+                for (int ch = 0; ch < kC; ++ch) {
+                    const float x0 = v[2 * ch] * dscale, x1 = v[2 * ch + 1] * dscale;
+                    const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+                    float q0, q1;
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(hh), "v"(x0));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(hh), "v"(x1));
+                    const fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(q0, q1);
+                    // (voxel l + 64 has lx + 2: the next block along x)
+                    ph[ch * kMPitch16] = hh[0]; ph[ch * kMPitch16 + 32] = hh[1];
+                    pq[ch * kMPitch16] = ll[0]; pq[ch * kMPitch16 + 32] = ll[1];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             // ---- per-lane constant operands (monomials, one-hot coordinates, moment factors).  They do not depend on the unit, but
             // formed once per kernel they stay live through the list phases above, which then spill -- and a spill reloaded behind
             // the gather requests waits for every one of them.  Formed here, from opaque copies of the lane coordinates, they live
@@ -701,30 +739,18 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #pragma unroll
                             for (int q = 0; q < 16; ++q) T[q] = 0.f;
                             {
-                                const float *dlp = s_dl + (8 * h) * kMPitch + 32 * b + n;
-                                float av[10];
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) av[j] = dlp[j * kMPitch];
-                                av[8] = s_dl[16 * kMPitch + 32 * b + n];
-                                av[9] = s_dl[17 * kMPitch + 32 * b + n];
-                                asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]), "+v"(av[8]), "+v"(av[9]));
-#pragma unroll
-                                for (int j = 0; j < 10; ++j) av[j] *= dscale;
-                                if (h) { av[8] = 0.f; av[9] = 0.f; }
+                                // (operands straight from the split arrays: element j of chunk 0 = channel 8 h + j of voxel n; chunk 1 =
+                                // channels 16, 17 in half 0, nothing in half 1)
+                                const _Float16 *dh = s_dh + (8 * h) * kMPitch16 + 32 * b + n, *dq = s_dq + (8 * h) * kMPitch16 + 32 * b + n;
                                 H8 a0h, a0l, a1h, a1l;
-                                const fp16x2 zz = __builtin_amdgcn_cvt_pkrtz(0.f, 0.f);
 #pragma unroll
-                                for (int j = 0; j < 10; j += 2) {
-                                    const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(av[j], av[j + 1]);
-                                    float q0, q1;
-                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(hh), "v"(av[j]));
-                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(hh), "v"(av[j + 1]));
-                                    const fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(q0, q1);
-                                    if (j < 8) { a0h.p[j >> 1] = hh; a0l.p[j >> 1] = ll; }
-                                    else { a1h.p[0] = hh; a1l.p[0] = ll; }
-                                }
+                                for (int j = 0; j < 8; ++j) { a0h.e[j] = dh[j * kMPitch16]; a0l.e[j] = dq[j * kMPitch16]; }
+                                const _Float16 *dh1 = s_dh + 16 * kMPitch16 + 32 * b + n, *dq1 = s_dq + 16 * kMPitch16 + 32 * b + n;
+                                const _Float16 zero16 = (_Float16)0.f;
+                                a1h.e[0] = h ? zero16 : dh1[0]; a1h.e[1] = h ? zero16 : dh1[kMPitch16];
+                                a1l.e[0] = h ? zero16 : dq1[0]; a1l.e[1] = h ? zero16 : dq1[kMPitch16];
 #pragma unroll
-                                for (int j = 1; j < 4; ++j) { a1h.p[j] = zz; a1l.p[j] = zz; }
+                                for (int j = 2; j < 8; ++j) { a1h.e[j] = zero16; a1l.e[j] = zero16; }
                                 T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l.v, b0h.v, T, 0, 0, 0);
                                 T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h.v, b0l.v, T, 0, 0, 0);
                                 T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l.v, b1h.v, T, 0, 0, 0);
@@ -757,21 +783,11 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                                 mom = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt.v, kl_[kc].v, mom, 0, 0, 0);
                                 mom = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt.v, kh_[kc].v, mom, 0, 0, 0);
                                 // dL^T operand: row = channel n (rows >= 18 repeat row 17: their outputs are never read), K element j
-                                // of chunk kc = voxel 16 kc + 4 h + j (j < 4), 16 kc + 8 + 4 h + (j - 4) (j >= 4): two 16-byte reads
-                                const float *dc = s_dl + min(n, kC - 1) * kMPitch + 32 * b + 16 * kc + 4 * h;
-                                const float4 x0 = *reinterpret_cast<const float4 *>(dc), x1 = *reinterpret_cast<const float4 *>(dc + 8);
-                                const float xv[8] = {x0.x * dscale, x0.y * dscale, x0.z * dscale, x0.w * dscale,
-                                                     x1.x * dscale, x1.y * dscale, x1.z * dscale, x1.w * dscale};
-                                H8 ah, al;
-#pragma unroll
-                                for (int j = 0; j < 8; j += 2) {
-                                    const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(xv[j], xv[j + 1]);
-                                    float q0, q1;
-                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(hh), "v"(xv[j]));
-                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(hh), "v"(xv[j + 1]));
-                                    ah.p[j >> 1] = hh;
-                                    al.p[j >> 1] = __builtin_amdgcn_cvt_pkrtz(q0, q1);
-                                }
+                                // of chunk kc = voxel 16 kc + 4 h + j (j < 4), 16 kc + 8 + 4 h + (j - 4) (j >= 4): two 8-byte reads per array
+                                const int dco = min(n, kC - 1) * kMPitch16 + 32 * b + 16 * kc + 4 * h;
+                                union { h8 v; uint2 u[2]; } ah, al;
+                                ah.u[0] = *reinterpret_cast<const uint2 *>(s_dh + dco); ah.u[1] = *reinterpret_cast<const uint2 *>(s_dh + dco + 8);
+                                al.u[0] = *reinterpret_cast<const uint2 *>(s_dq + dco); al.u[1] = *reinterpret_cast<const uint2 *>(s_dq + dco + 8);
                                 dsm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, eh[kc].v, dsm, 0, 0, 0);
                                 dsm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, el[kc].v, dsm, 0, 0, 0);
                                 dsm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, eh[kc].v, dsm, 0, 0, 0);
