@@ -52,7 +52,7 @@ union H8 {
 
 struct BwdMArgs {
     const float *pts;            // lattice: pts[0] and the three axis steps
-    const float *records;        // [P][32]   (gf_splat_prep_kernel; natural-log covariance, dword 31 = first row)
+    const float *records;        // [P][32]   (gf_splat_prep_kernel; natural-log covariance)
     const uint2 *boxes;          // [P]
     const unsigned long long *bitmask;
     const float *out_grad;       // [N,18]
@@ -61,6 +61,8 @@ struct BwdMArgs {
     const uint32_t *state;       // the forward's state block
     uint32_t *tile_counters;     // [64 x]: next unclaimed unit of XCD x
     const uint32_t *gen_word;    // the workspace's generation word
+    const uint32_t *row_first;   // [P] first row of each Gaussian in `rows` (0xFFFFFFFF: none, atomics instead)
+    const uint32_t *wave_total;  // records pass: bit 31 = the wave of 64 Gaussians holds one with more than kBwdBigRows rows
     int P, N, nwords, nrow, H, W, D, nsx, nsy;
     int gate;                    // 1: run only if the forward's state says "matrix cores" (2: the set-up kernel wrote NaN gradients otherwise)
     int records_asserted;        // 1: no records pass ran -- stand down unless the workspace still holds the forward's (generation)
@@ -72,10 +74,11 @@ constexpr int kMQCap = 128;      // hit queue (ring)
 constexpr int kMPitch16 = 136;   // halves per channel row of the staged dL: two f16 arrays (hi, lo) [18][136], column = block * 32 + voxel in block
 constexpr int kMDlDwords = kC * kMPitch16;   // both arrays: 2 x 18 x 136 halves
 static_assert(128 * kC <= kMDlDwords, "the 128 fp32 rows land in the same area before they are split");
-// LDS map (dwords): [0, 1536) record slot (six 1 KB pieces per group) | [1536, 2304) list | [2304, 4752) dL | [4752, 4880) queue.
+// LDS map (dwords): [0, 1536) record slot (six 1 KB pieces per group) | [1536, 2304) list | [2304, 4752) dL | [4752, 4880) queue | [4880, 4944) first rows.
 // The unit's bitmask row lands at [768, 768 + 2 kWRow): the upper half of the slot and most of the list, both idle until the
 // row has been read into registers; the dense-word compaction borrows [0, 768).
-constexpr int kMLdsDwords = 1536 + 3 * kMList + kMDlDwords + kMQCap;
+constexpr int kMFirstAt = 1536 + 3 * kMList + kMDlDwords + kMQCap;   // first rows of the group's Gaussians (seventh piece of a record request)
+constexpr int kMLdsDwords = kMFirstAt + 64;
 constexpr int kMRowAt = 768;
 static_assert(kMRowAt + 2 * kWRow <= 1536 + 3 * kMList, "the bitmask row fits over the slot's upper half and the list");
 static_assert(3 * kMList <= kMRowAt, "the dense-word compaction borrows the lower half of the record slot");
@@ -133,46 +136,39 @@ __device__ __forceinline__ bool records_still_there(const uint32_t *state, const
 }
 
 // ---------------------------------------------------------------------------------------
-// One launch ahead of the gradient kernel: zeroes the four gradient outputs, arms the per-XCD unit counters and turns the
-// records pass's row layout (per wave of 64 Gaussians: rows needed; per Gaussian: offset inside its wave, record dword 30) into
-// every Gaussian's first row (record dword 31; 0xFFFFFFFF = the buffer has no room: atomics instead).  Repeating it gives the
-// same words, so a second backward of the same forward finds the records as it needs them.
+// Behind the backward's own records pass (i.e. only when the workspace no longer held the forward's): the first row of every
+// Gaussian from the pass's layout words (prefix of the per-wave totals + the Gaussian's offset in its wave; 0xFFFFFFFF = the
+// buffer has no room for the wave's rows), and zeroed gradients for the float atomics those Gaussians fall back to.  The forward
+// does the same prefix inside its render kernel (finish_row_layout, splat_fwd.hip), and states in word 4 of the state block
+// whether everything fitted -- so with the forward's records in place this kernel stands down, like the records pass.
 struct BwdSetupArgs {
     float *means_grad, *opa_grad, *sem_grad, *cov_grad;
-    float *records;
-    const uint32_t *wave_total;
+    const uint32_t *wave_total, *row_local;
+    uint32_t *row_first;
     uint32_t *gen_word;
-    uint32_t *tile_counters;
     const uint32_t *state;
-    uint32_t tile_counter_init, cap;
-    int P, gate, records_asserted;
+    uint32_t cap;
+    int P;
 };
 
 __global__ __launch_bounds__(256) void gf_splat_bwd_setup_kernel(BwdSetupArgs a)
 {
-    const bool mc = state_is_matrix_core(a.state);
-    if (a.gate == 1 && !mc) return;
-    // a caller's assertion that does not hold (not a matrix-core forward, or the workspace has been used since) gives NaN, not
-    // wrong numbers
-    const bool bad = (a.gate == 2 && !mc) || (a.records_asserted && !records_still_there(a.state, a.gen_word));
-    const float fill = bad ? __uint_as_float(0x7fc00000u) : 0.f;
-    // the four arrays as flat runs of floats, grid-strided (coalesced dword stores; the arrays need not be 16-byte aligned)
+    if (!state_is_matrix_core(a.state)) return;
+    // (the generation word is bumped by the LAST kernel of such a backward, gf_splat_bwd_rows_kernel: every workgroup here
+    // compares it with the state block's copy)
+    if (records_still_there(a.state, a.gen_word)) return;
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
-    for (size_t i = i0; i < (size_t)kC * a.P; i += stride) a.sem_grad[i] = fill;
-    for (size_t i = i0; i < (size_t)6 * a.P; i += stride) a.cov_grad[i] = fill;
-    for (size_t i = i0; i < (size_t)3 * a.P; i += stride) a.means_grad[i] = fill;
-    for (size_t i = i0; i < (size_t)a.P; i += stride) a.opa_grad[i] = fill;
-    if (bad) return;
-    if (blockIdx.x == 0 && threadIdx.x < 8) a.tile_counters[64 * threadIdx.x] = a.tile_counter_init;
-    // (the records pass ran just now, because the generations differed: the workspace no longer holds what any earlier
-    // forward's state block describes.  Nobody else reads the word in this launch.)
-    if (!a.records_asserted && blockIdx.x == 0 && threadIdx.x == 0 && !records_still_there(a.state, a.gen_word))
-        *a.gen_word = *a.gen_word + 1u;
+    for (size_t i = i0; i < (size_t)kC * a.P; i += stride) a.sem_grad[i] = 0.f;
+    for (size_t i = i0; i < (size_t)6 * a.P; i += stride) a.cov_grad[i] = 0.f;
+    for (size_t i = i0; i < (size_t)3 * a.P; i += stride) a.means_grad[i] = 0.f;
+    for (size_t i = i0; i < (size_t)a.P; i += stride) a.opa_grad[i] = 0.f;
     // ---- first rows: workgroup b has Gaussians [256 b, 256 b + 256) = waves 4 b .. 4 b + 3 of the records pass
     const int nblk = (a.P + 255) >> 8;
     if ((int)blockIdx.x >= nblk) return;
     __shared__ uint32_t s_sum[4];
     const int tid = threadIdx.x, w0 = 4 * (int)blockIdx.x, nw = (a.P + 63) >> 6;
+    const int g = 256 * (int)blockIdx.x + tid;
+    const uint32_t local = g < a.P ? a.row_local[g] : 0u;
     uint32_t before = 0u;
     for (int w = tid; w < w0; w += 256) before += a.wave_total[w] & 0x7FFFFFFFu;
 #pragma unroll
@@ -187,12 +183,37 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_setup_kernel(BwdSetupArgs a)
         if (k < wv) base += t;
         if (k == wv) mine = t;
     }
-    const int g = 256 * (int)blockIdx.x + tid;
-    if (g < a.P) {
-        // (a wave's rows are taken or left as a whole)
-        const bool fits = (unsigned long long)base + mine <= (unsigned long long)a.cap;
-        uint32_t *rec = reinterpret_cast<uint32_t *>(a.records + (size_t)g * kRecDwords);
-        rec[31] = fits ? base + rec[30] : 0xFFFFFFFFu;
+    // (a wave's rows are taken or left as a whole)
+    if (g < a.P) a.row_first[g] = (unsigned long long)base + mine <= (unsigned long long)a.cap ? base + local : 0xFFFFFFFFu;
+}
+
+// Gaussians with more than kBwdBigRows rows get their gradients from float atomics (gf_splat_bwd_rows_kernel): one wave of the
+// gradient kernel zeroes them first.  The records pass flagged the waves of 64 Gaussians that hold one (normally exactly
+// one: the whole-grid "empty" Gaussian).
+__device__ __forceinline__ void zero_big_gaussians(const BwdMArgs &a, int lane)
+{
+    const int nw = (a.P + 63) >> 6;
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        const bool f = w0 + lane < nw && (a.wave_total[w0 + lane] >> 31) != 0u;
+        unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+        while (m) {
+            const int w = w0 + __builtin_ctzll(m);
+            m &= m - 1;
+            const int g = 64 * w + lane;
+            if (g < a.P) {
+                const uint2 b = a.boxes[g];
+                const bool ne = ux(b.y) > ux(b.x) && uy(b.y) > uy(b.x) && uz(b.y) > uz(b.x);
+                const int cnt = !ne ? 0 : (((ux(b.y) - 1) >> 2) - (ux(b.x) >> 2) + 1) * (((uy(b.y) - 1) >> 2) - (uy(b.x) >> 2) + 1) *
+                                              (((uz(b.y) - 1) >> 3) - (uz(b.x) >> 3) + 1);
+                // (one without rows was zeroed by the set-up kernel and is receiving this kernel's atomics: hands off)
+                if (cnt > kBwdBigRows && a.row_first[g] != 0xFFFFFFFFu) {
+                    for (int k = 0; k < kC; ++k) a.sem_grad[(size_t)kC * g + k] = 0.f;
+                    for (int k = 0; k < 6; ++k) a.cov_grad[6 * (size_t)g + k] = 0.f;
+                    for (int k = 0; k < 3; ++k) a.means_grad[3 * (size_t)g + k] = 0.f;
+                    a.opa_grad[g] = 0.f;
+                }
+            }
+        }
     }
 }
 
@@ -211,6 +232,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     if (a.records_asserted && !records_still_there(a.state, a.gen_word)) return;
 
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0) zero_big_gaussians(a, lane);
     const int n_ = lane & 31, h_ = lane >> 5;
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     const int xcd = (int)(blockIdx.x & 7u);
@@ -233,7 +255,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     auto request_records_at = [&](int qh, int start, int count) {
         const uint32_t id = q_id[(qh + start + (n_ < count ? n_ : 0)) & (kMQCap - 1)];
         const char *rec = reinterpret_cast<const char *>(a.records + (size_t)id * kRecDwords);
-        // both halves: mean / opacity, covariance, covariance + box, and piece 7 (semantics 16, 17; dword 31 = first row);
+        // both halves: mean / opacity, covariance, covariance + box, piece 7 (semantics 16, 17) and the Gaussian's first row;
         // half 0: semantics 0..7 (pieces 3, 4), half 1: semantics 8..15 (pieces 5, 6)
         const int o3 = (3 + 2 * h_) * 16, o4 = (4 + 2 * h_) * 16, o5 = 7 * 16;
         char *dst = reinterpret_cast<char *>(slot);
@@ -243,6 +265,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
         __builtin_amdgcn_global_load_lds((gptr)(rec + o3), (lptr)(dst + 3072), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr)(rec + o4), (lptr)(dst + 4096), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr)(rec + o5), (lptr)(dst + 5120), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(a.row_first + id), (lptr)(s_u + kMFirstAt), 4, 0, 0);
     };
     // (wl = an opaque copy of the lane index: formed from `lane` itself, the per-lane address parts are hoisted out of the unit loop,
     // do not survive its register pressure, and a spill reloaded here waits -- vmcnt(0) -- for the previous unit's row stores
@@ -644,6 +667,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                         const float4 r0 = slot[lane], r1 = slot[64 + lane], r2 = slot[128 + lane];
                         const float4 e0 = slot[192 + lane], e1 = slot[256 + lane], e2 = slot[320 + lane];
                         const uint32_t my_id = q_id[(qhead + (live ? n : 0)) & (kMQCap - 1)];
+                        const uint32_t first = s_u[kMFirstAt + lane];
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const int nnext = min(avail, 32);
@@ -830,8 +854,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #pragma unroll
                                 for (int k = 8; k < 20; ++k) o[k] = 0.f;
                             }
-                            // row of (Gaussian, this double brick): first row from record dword 31 (piece 7: e2.w in both halves)
-                            const uint32_t first = __float_as_uint(e2.w);
+                            // row of (Gaussian, this double brick)
                             const uint32_t glo = __float_as_uint(r2.z), ghi = __float_as_uint(r2.w);
                             const int bx0 = ux(glo) >> 2, by0 = uy(glo) >> 2, bz0 = uz(glo) >> 3;
                             const int nby = ((uy(ghi) - 1) >> 2) - by0 + 1, nbz = ((uz(ghi) - 1) >> 3) - bz0 + 1;
@@ -905,67 +928,100 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
-// Adds a Gaussian's rows up.  Half a wave per Gaussian, lane = column of the 32-float row, sixteen rows in flight; the sums
-// are stored (the gradients were zeroed by gf_splat_bwd_zero_kernel and nothing else writes them, except for the Gaussians
-// without rows, which this kernel leaves alone).  Gaussians of the big list (more than kBwdBigRows rows) are summed by
-// the workgroups past the Gaussian range, 512 rows per workgroup, and combined with float atomics.
+// Adds a Gaussian's rows up and writes its gradients: every Gaussian's, with plain stores -- nothing else writes them when all rows
+// fitted the buffer, so they need not be zeroed (Gaussians without rows, first = 0xFFFFFFFF, are left to the atomics of the
+// gradient kernel and the zeroes of the set-up kernel).  Eight lanes per Gaussian, four columns of the 32-float row each, twenty
+// rows in flight; each column always in ascending row order.  A Gaussian with more than kBwdBigRows rows (the whole-grid "empty"
+// Gaussian: 5 000) is summed by the workgroups past the Gaussian range, 64 rows per work item -- one round trip -- and the items
+// are combined with float atomics into gradients the gradient kernel zeroed (zero_big_gaussians).  (Built and measured: the
+// items' sums stored over their first rows and added up, in order, by the workgroup that finishes the last one -- bitwise
+// reproducible, but the release / acquire fences around the counter flush and invalidate a whole L2 each: 20 us against 13.)
 struct BwdRowsArgs {
     const float *records;
-    const float *rows;
+    float *rows;
     float *means_grad, *opa_grad, *sem_grad, *cov_grad;
     const uint32_t *wave_total;   // records pass: rows per wave of 64 Gaussians, bit 31 = the wave has a Gaussian of more than kBwdBigRows rows
-    const uint32_t *gen_word;
+    const uint32_t *row_first;
+    uint32_t *gen_word;
+    uint32_t *unit_counters;      // the gradient kernel's per-XCD unit counters: re-armed here for the next backward
     const uint32_t *state;
+    uint32_t counter_init;
     int P, gate, ngauss_blocks, records_asserted;
 };
 
-__device__ __forceinline__ void bwd_store_column(const BwdRowsArgs &a, int g, int col, float v, bool atomic)
+__device__ __forceinline__ void bwd_store_column(const BwdRowsArgs &a, int g, int col, float v)
 {
-    // row columns: 0..17 semantics (as the two halves wrote them: 0-3, 4-7, 8-11, 12-15, 16, 17), 18..23 covariance, 24..26 mean, 27 opacity
+    // row columns: 0..17 semantics, 18..23 covariance, 24..26 mean, 27 opacity
     float *dst = col < 18 ? a.sem_grad + (size_t)kC * g + col
                : col < 24 ? a.cov_grad + 6 * (size_t)g + (col - 18)
                : col < 27 ? a.means_grad + 3 * (size_t)g + (col - 24)
                : col == 27 ? a.opa_grad + g : nullptr;
-    if (!dst) return;
-    if (atomic) unsafeAtomicAdd(dst, v);
-    else *dst = v;
+    if (dst) *dst = v;
+}
+__device__ __forceinline__ void bwd_add_column(const BwdRowsArgs &a, int g, int col, float v)
+{
+    float *dst = col < 18 ? a.sem_grad + (size_t)kC * g + col
+               : col < 24 ? a.cov_grad + 6 * (size_t)g + (col - 18)
+               : col < 27 ? a.means_grad + 3 * (size_t)g + (col - 24)
+               : a.opa_grad + g;
+    unsafeAtomicAdd(dst, v);
 }
 
 __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
 {
-    if (a.gate && !state_is_matrix_core(a.state)) return;
-    if (a.records_asserted && !records_still_there(a.state, a.gen_word)) return;
-    const int tid = threadIdx.x, col = tid & 31, sub = tid >> 5;
-    auto box_rows = [&](int g, uint32_t &first) -> int {
+    const bool mc = state_is_matrix_core(a.state);
+    if (a.gate == 1 && !mc) return;
+    const int tid = threadIdx.x;
+    // a caller's assertion that does not hold (not a matrix-core forward, or the workspace has been used since): NaN, not numbers
+    const bool bad = (a.gate == 2 && !mc) || (a.records_asserted && !records_still_there(a.state, a.gen_word));
+    if (!bad && blockIdx.x == 0) {
+        if (tid < 8) a.unit_counters[64 * tid] = a.counter_init;
+        // (a backward that ran its own records pass: the workspace no longer holds what any forward's state block describes.
+        // Nobody else reads the word in this launch.)
+        if (!a.records_asserted && tid == 0 && !records_still_there(a.state, a.gen_word)) *a.gen_word = *a.gen_word + 1u;
+    }
+    auto box_rows = [&](int g) -> int {
         const float4 r2 = *reinterpret_cast<const float4 *>(a.records + (size_t)g * kRecDwords + 8);
-        first = __float_as_uint(a.records[(size_t)g * kRecDwords + 31]);
         const uint32_t glo = __float_as_uint(r2.z), ghi = __float_as_uint(r2.w);
         if (!(ux(ghi) > ux(glo) && uy(ghi) > uy(glo) && uz(ghi) > uz(glo))) return 0;
         return (((ux(ghi) - 1) >> 2) - (ux(glo) >> 2) + 1) * (((uy(ghi) - 1) >> 2) - (uy(glo) >> 2) + 1) *
                (((uz(ghi) - 1) >> 3) - (uz(glo) >> 3) + 1);
     };
     if ((int)blockIdx.x < a.ngauss_blocks) {
-        const int g = blockIdx.x * 8 + sub;
+        // at the nuScenes shape a Gaussian has 11 rows on average and three in ten have 18 (3 x 3 x 2 double bricks): all but the
+        // odd one are summed after one round trip; each column always in the same (ascending) order
+        constexpr int kRowsInFlight = 20;
+        const int g = blockIdx.x * 32 + (tid >> 3), c4 = 4 * (tid & 7);
         if (g >= a.P) return;
-        uint32_t first;
-        const int cnt = box_rows(g, first);
-        if (cnt == 0 || first == 0xFFFFFFFFu || cnt > kBwdBigRows) return;
-        const float *base = a.rows + (size_t)first * kBwdRowDwords + col;
-        float acc = 0.f;
-        // sixteen rows in flight (a Gaussian has 13.5 rows on average: most are summed after one round trip); always the same order
-        for (int r = 0; r < cnt; r += 16) {
-            float v[16];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bad) {
+            acc.x = acc.y = acc.z = acc.w = __uint_as_float(0x7fc00000u);
+        } else {
+            const uint32_t first = a.row_first[g];
+            const int cnt = box_rows(g);
+            if (cnt > 0 && (first == 0xFFFFFFFFu || cnt > kBwdBigRows)) return;
+            const float *base = a.rows + (size_t)first * kBwdRowDwords + c4;
+            for (int r = 0; r < cnt; r += kRowsInFlight) {
+                float4 v[kRowsInFlight];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = base[(size_t)min(r + k, cnt - 1) * kBwdRowDwords];
+                for (int k = 0; k < kRowsInFlight; ++k) v[k] = *reinterpret_cast<const float4 *>(base + (size_t)min(r + k, cnt - 1) * kBwdRowDwords);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc += (r + k < cnt) ? v[k] : 0.f;
+                for (int k = 0; k < kRowsInFlight; ++k) {
+                    const bool in = r + k < cnt;
+                    acc.x += in ? v[k].x : 0.f; acc.y += in ? v[k].y : 0.f; acc.z += in ? v[k].z : 0.f; acc.w += in ? v[k].w : 0.f;
+                }
+            }
         }
-        bwd_store_column(a, g, col, acc, false);
+        bwd_store_column(a, g, c4, acc.x);
+        bwd_store_column(a, g, c4 + 1, acc.y);
+        bwd_store_column(a, g, c4 + 2, acc.z);
+        bwd_store_column(a, g, c4 + 3, acc.w);
         return;
     }
-    // ---- big Gaussians: work item = 512 rows of one of them.  Every workgroup of this range walks the flagged waves and their
-    // Gaussians in the same (ascending) order and takes the items that fall to it.
-    __shared__ float s_part[8][32];
+    if (bad) return;
+    // ---- big Gaussians.  Every workgroup of this range walks the flagged waves and their Gaussians in the same (ascending)
+    // order and takes the items that fall to it.
+    __shared__ __attribute__((aligned(16))) float s_part[32][32];
     __shared__ int s_wave[kBwdBigCap], s_cnt[64];
     __shared__ uint32_t s_first[64];
     __shared__ int s_nwave;
@@ -984,12 +1040,34 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
     const int nflag = s_nwave;
     int item = (int)blockIdx.x - a.ngauss_blocks;
     const int stride = (int)gridDim.x - a.ngauss_blocks;
+    const int lg = tid >> 3, c4 = 4 * (tid & 7);
+    // sum of `n` rows, `pitch` rows apart, from `src` (this thread's four columns): lane group lg takes rows lg, lg + 32, ...;
+    // the 32 lane groups' sums are then added in lane-group order; threads 0..31 return column `tid`
+    auto sum_rows = [&](const float *src, int n, size_t pitch) -> float {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = lg; r < n; r += 64) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)r * pitch);
+            const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)min(r + 32, n - 1) * pitch);
+            const bool in1 = r + 32 < n;
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += in1 ? v1.x : 0.f; acc.y += in1 ? v1.y : 0.f; acc.z += in1 ? v1.z : 0.f; acc.w += in1 ? v1.w : 0.f;
+        }
+        __syncthreads();
+        *reinterpret_cast<float4 *>(&s_part[lg][c4]) = acc;
+        __syncthreads();
+        float t = 0.f;
+        if (tid < 32) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) t += s_part[k][tid];
+        }
+        return t;
+    };
     for (int e = 0; e < nflag; ++e) {
         __syncthreads();
         if (tid < 64) {
             const int gq = 64 * s_wave[e] + tid;
-            uint32_t first = 0xFFFFFFFFu;
-            const int cnt = gq < a.P ? box_rows(gq, first) : 0;
+            const uint32_t first = gq < a.P ? a.row_first[gq] : 0xFFFFFFFFu;
+            const int cnt = gq < a.P ? box_rows(gq) : 0;
             s_cnt[tid] = first == 0xFFFFFFFFu ? 0 : cnt;   // (no rows: the gradient kernel used atomics)
             s_first[tid] = first;
         }
@@ -998,28 +1076,13 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
             const int cnt = s_cnt[j];
             if (cnt <= kBwdBigRows) continue;
             const int g = 64 * s_wave[e] + j;
-            const uint32_t first = s_first[j];
-            const int parts = (cnt + 511) / 512;
+            const float *grows = a.rows + (size_t)s_first[j] * kBwdRowDwords;
+            const int parts = (cnt + 63) / 64;
             while (item < parts) {
-                const int r0 = item * 512, r1 = min(cnt, r0 + 512);
-                const float *base = a.rows + ((size_t)first + r0) * kBwdRowDwords + col;
-                float acc = 0.f;
-                for (int r = sub; r0 + r < r1; r += 32) {   // eight half-waves, four rows in flight each
-                    float v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = base[(size_t)min(r + 8 * k, r1 - r0 - 1) * kBwdRowDwords];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc += (r0 + r + 8 * k < r1) ? v[k] : 0.f;
-                }
-                s_part[sub][col] = acc;
-                __syncthreads();
-                if (sub == 0) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) t += s_part[k][col];
-                    bwd_store_column(a, g, col, t, true);
-                }
-                __syncthreads();
+                const int r0 = item * 64;
+                const float t = sum_rows(grows + (size_t)r0 * kBwdRowDwords + c4, min(cnt - r0, 64), kBwdRowDwords);
+                // (the gradient kernel zeroed this Gaussian's gradients: zero_big_gaussians)
+                if (tid < 28) bwd_add_column(a, g, tid, t);
                 item += stride;
             }
             item -= parts;
@@ -1055,26 +1118,28 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
                                 const SplatWorkspace &ws, int gate, int records_asserted, hipStream_t stream)
 {
     uint32_t *gen_word = ws.flags + kGenWord;
-    // the records pass, unless the caller vouches for the forward's; it stands down by itself if the workspace still holds them
-    if (!records_asserted)
+    // The records pass and the set-up kernel, unless the caller vouches for the forward's records: both stand down by themselves
+    // if the workspace still holds them (then the forward's render kernel has laid out the rows as well).
+    if (!records_asserted) {
         launch_prep_for_backward(radii_per_axis, P, N, H, W, D, pts, points_int, means3D, means3D_int, opacity, semantics, radii,
                                  cov3D, state, ws, stream);
+        BwdSetupArgs z{means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, ws.bwd_row_local, ws.bwd_row_first, gen_word, state,
+                       ws.bwd_cap, P};
+        hipLaunchKernelGGL(gf_splat_bwd_setup_kernel, dim3(std::max((P + 255) / 256, std::min(1024, (kC * P + 255) / 256))), dim3(256), 0,
+                           stream, z);
+    }
     const int nunits = ws.nsuper * 4 * ((D + 7) / 8);
     const int grid = bwd_mfma_grid(nunits);
-    BwdSetupArgs z{means_grad, opa_grad, sem_grad, cov_grad, ws.records, ws.bwd_wave_total, gen_word, ws.flags + 4608, state,
-                   (uint32_t)(grid / 8), ws.bwd_cap, P, gate, records_asserted};
-    hipLaunchKernelGGL(gf_splat_bwd_setup_kernel, dim3(std::max((P + 255) / 256, std::min(1024, (kC * P + 255) / 256))), dim3(256), 0,
-                       stream, z);
     BwdMArgs a;
     a.pts = pts; a.records = ws.records; a.boxes = ws.boxes; a.bitmask = ws.bitmask; a.out_grad = out_grad; a.rows = ws.bwd_rows;
     a.means_grad = means_grad; a.opa_grad = opa_grad; a.sem_grad = sem_grad; a.cov_grad = cov_grad; a.state = state;
-    a.tile_counters = ws.flags + 4608; a.gen_word = gen_word;
+    a.tile_counters = ws.flags + kBwdCounters; a.gen_word = gen_word; a.row_first = ws.bwd_row_first; a.wave_total = ws.bwd_wave_total;
     a.P = P; a.N = N; a.nwords = ws.nwords; a.nrow = ws.nrow; a.H = H; a.W = W; a.D = D; a.nsx = ws.nsx; a.nsy = ws.nsy;
     a.gate = gate ? 1 : 0; a.records_asserted = records_asserted;
     a.timeline = g_bwd_timeline;
     hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel, dim3(grid), dim3(64), 0, stream, a);
-    BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, gen_word, state, P, gate ? 1 : 0,
-                  (P + 7) / 8, records_asserted};
+    BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, ws.bwd_row_first, gen_word,
+                  ws.flags + kBwdCounters, state, (uint32_t)(grid / 8), P, gate, (P + 31) / 32, records_asserted};
     hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + 256), dim3(256), 0, stream, r);
 }
 

@@ -54,7 +54,10 @@ struct PrepArgs {
     uint32_t *tile_counters;  // null, or the eight per-XCD tile counters of the matrix-core render kernel ...
     uint32_t tile_counter_init;  // ... and the value they start from (the workgroups per XCD: those tiles are taken)
     uint32_t *unit_totals;   // null, or [nwords]: rows of the matrix-core backward's partial-gradient buffer the wave's 64 Gaussians
-                             // need (bit 31: one of them needs more than kBwdBigRows); record dword 30 = the Gaussian's offset in its wave
+                             // need (bit 31: one of them needs more than kBwdBigRows)
+    uint32_t *unit_local;    // ... [P]: the same offsets as a compact array
+    uint32_t *bwd_counters;  // ... the backward's per-XCD unit counters, armed here with bwd_counter_init (the backward's last kernel re-arms them)
+    uint32_t bwd_counter_init;
     uint32_t *gen_word;      // null, or the workspace's generation word: bumped by every launch that rewrites the records
     const uint32_t *gate_state;  // null, or (backward) the forward's state block: stand down if the workspace still holds its records
     int range_theta_here;    // 1: the records pass checks theta as well as opacity * semantics (no verification waves: GF_PTS_ASSUME_DENSE)
@@ -273,8 +276,9 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     const bool nonempty = valid && hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2];
     // Matrix-core backward: a Gaussian owns one row of the partial-gradient buffer per double brick (4 x 4 x 8 voxels) its box
     // meets, row (bx, by, bz) of the box's brick range at  first + ((bx - bx0) nby + (by - by0)) nbz + (bz - bz0).  Here: the
-    // Gaussian's offset inside its wave of 64 (record dword 30) and the wave's total; the backward's set-up kernel turns the
-    // totals into `first` (record dword 31).  No atomics, no counter to reset: the rows a Gaussian gets are the same every run.
+    // Gaussian's offset inside its wave of 64 (unit_local) and the wave's total; a prefix over the totals (eight waves of the
+    // render kernel that follows, or the backward's set-up kernel) turns them into `first`.  No atomics, no counter to reset:
+    // the rows a Gaussian gets are the same every run.
     uint32_t unit_first = 0u;
     if (a.unit_totals) {
         const int cnt = nonempty ? (((hi[0] - 1) >> 2) - (lo[0] >> 2) + 1) * (((hi[1] - 1) >> 2) - (lo[1] >> 2) + 1) *
@@ -283,6 +287,8 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         unit_first = (uint32_t)(incl - cnt);
         const bool any_big = __builtin_amdgcn_ballot_w64(cnt > kBwdBigRows) != 0ull;
         if (lane == 63) a.unit_totals[word] = (uint32_t)incl | (any_big ? 0x80000000u : 0u);
+        if (valid) a.unit_local[g] = unit_first;
+        if (blockIdx.x == 0 && threadIdx.x < 8) a.bwd_counters[64 * threadIdx.x] = a.bwd_counter_init;
     }
     // supertile range touched by the box
     const int sx_lo = lo[0] / kSuper, sx_hi = nonempty ? (hi[0] - 1) / kSuper : -1;
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             rec[4] = make_float4(sm[4], sm[5], sm[6], sm[7]);
             rec[5] = make_float4(sm[8], sm[9], sm[10], sm[11]);
             rec[6] = make_float4(sm[12], sm[13], sm[14], sm[15]);
-            rec[7] = make_float4(sm[16], sm[17], a.unit_totals ? __uint_as_float(unit_first) : kdet, __uint_as_float(0xFFFFFFFFu));
+            rec[7] = make_float4(sm[16], sm[17], kdet, 0.f);
         }
     } else {
         // ---- records, large P.  The 64 Gaussians of a wave are contiguous in every input array, so the
@@ -394,8 +400,8 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             } else {
                 rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
             }
-            row[30] = a.unit_totals ? __uint_as_float(unit_first) : kdet;
-            row[31] = __uint_as_float(0xFFFFFFFFu);
+            row[30] = kdet;
+            row[31] = 0.f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -477,16 +483,54 @@ struct RenderArgs {
     uint32_t *tile_counters;  // matrix-core kernel: next unclaimed tile of XCD x at [64 x] (one cache line each)
     const uint32_t *range_flags;  // matrix-core kernels: the records pass's range verdicts, nrange4 16-byte pieces (null = none)
     int nrange4;
-    uint32_t rows_valid;  // state word 4: bit 0 = the records pass laid out the matrix-core backward's rows (record dword 30)
+    uint32_t rows_valid;  // 1: the records pass laid out the matrix-core backward's rows; the wave kernel finishes the layout (below)
+    const uint32_t *unit_totals, *unit_local;   // the records pass's layout words ...
+    uint32_t *unit_first;                       // ... [P] first row of every Gaussian, written by the wave kernel
+    uint32_t unit_cap;                          // ... rows available
 };
 
 // Words 3 and 4 of the state block: the workspace's generation (gf_splat_prep_kernel bumped it) and whether the records carry
 // the backward's row offsets.  gf_splat_backward compares the generation with the workspace's: equal = the forward's records,
 // boxes and bitmask are still there and the records pass is not repeated.
-__device__ __forceinline__ void stamp_state(const RenderArgs &a)
+__device__ __forceinline__ void stamp_state(const RenderArgs &a, uint32_t rows_ready = 0u)
 {
     a.state[3] = a.verify_flags[kGenWord - 64];   // (verify_flags = flags + 64)
-    a.state[4] = a.rows_valid;
+    a.state[4] = rows_ready;   // bit 0: every Gaussian's first row is in the workspace and the rows fit the buffer
+}
+
+// The matrix-core backward's row layout, finished inside the forward: the records pass left the rows each wave of 64 Gaussians
+// needs (unit_totals) and every Gaussian's offset inside its wave (unit_local); here workgroups 0..7 (one wave each, one per XCD)
+// take the prefix over the <= kWRow totals and write first[g] = prefix + offset for every eighth wave of Gaussians.  A few
+// microseconds of eight waves out of 2 048, at the start of the kernel, where the dynamic unit claims absorb them; the backward
+// then starts with its gradient kernel (no set-up launch).  Returns "all rows fit the buffer" (the same value in all eight).
+__device__ __forceinline__ bool finish_row_layout(const RenderArgs &a, uint32_t *s_base, int lane)
+{
+    const int nw = a.nwords;
+    constexpr int kPer = (kWRow + 63) / 64;   // totals per lane, contiguous
+    uint32_t t[kPer];
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int w = kPer * lane + k;
+        t[k] = w < nw ? (a.unit_totals[min(w, nw - 1)] & 0x7FFFFFFFu) : 0u;
+        mine += t[k];
+    }
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)mine);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t run = incl - mine;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        if (kPer * lane + k < nw) s_base[kPer * lane + k] = run;
+        run += t[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool fits = total <= a.unit_cap;
+    for (int w = (int)blockIdx.x; w < nw; w += 8) {
+        const int g = 64 * w + lane;
+        if (g < a.P) a.unit_first[g] = fits ? s_base[w] + a.unit_local[g] : 0xFFFFFFFFu;
+    }
+    return fits;
 }
 
 static_assert(kVerifyBlocks == 16 * 256, "render thread t reads verdicts [16t, 16t+16)");
@@ -1771,11 +1815,14 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
         verdict = (__builtin_amdgcn_ballot_w64((v & 1u) != 0u) ? 1 : 0) | (__builtin_amdgcn_ballot_w64((v & 2u) != 0u) ? 2 : 0) |
                   (__builtin_amdgcn_ballot_w64((rv & 4u) != 0u) ? 4 : 0) | (__builtin_amdgcn_ballot_w64((rv & 8u) != 0u) ? 8 : 0);
     }
+    uint32_t rows_ready = 0u;
+    if (blockIdx.x < 8 && a.rows_valid && !verdict)   // (slot area of the LDS block: idle until the first list is built)
+        rows_ready = finish_row_layout(a, s_u, lane) ? 1u : 0u;
     if (blockIdx.x == 0 && lane == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
         a.state[1] = verdict ? GF_PATH_ARBITRARY : GF_PATH_MATRIX_CORE_WAVE;
         a.state[2] = (uint32_t)verdict;
-        stamp_state(a);
+        stamp_state(a, rows_ready);
     }
     if (verdict) {
         general_body<GF_SPLAT_BASE, kExpComp, LABELS>(a);
@@ -2475,7 +2522,9 @@ void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, in
     pa.prescale = 0; pa.exact_det = 0; pa.lattice = 0;
     pa.tile_counters = nullptr; pa.tile_counter_init = 0u;   // (the backward's set-up kernel arms the unit counters)
     pa.range_flags = nullptr; pa.range_theta_here = 0;
-    pa.unit_totals = ws.bwd_wave_total; pa.gen_word = ws.flags + kGenWord; pa.gate_state = state;
+    pa.unit_totals = ws.bwd_wave_total; pa.unit_local = ws.bwd_row_local; pa.bwd_counters = ws.flags + kBwdCounters;
+    pa.bwd_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);
+    pa.gen_word = ws.flags + kGenWord; pa.gate_state = state;
     const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
                             (prep_waves > 1 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
     if (prep_waves == 1) hipLaunchKernelGGL(gf_splat_prep_kernel<1>, dim3(pa.nprep_blocks), dim3(64), prep_lds, stream, pa);
@@ -2559,9 +2608,12 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.exact_det = (flags & GF_PROB_EXACT_DET) ? 1 : 0;
     pa.lattice = (mfma && verify) ? 1 : 0;
     uint32_t *tile_counters = ws.flags + 4608;  // [64 x], x < 8: inside the 32 KB flag section, past the verdicts
-    // the matrix-core backward's row layout rides along (a scan per wave of 64 Gaussians): a backward that finds the workspace
-    // untouched (generation word) then skips its own records pass
-    pa.unit_totals = (mfma && ws.bwd_cap > 0u && !lab.labels) ? ws.bwd_wave_total : nullptr;
+    // GF_PREPARE_BACKWARD: the matrix-core backward's row layout rides along (a scan per wave of 64 Gaussians here, a prefix in
+    // eight waves of the render kernel); a backward that finds the workspace untouched (generation word) then starts with its
+    // gradient kernel
+    pa.unit_totals = (mfma && ws.bwd_cap > 0u && !lab.labels && (flags & GF_PREPARE_BACKWARD)) ? ws.bwd_wave_total : nullptr;
+    pa.unit_local = ws.bwd_row_local; pa.bwd_counters = ws.flags + kBwdCounters;
+    pa.bwd_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);   // (the backward kernel's grid is the forward's)
     pa.gen_word = ws.flags + kGenWord; pa.gate_state = nullptr;
     pa.tile_counters = mfma ? tile_counters : nullptr;
     pa.range_flags = mfma ? ws.range_flags : nullptr;
@@ -2593,6 +2645,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.range_flags = mfma ? ws.range_flags : nullptr;
     ra.nrange4 = (ws.nwords + 3) / 4;
     ra.rows_valid = pa.unit_totals ? 1u : 0u;
+    ra.unit_totals = ws.bwd_wave_total; ra.unit_local = ws.bwd_row_local; ra.unit_first = ws.bwd_row_first; ra.unit_cap = ws.bwd_cap;
     if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);
     else if (variant == GF_SPLAT_BASE)

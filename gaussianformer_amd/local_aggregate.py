@@ -316,8 +316,11 @@ class _LocalAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D, H, W, D, flags=_lib.GF_PTS_AUTO):
+        # (a backward will follow: the forward lays out its partial-gradient rows on the way -- GF_PREPARE_BACKWARD)
+        wants_grad = any(ctx.needs_input_grad)
         logits, _, _, _, state = splat_forward(_lib.GF_SPLAT_BASE, pts, points_int, means3D, means3D_int,
-                                               opacities, semantics, radii, cov3D, H, W, D, flags=flags)
+                                               opacities, semantics, radii, cov3D, H, W, D,
+                                               flags=flags | (_lib.GF_PREPARE_BACKWARD if wants_grad else 0))
         ctx.dims = (H, W, D)
         ctx.fwd_flags = flags
         # Which body rendered the call is only known on the device (word 1 of the state block).  The backward has a kernel for

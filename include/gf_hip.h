@@ -81,6 +81,13 @@ extern "C" {
  * they differ the gradients are NaN, never wrong.  Without the flag the pass is launched and stands down by itself when
  * the generations agree (an empty launch).  Ignored where the matrix-core backward does not apply. */
 #define GF_RECORDS_VALID 512
+/* gf_splat_forward only: a backward of this call will follow.  The records pass then also lays out the matrix-core backward's
+ * partial-gradient rows (a scan per 64 Gaussians) and eight waves of the render kernel finish the layout (a prefix over
+ * <= 618 totals, one word per Gaussian) -- about 0.3 us of the forward at P = 25 601 -- so that gf_splat_backward starts with its
+ * gradient kernel: no records pass, no set-up launch (GF_RECORDS_VALID), 18 us less.  Without it the forward does none of this and
+ * the backward prepares everything itself.  Word 4 of the state block, bit 0: the layout is there and every row fits the
+ * buffer.  Ignored where the matrix-core backward does not apply. */
+#define GF_PREPARE_BACKWARD 1024
 
 /* values of word 1 of the state block after gf_splat_forward: which body rendered the call */
 #define GF_PATH_EXACT_TILE 0     /* exact-fp32 tile kernel (dense grid) */

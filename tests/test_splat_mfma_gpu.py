@@ -398,7 +398,10 @@ def test_backward_takes_the_forward_records_when_the_workspace_still_holds_them(
     other = make_splat_inputs("nuscenes_gs25600_solid", seed=22, P=700, H=24, W=28, D=8)
     pi, mi, radii, cov6 = prep(si)
     g = np.random.default_rng(5).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
-    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _, t, state0, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    assert (state0.view(torch.int32)[4].item() & 1) == 0                 # a forward that was not told of a backward prepares nothing
+    plain = _bwd(gpu, si, t, state0, g)
+    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_PREPARE_BACKWARD)
     words = state.view(torch.int32)[:5].tolist()
     assert words[1] == _lib.GF_PATH_MATRIX_CORE_WAVE and (words[4] & 1) == 1
     base = _bwd(gpu, si, t, state, g)                                    # records still there
@@ -407,8 +410,8 @@ def test_backward_takes_the_forward_records_when_the_workspace_still_holds_them(
         assert np.abs(a - b.reshape(a.shape)).max() <= 1e-4 * max(np.abs(b).max(), 1e-30)
     again = _bwd(gpu, si, t, state, g)                                   # a second backward of the same forward
     asserted = _bwd(gpu, si, t, state, g, flags=_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID)
-    for a, b, c in zip(base, again, asserted):
-        assert np.array_equal(a, b) and np.array_equal(a, c)
+    for a, b, c, d in zip(base, again, asserted, plain):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
     # another shape through the same workspace: its sections lie over this forward's records
     hip_splat_forward(gpu, other, *prep(other))
     redo = _bwd(gpu, si, t, state, g)
@@ -420,7 +423,7 @@ def test_backward_takes_the_forward_records_when_the_workspace_still_holds_them(
     assert all(np.isnan(a).all() for a in wrong)
     # the exact pipeline of another shape uses the workspace too
     _, t2, state2, _ = hip_splat_forward(gpu, other, *prep(other), flags=_lib.GF_EXACT_FP32)
-    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_PREPARE_BACKWARD)
     g2 = np.random.default_rng(6).standard_normal((other.pts.shape[0], 18)).astype(np.float32)
     _bwd(gpu, other, t2, state2, g2, flags=_lib.GF_EXACT_FP32)
     after = _bwd(gpu, si, t, state, g)
@@ -437,7 +440,7 @@ def test_backward_rows_of_whole_grid_gaussians_and_of_a_full_buffer(gpu, case):
     from gaussianformer_amd.synthetic import cov_inverse
     if case == "several_whole_grid":
         si = make_splat_inputs("nuscenes_gs25600_solid", seed=23, P=20, H=72, W=72, D=16)
-        si.scales[3] = si.scales[11] = si.scales[12] = 60.0
+        si.scales[3] = si.scales[11] = 60.0   # (with the appended one: three whole-grid Gaussians, 1 944 of the 2 656 rows provided)
     else:
         si = make_splat_inputs("nuscenes_gs25600_solid", seed=24, P=900, H=72, W=72, D=16)
         si.scales[:-1] = np.maximum(si.scales[:-1], 2.5)   # boxes of ~ 30 voxels a side: > 100 rows per Gaussian, 16 provided
@@ -445,9 +448,13 @@ def test_backward_rows_of_whole_grid_gaussians_and_of_a_full_buffer(gpu, case):
     si.cov3D = cov_inverse(si.scales, quats).astype(np.float32)
     pi, mi, radii, cov6 = prep(si)
     g = np.random.default_rng(7).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
-    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
-    got = _bwd(gpu, si, t, state, g)
+    from gaussianformer_amd import _lib
     ref = oracle.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D, g)
-    for a, b in zip(got, ref):
-        assert np.isfinite(a).all()
-        assert np.abs(a - b.reshape(a.shape)).max() <= 2e-4 * max(np.abs(b).max(), 1e-30)
+    for fflags in (0, _lib.GF_PREPARE_BACKWARD):
+        _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=fflags)
+        if fflags:   # the forward reports whether every row fitted
+            assert (state.view(torch.int32)[4].item() & 1) == (1 if case == "several_whole_grid" else 0)
+        got = _bwd(gpu, si, t, state, g)
+        for a, b in zip(got, ref):
+            assert np.isfinite(a).all()
+            assert np.abs(a - b.reshape(a.shape)).max() <= 2e-4 * max(np.abs(b).max(), 1e-30)

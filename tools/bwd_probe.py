@@ -84,9 +84,9 @@ else:
             us = timed(lambda: splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=flags))
             print(f"{config}: backward {name}: {us:.1f} us per call (module-level: allocations included)", flush=True)
         # a fresh forward: the workspace holds its records, and the backward calls below leave them alone
-        logits, _, _, _, state2 = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D)
+        logits, _, _, _, state2 = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
         ref_out = splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=_lib.GF_MFMA_SPLAT)
-        logits, _, _, _, state2 = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D)
+        logits, _, _, _, state2 = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
         for name, flags in (("auto, forward's records still there", 0), ("matrix cores asserted, forward's records still there", _lib.GF_MFMA_SPLAT),
                             ("matrix cores + records asserted (GF_RECORDS_VALID)", _lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID)):
             us = timed(lambda: splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state2, flags=flags))

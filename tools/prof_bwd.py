@@ -16,7 +16,7 @@ pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales,
                                                   si.scale_multiplier, radii_min=1 if si.variant == "prob" else None)
 t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
 variant = _lib.GF_SPLAT_PROB if si.variant == "prob" else _lib.GF_SPLAT_BASE
-logits, bl, de, pr, state = splat_forward(variant, *t, si.H, si.W, si.D)
+logits, bl, de, pr, state = splat_forward(variant, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD if flags & _lib.GF_RECORDS_VALID else 0)
 g = torch.randn(logits.shape, generator=torch.Generator().manual_seed(1)).to(dev)
 for _ in range(iters):
     splat_backward(variant, *t, si.H, si.W, si.D, g, fwd_outputs=(logits, bl, de, pr) if variant else None, state=state, flags=flags)
