@@ -413,6 +413,40 @@ def main():
                     "bit_identical_to_headline": same,
                     "note": "same K steps with GF_PTS_ASSUME_DENSE (pts / points_int not re-scanned; range verdicts kept)"}
 
+        def splat_backward_extra():
+            # SURVEY.md section 8 row (a), second half: the splat backward of the same frame through the C ABI, as the autograd
+            # module calls it (forward with GF_PREPARE_BACKWARD, backward with GF_MFMA_SPLAT | GF_RECORDS_VALID when the forward ran
+            # on the matrix cores; the Gaussian-major exact kernels beside it).  Algorithmic bytes: dL/dlogits once + parameters +
+            # gradients (section 8d).
+            if si.variant == "prob":
+                return None
+            from gaussianformer_amd.local_aggregate import splat_backward, splat_forward
+            t = wl.tensors
+            logits, _, _, _, state = splat_forward(wl.variant, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
+            torch.cuda.synchronize()
+            words = state.view(torch.int32)[:5].tolist()
+            fast = words[0] == 0 and words[1] in (_lib.GF_PATH_MATRIX_CORE, _lib.GF_PATH_MATRIX_CORE_WAVE) and (words[4] & 1)
+            g = torch.randn(logits.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+            res = {}
+            for name, flags in (("matrix_core", (_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if fast else 0), ("exact_fp32", _lib.GF_EXACT_FP32)):
+                fn = lambda: splat_backward(wl.variant, *t, si.H, si.W, si.D, g, state=state, flags=flags)
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+                t7 = time.perf_counter()
+                for _ in range(args.steps):
+                    out = fn()
+                torch.cuda.synchronize()
+                res[name] = (time.perf_counter() - t7) / args.steps
+                if name == "matrix_core":
+                    finite = all(bool(torch.isfinite(x).all()) for x in out)
+            by = 128 * P + 24 * N + 72 * N + 112 * P   # SURVEY.md section 8d (the same figure tools/bench_ops.py uses)
+            return {"us_per_call": res["matrix_core"] * 1e6, "exact_fp32_us_per_call": res["exact_fp32"] * 1e6,
+                    "algorithmic_bytes": by, "frac_of_8TBs": by / res["matrix_core"] / 8e12, "finite": finite,
+                    "forward_prepared_rows": bool(fast),
+                    "note": "module-level calls (four output allocations included); matrix-core backward = gradient kernel + row sums"}
+
+        extra("splat_backward", splat_backward_extra)
         extra("two_stream", two_stream)
         extra("hip_graph", hip_graph)
         extra("verified_once", verified_once)

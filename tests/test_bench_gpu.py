@@ -42,6 +42,9 @@ def test_bench_single_gpu_line(gpu):
     assert "error" not in g3 and g3["roofline"]["kernel_launches_timed"] >= 8 and 0 < g3["roofline"]["frac"] < 1
     v1 = b["verified_once"]
     assert "error" not in v1 and v1["bit_identical_to_headline"] is True
+    bw = b["splat_backward"]
+    assert "error" not in bw and bw["finite"] is True and bw["forward_prepared_rows"] is True
+    assert 0 < bw["us_per_call"] < bw["exact_fp32_us_per_call"] * 1.2
 
 
 def test_bench_two_rank_strong_scaling_path(gpu):

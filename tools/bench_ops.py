@@ -52,12 +52,18 @@ for config in ("nuscenes_gs25600_solid", "nuscenes_gs144000", "prob_gs6400"):
     extra_out = 12 * N if variant else 0
     sec = timed(lambda: splat_forward(variant, *t, si.H, si.W, si.D))
     report("splat_forward(module-level call)", config, sec, 128 * P + 24 * N + 72 * N + extra_out, {"P": P, "Gaussians_per_s": P / sec})
-    logits, bl, de, pr, state = splat_forward(variant, *t, si.H, si.W, si.D)
+    # as the autograd module calls the pair: the forward told of the backward (GF_PREPARE_BACKWARD), the backward told what the
+    # forward's state block says (matrix cores, rows laid out -> GF_MFMA_SPLAT | GF_RECORDS_VALID)
+    logits, bl, de, pr, state = splat_forward(variant, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
+    torch.cuda.synchronize()
+    words = state.view(torch.int32)[:5].tolist()
+    fast = words[0] == 0 and words[1] in (_lib.GF_PATH_MATRIX_CORE, _lib.GF_PATH_MATRIX_CORE_WAVE) and (words[4] & 1)
     g = torch.randn(N, 18, device=dev)
     gb = torch.randn(N, device=dev) if variant else None
     sec = timed(lambda: splat_backward(variant, *t, si.H, si.W, si.D, g, fwd_outputs=(logits, bl, de, pr) if variant else None,
-                                       bin_logits_grad=gb, density_grad=gb, state=state), iters=10)
-    report("splat_backward", config, sec, 128 * P + 24 * N + 72 * N + 112 * P, {"P": P})
+                                       bin_logits_grad=gb, density_grad=gb, state=state,
+                                       flags=(_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if fast else 0), iters=10)
+    report("splat_backward", config, sec, 128 * P + 24 * N + 72 * N + 112 * P, {"P": P, "matrix_core_backward": bool(fast)})
 
 from gaussianformer_amd.gaussian_prepare import gaussian_prepare  # noqa: E402
 for P in (25601, 144000):
