@@ -151,13 +151,16 @@ int gf_splat_forward(int variant, int radii_per_axis, int flags, int P, int N, i
  * tensor's maximum from the reference's own kernels).  (2) For the base variant after a forward that one of the matrix-core
  * kernels rendered (word 1 of `state`) and bitmask rows of <= 618 words (P <= 39 552): the voxel-major matrix-core backward --
  * every double brick loads its gradient rows once, the sums over voxels are contractions on the MFMAs (split-f16 operands,
- * fp32 accumulate, an exact-fp32 MFMA for sum_c dL sem), per-(Gaussian, brick) partial rows are added up in a fixed order
+ * fp32 accumulate), per-(Gaussian, brick) partial rows are added up in a fixed order
  * (~1e-5 from the reference; tolerance 1e-3).  Which one applies is device-side knowledge, so by default BOTH pipelines are
  * launched, each gated on the state block (the one that stands down costs its empty launches).  flags:
  *   GF_EXACT_FP32   (1) only.
  *   GF_MFMA_SPLAT   (2) only: the caller has seen the state block and asserts a matrix-core forward; if the state block says
  *                   otherwise every gradient comes out NaN (never silently wrong).  Ignored where (2) does not apply.
+ *   GF_RECORDS_VALID  (2) without its records pass and set-up launch: see the flag (pairs with GF_PREPARE_BACKWARD in the forward).
  *   GF_PTS_ASSUME_DENSE / GF_PTS_GENERAL as in the forward (they select (1)'s body; (2) takes its verdict from `state`).
+ * State block after a forward: word 0 = pts is not the dense grid, 1 = GF_PATH_*, 2 = verdict bits, 3 = the workspace's
+ * generation at that forward, 4 bit 0 = the matrix-core backward's rows are laid out in the workspace and all fit.
  */
 int gf_splat_backward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
                       int W, int D, const float *pts, const int *points_int,
