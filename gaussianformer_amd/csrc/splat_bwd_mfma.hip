@@ -193,8 +193,16 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_setup_kernel(BwdSetupArgs a)
 __device__ __forceinline__ void zero_big_gaussians(const BwdMArgs &a, int lane)
 {
     const int nw = (a.P + 63) >> 6;
-    for (int w0 = 0; w0 < nw; w0 += 64) {
-        const bool f = w0 + lane < nw && (a.wave_total[w0 + lane] >> 31) != 0u;
+    constexpr int kPer = (kWRow + 63) / 64;
+    static_assert(kPer == 10, "operand list below");
+    uint32_t fl[kPer];   // (all loads first, clamped: as `in range ? load : 0` each is a branch with its own round trip)
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) fl[k] = a.wave_total[min(64 * k + lane, nw - 1)];
+    asm volatile("" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]), "+v"(fl[4]), "+v"(fl[5]), "+v"(fl[6]), "+v"(fl[7]), "+v"(fl[8]), "+v"(fl[9]));
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int w0 = 64 * k;
+        const bool f = w0 + lane < nw && (fl[k] >> 31) != 0u;
         unsigned long long m = __builtin_amdgcn_ballot_w64(f);
         while (m) {
             const int w = w0 + __builtin_ctzll(m);
@@ -1026,10 +1034,25 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
     __shared__ uint32_t s_first[64];
     __shared__ int s_nwave;
     const int nw = (a.P + 63) >> 6;
-    if (tid < 64) {   // wave 0: flagged waves, compacted in order
+    {   // (one round trip for all the layout words, then wave 0 compacts the flagged ones in order)
+        uint32_t wt[kBwdBigCap / 256];
+#pragma unroll
+        for (int k = 0; k < kBwdBigCap / 256; ++k) wt[k] = a.wave_total[min(tid + 256 * k, nw - 1)];
+#pragma unroll
+        for (int k = 0; k < kBwdBigCap / 256; ++k) s_wave[tid + 256 * k] = (int)(wt[k] >> 31);
+    }
+    __syncthreads();
+    if (tid < 64) {
         int n = 0;
-        for (int w0 = 0; w0 < nw; w0 += 64) {
-            const bool f = w0 + tid < nw && (a.wave_total[w0 + tid] >> 31) != 0u;
+        bool fs[kBwdBigCap / 64];
+#pragma unroll
+        for (int k = 0; k < kBwdBigCap / 64; ++k) fs[k] = 64 * k + tid < nw && s_wave[64 * k + tid] != 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (the list below overwrites the flags, front to back, never ahead of what was read)
+#pragma unroll
+        for (int k = 0; k < kBwdBigCap / 64; ++k) {
+            const int w0 = 64 * k;
+            const bool f = fs[k];
             const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
             if (f) s_wave[n + __builtin_popcountll(m & ((1ull << tid) - 1ull))] = w0 + tid;
             n += __builtin_popcountll(m);

@@ -499,20 +499,31 @@ __device__ __forceinline__ void stamp_state(const RenderArgs &a, uint32_t rows_r
 }
 
 // The matrix-core backward's row layout, finished inside the forward: the records pass left the rows each wave of 64 Gaussians
-// needs (unit_totals) and every Gaussian's offset inside its wave (unit_local); here workgroups 0..7 (one wave each, one per XCD)
-// take the prefix over the <= kWRow totals and write first[g] = prefix + offset for every eighth wave of Gaussians.  A few
-// microseconds of eight waves out of 2 048, at the start of the kernel, where the dynamic unit claims absorb them; the backward
-// then starts with its gradient kernel (no set-up launch).  Returns "all rows fit the buffer" (the same value in all eight).
+// needs (unit_totals) and every Gaussian's offset inside its wave (unit_local); here workgroups 0..63 (one wave each, eight per
+// XCD) take the prefix over the <= kWRow totals and write first[g] = prefix + offset for every 64th wave of Gaussians: two
+// batches of ten loads, a wave scan and ten stores -- ~3 us of 64 waves out of 2 048, at the start of the kernel, where the
+// dynamic unit claims absorb them; the backward then starts with its gradient kernel (no set-up launch).  Returns "all rows fit
+// the buffer" (the same value in all of them).
+constexpr int kRowLayoutBlocks = 64;
+static_assert(kRowLayoutBlocks * ((kWRow + 63) / 64) >= kWRow, "every wave of Gaussians has a workgroup");
 __device__ __forceinline__ bool finish_row_layout(const RenderArgs &a, uint32_t *s_base, int lane)
 {
     const int nw = a.nwords;
-    constexpr int kPer = (kWRow + 63) / 64;   // totals per lane, contiguous
-    uint32_t t[kPer];
+    constexpr int kPer = (kWRow + 63) / 64;   // totals per lane, contiguous; also: waves of Gaussians per participating workgroup
+    static_assert(kPer == 10, "operand lists below");
+    // (all loads first, from clamped indices, then the masks: written as `w < nw ? load : 0` every load sits in a branch of its
+    // own with its own wait -- ten round trips in a row)
+    uint32_t t[kPer], loc[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) t[k] = a.unit_totals[min(kPer * lane + k, nw - 1)];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) loc[j] = a.unit_local[min(64 * ((int)blockIdx.x + kRowLayoutBlocks * j) + lane, a.P - 1)];
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]));
+    asm volatile("" : "+v"(loc[0]), "+v"(loc[1]), "+v"(loc[2]), "+v"(loc[3]), "+v"(loc[4]), "+v"(loc[5]), "+v"(loc[6]), "+v"(loc[7]), "+v"(loc[8]), "+v"(loc[9]));
     uint32_t mine = 0u;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const int w = kPer * lane + k;
-        t[k] = w < nw ? (a.unit_totals[min(w, nw - 1)] & 0x7FFFFFFFu) : 0u;
+        t[k] = kPer * lane + k < nw ? (t[k] & 0x7FFFFFFFu) : 0u;
         mine += t[k];
     }
     const uint32_t incl = (uint32_t)wave_inclusive_scan((int)mine);
@@ -526,9 +537,10 @@ __device__ __forceinline__ bool finish_row_layout(const RenderArgs &a, uint32_t 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool fits = total <= a.unit_cap;
-    for (int w = (int)blockIdx.x; w < nw; w += 8) {
-        const int g = 64 * w + lane;
-        if (g < a.P) a.unit_first[g] = fits ? s_base[w] + a.unit_local[g] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int w = (int)blockIdx.x + kRowLayoutBlocks * j, g = 64 * w + lane;
+        if (w < nw && g < a.P) a.unit_first[g] = fits ? s_base[w] + loc[j] : 0xFFFFFFFFu;
     }
     return fits;
 }
@@ -1816,7 +1828,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                   (__builtin_amdgcn_ballot_w64((rv & 4u) != 0u) ? 4 : 0) | (__builtin_amdgcn_ballot_w64((rv & 8u) != 0u) ? 8 : 0);
     }
     uint32_t rows_ready = 0u;
-    if (blockIdx.x < 8 && a.rows_valid && !verdict)   // (slot area of the LDS block: idle until the first list is built)
+    if (blockIdx.x < (unsigned)kRowLayoutBlocks && a.rows_valid && !verdict)   // (slot area of the LDS block: idle until the first list is built)
         rows_ready = finish_row_layout(a, s_u, lane) ? 1u : 0u;
     if (blockIdx.x == 0 && lane == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;

@@ -83,6 +83,9 @@ else:
         for name, flags in (("exact (Gaussian-major)", _lib.GF_EXACT_FP32), ("auto (both pipelines gated)", 0), ("matrix cores asserted", _lib.GF_MFMA_SPLAT)):
             us = timed(lambda: splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=flags))
             print(f"{config}: backward {name}: {us:.1f} us per call (module-level: allocations included)", flush=True)
+        for name, fl in (("plain", 0), ("GF_PREPARE_BACKWARD", _lib.GF_PREPARE_BACKWARD)):
+            us = timed(lambda: splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=fl), n=200)
+            print(f"{config}: forward {name}: {us:.1f} us per call (module-level: allocations included)", flush=True)
         # a fresh forward: the workspace holds its records, and the backward calls below leave them alone
         logits, _, _, _, state2 = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
         ref_out = splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=_lib.GF_MFMA_SPLAT)
