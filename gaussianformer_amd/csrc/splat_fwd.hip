@@ -152,17 +152,30 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         const long long stride = (long long)kVerifyBlocks * 64;
         // lattice (matrix-core render kernel only): pts[n] == p0 + index * step per axis, exactly, in fp64 -- the kernel
         // evaluates its polynomial at those positions without reading pts
+        // Every load of this wave goes out before anything is waited for -- the lattice origin and steps, the wave's four points
+        // (index triple + position) and, for the first P / 64 waves, one Gaussian's covariance and radii: ONE round trip.  None
+        // sits under a condition: `if (a.lattice) load` is a branch with its own `s_waitcnt vmcnt(0)` inside, even when the
+        // condition is kernel-uniform -- the four "independent" rounds below were four serial round trips, after one for the
+        // lattice constants and before one for the covariances.  Where a load is not wanted it reads a harmless address instead
+        // (points_int in place of pts; the points in place of a Gaussian) and its value is ignored.
+        const float *pp = a.lattice ? a.pts : reinterpret_cast<const float *>(a.points_int);
+        const float q0x = pp[0], q0y = pp[1], q0z = pp[2];
+        const float q1x = pp[a.H > 1 ? 3 * (size_t)a.W * a.D : 0], q1y = pp[a.W > 1 ? 3 * (size_t)a.D + 1 : 1], q1z = pp[a.D > 1 ? 3 + 2 : 2];
+        const int g0 = vb * 64 + lane;
+        const bool has_g = a.lattice && g0 < a.P;
+        const float *cv0 = has_g ? a.cov3D + 6 * (size_t)g0 : pp;
+        const int *rd0 = has_g ? a.radii + (a.per_axis ? 3 * (size_t)g0 : (size_t)g0) : a.points_int;
+        float c0[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) c0[j] = cv0[j];
+        const int rr0 = rd0[0], rr1 = rd0[a.per_axis ? 1 : 0], rr2 = rd0[a.per_axis ? 2 : 0];
+        uint32_t rbits = 0u;
         double p0x = 0, p0y = 0, p0z = 0, sx = 0, sy = 0, sz = 0;
-        if (a.lattice) {
-            p0x = a.pts[0]; p0y = a.pts[1]; p0z = a.pts[2];
-            sx = a.H > 1 ? (double)a.pts[3 * (size_t)a.W * a.D] - p0x : 1.0;
-            sy = a.W > 1 ? (double)a.pts[3 * (size_t)a.D + 1] - p0y : 1.0;
-            sz = a.D > 1 ? (double)a.pts[3 + 2] - p0z : 1.0;
-        }
+        bool first_round = true;
         for (long long n0 = (long long)vb * 64 + lane; n0 < a.N; n0 += 4 * stride) {
             // four independent loads in flight per round trip
             int x[4], y[4], z[4];
-            float px[4] = {0, 0, 0, 0}, py[4] = {0, 0, 0, 0}, pz[4] = {0, 0, 0, 0};
+            float px[4], py[4], pz[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 // clamped, not conditional: `in ? load : 0` compiles to a branch around the load and the
@@ -171,9 +184,14 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 x[k] = a.points_int[3 * n];
                 y[k] = a.points_int[3 * n + 1];
                 z[k] = a.points_int[3 * n + 2];
-                if (a.lattice) {  // kernel-uniform
-                    px[k] = a.pts[3 * n]; py[k] = a.pts[3 * n + 1]; pz[k] = a.pts[3 * n + 2];
-                }
+                px[k] = pp[3 * n]; py[k] = pp[3 * n + 1]; pz[k] = pp[3 * n + 2];
+            }
+            if (first_round) {
+                p0x = q0x; p0y = q0y; p0z = q0z;
+                sx = a.H > 1 ? (double)q1x - p0x : 1.0;
+                sy = a.W > 1 ? (double)q1y - p0y : 1.0;
+                sz = a.D > 1 ? (double)q1z - p0z : 1.0;
+                first_round = false;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -188,22 +206,28 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 }
             }
         }
+        if (first_round) {   // (a wave without points still needs the steps for the range verdict)
+            p0x = q0x; p0y = q0y; p0z = q0z;
+            sx = a.H > 1 ? (double)q1x - p0x : 1.0;
+            sy = a.W > 1 ? (double)q1y - p0y : 1.0;
+            sz = a.D > 1 ? (double)q1z - p0z : 1.0;
+        }
         // The theta range verdict of the matrix-core kernel (see range_of below).  With the point scans running (GF_PTS_AUTO) it
         // rides along here, beside the records pass instead of on its critical path (there it needs the lattice steps -- a
         // dependent round trip: +0.75 us at P = 25 601, +2.8 us at P = 144 000); with GF_PTS_ASSUME_DENSE there are no
         // verification waves and the records pass takes it.  The opacity * semantics verdict is always the records pass's: its
         // lanes hold those values in registers anyway.
-        uint32_t rbits = 0u;
         if (a.lattice) {
             const float lx_ = fabsf((float)sx), ly_ = fabsf((float)sy), lz_ = fabsf((float)sz);
+            const float zero[kC] = {0.f};
+            if (has_g) rbits |= range_bits_of(c0, zero, 0.f, rr0, rr1, rr2, a.H, a.W, a.D, lx_, ly_, lz_) & 4u;
 #pragma nounroll
-            for (int g = vb * 64 + lane; g < a.P; g += kVerifyBlocks * 64) {
+            for (int g = g0 + kVerifyBlocks * 64; g < a.P; g += kVerifyBlocks * 64) {   // (P > 262 144 only)
                 const float *cv = a.cov3D + 6 * (size_t)g;
                 const int r0 = a.radii[a.per_axis ? 3 * g : g], r1 = a.radii[a.per_axis ? 3 * g + 1 : g], r2 = a.radii[a.per_axis ? 3 * g + 2 : g];
                 float c[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) c[j] = cv[j];
-                const float zero[kC] = {0.f};
                 rbits |= range_bits_of(c, zero, 0.f, r0, r1, r2, a.H, a.W, a.D, lx_, ly_, lz_) & 4u;
             }
         }
@@ -264,6 +288,13 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         for (int j = 0; j < kC; ++j) sm_in[j] = sm[j];
         mean_in[0] = a.means3D[3 * gc]; mean_in[1] = a.means3D[3 * gc + 1]; mean_in[2] = a.means3D[3 * gc + 2];
         opa_in = a.opacity[gc];
+        // (every request above is out before the first value is used: left to itself hipcc issued the mean, the opacity and two
+        // of the radii only after waiting for the first covariance pieces -- a second round trip in front of the record stores)
+        {
+            int mm0 = m0, mm1 = m1, mm2 = m2, q0 = r0, q1 = r1, q2 = r2;
+            asm volatile("" : "+v"(mm0), "+v"(mm1), "+v"(mm2), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(mean_in[0]), "+v"(mean_in[1]), "+v"(mean_in[2]), "+v"(opa_in),
+                              "+v"(c_in[0]), "+v"(c_in[4]), "+v"(sm_in[0]), "+v"(sm_in[4]), "+v"(sm_in[8]), "+v"(sm_in[12]), "+v"(sm_in[16]));
+        }
         if (valid) {
             lo[0] = min(a.H, max(0, m0 - r0)); hi[0] = min(a.H, max(0, m0 + r0 + 1));
             lo[1] = min(a.W, max(0, m1 - r1)); hi[1] = min(a.W, max(0, m1 + r1 + 1));
