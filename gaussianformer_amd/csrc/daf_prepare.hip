@@ -141,8 +141,15 @@ __global__ __launch_bounds__(256) void gf_daf_prepare_kernel(DafPrepArgs a)
                 const int in = (int)(t & 0xfffffu), r = (int)(t >> 20);
                 x = mine4[in >> 2];
                 const bool vis = s_valid[wave][r];
+                // (the four keep-mask bytes together, not each behind `vis &&`: a load under a condition is waited for inside
+                // its branch -- four round trips in a row, twice per piece)
+                unsigned char kb[4] = {1, 1, 1, 1};
+                if (wm) {
     #pragma unroll
-                for (int c = 0; c < 4; ++c) ok[c] = vis && (!wm || wm[in + c]);
+                    for (int c = 0; c < 4; ++c) kb[c] = wm[in + c];
+                }
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) ok[c] = vis && kb[c] != 0;
             };
             float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             for (int i4 = lane; i4 < E / 4; i4 += 64) {

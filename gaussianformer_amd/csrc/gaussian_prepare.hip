@@ -195,22 +195,44 @@ __global__ __launch_bounds__(256) void gf_gaussian_pack_kernel(PackArgs a)
         a.opa_o[g] = 1.f;
         return;
     }
+    // every input of this Gaussian first, then the stores: written as copy statements each element was a round trip of its own
+    // (the outputs may alias the inputs as far as the compiler knows, so no load moves above a store) -- eleven in a row
+    constexpr int kMaxC = 18;
+    float m[3], sc[3], q[4], sv[kMaxC];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { a.means_o[3 * (size_t)g + k] = a.means[3 * (size_t)g + k]; a.scales_o[3 * (size_t)g + k] = a.scales[3 * (size_t)g + k]; }
+    for (int k = 0; k < 3; ++k) { m[k] = a.means[3 * (size_t)g + k]; sc[k] = a.scales[3 * (size_t)g + k]; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a.rot_o[4 * (size_t)g + k] = a.rotations[4 * (size_t)g + k];
-    a.opa_o[g] = a.opa ? a.opa[g] : 1.f;
+    for (int k = 0; k < 4; ++k) q[k] = a.rotations[4 * (size_t)g + k];
+    const float *opa_src = a.opa ? a.opa + g : a.means;   // (no opacity given: a harmless address, the value is not used)
+    float op = *opa_src;
     const float *si = a.sem + (size_t)a.Cin * g;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) sv[c] = si[min(c, a.Cin - 1)];
+    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(op));
+    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]), "+v"(sv[8]), "+v"(sv[9]),
+                      "+v"(sv[10]), "+v"(sv[11]), "+v"(sv[12]), "+v"(sv[13]), "+v"(sv[14]), "+v"(sv[15]), "+v"(sv[16]), "+v"(sv[17]));
+    if (!a.opa) op = 1.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.means_o[3 * (size_t)g + k] = m[k]; a.scales_o[3 * (size_t)g + k] = sc[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.rot_o[4 * (size_t)g + k] = q[k];
+    a.opa_o[g] = op;
     const int shift = (a.Cout > a.Cin && a.zero_first) ? 1 : 0;
     if (a.softmax) {
         // torch.softmax over the Cin classes: exp(x - max) / sum, fp32
-        float mx = si[0];
-        for (int c = 1; c < a.Cin; ++c) mx = fmaxf(mx, si[c]);
+        float mx = sv[0];
+#pragma unroll
+        for (int c = 1; c < kMaxC; ++c) mx = c < a.Cin ? fmaxf(mx, sv[c]) : mx;
         float sum = 0.f;
-        for (int c = 0; c < a.Cin; ++c) sum += expf(si[c] - mx);
-        for (int c = 0; c < a.Cin; ++c) so[c + shift] = expf(si[c] - mx) / sum;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) sum += c < a.Cin ? expf(sv[c] - mx) : 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < a.Cin) so[c + shift] = expf(sv[c] - mx) / sum;
     } else {
-        for (int c = 0; c < a.Cin; ++c) so[c + shift] = si[c];
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+            if (c < a.Cin) so[c + shift] = sv[c];
     }
     if (a.Cout > a.Cin) so[a.zero_first ? 0 : a.Cout - 1] = 0.f;
 }
@@ -225,7 +247,7 @@ extern "C" int gf_gaussian_pack(int P, int Cin, int Cout, int zero_first, int wi
 {
     using namespace gf;
     hipStream_t stream = (hipStream_t)stream_;
-    GF_CHECK_ARG(P >= 0 && Cin > 0 && (Cout == Cin || Cout == Cin + 1), "bad sizes (Cout is Cin or Cin + 1)");
+    GF_CHECK_ARG(P >= 0 && Cin > 0 && Cin <= 18 && (Cout == Cin || Cout == Cin + 1), "bad sizes (Cin <= 18; Cout is Cin or Cin + 1)");
     GF_CHECK_ARG(!(with_empty && softmax), "the empty Gaussian and the softmax belong to different heads");
     GF_CHECK_ARG(!with_empty || (empty_mean && empty_scale && empty_rot && empty_scalar && empty_label >= 0 && empty_label < Cout),
                  "with_empty needs the empty Gaussian's parameters");

@@ -30,18 +30,29 @@ __global__ __launch_bounds__(256) void gf_head_labels_kernel(LabelArgs a)
     const float *blk = a.logits + n0 * kC;  // 64 rows = 4608 contiguous bytes, 16-byte aligned when logits is
     float *mine = s_rows[wave];
     const bool vec_ok = ((uintptr_t)a.logits & 15) == 0;
-    for (int e0 = 4 * lane; e0 < nflt; e0 += 256) {
-        if (vec_ok && e0 + 3 < nflt) {
-            *reinterpret_cast<float4 *>(mine + e0) = *reinterpret_cast<const float4 *>(blk + e0);
-        } else {
-            for (int j = 0; j < 4 && e0 + j < nflt; ++j) mine[e0 + j] = blk[e0 + j];
+    const float bin = a.mode != 0 ? a.bin_logits[n0 + min(lane, rows - 1)] : 0.f;
+    if (vec_ok && rows == 64) {
+        // the usual case: the wave's five 16-byte pieces per lane (4.5 on average) requested together, then written to LDS --
+        // as a load-store loop every piece was a round trip of its own
+        float4 v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = *reinterpret_cast<const float4 *>(blk + min(4 * lane + 256 * k, 64 * kC - 4));
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (4 * lane + 256 * k < 64 * kC) *reinterpret_cast<float4 *>(mine + 4 * lane + 256 * k) = v[k];
+    } else {
+        for (int e0 = 4 * lane; e0 < nflt; e0 += 256) {
+            if (vec_ok && e0 + 3 < nflt) {
+                *reinterpret_cast<float4 *>(mine + e0) = *reinterpret_cast<const float4 *>(blk + e0);
+            } else {
+                for (int j = 0; j < 4 && e0 + j < nflt; ++j) mine[e0 + j] = blk[e0 + j];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (lane >= rows) return;
     const float *row = mine + lane * kC;
-    const float bin = a.mode != 0 ? a.bin_logits[n0 + lane] : 0.f;
     float best = 0.f;
     int arg = 0;
 #pragma unroll

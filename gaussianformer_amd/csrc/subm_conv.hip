@@ -155,17 +155,40 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
     // scans for every kz first, then the cross-wave totals, then thread kz reserves the slots of offset kz.
     // (One kz at a time it was three barriers and, in the fill pass, a returning atomic per kz: five
     // serial round trips per workgroup.)
+    // The look-ups of the K cells are chains of dependent loads (head -> entry of the ascending list -> successor ...) but
+    // the K chains are independent: every step is taken for all K cells at once, from clamped indices (a load under a
+    // condition is waited for inside its branch, which made the column 2-3 K serial round trips instead of 3).
     unsigned int c[KMAX], incl[KMAX];
-    int first[KMAX];
+    int first[KMAX], second[KMAX];
+    bool want[KMAX];
 #pragma unroll
     for (int kz = 0; kz < KMAX; ++kz) {
-        c[kz] = 0; first[kz] = -1;
         const int zz = z + kz - r;
-        if (kz < a.K && col >= 0 && zz >= 0 && zz < a.Z && (!FILL || ((seen >> kz) & 1u))) {
-            first[kz] = a.t.head[col + zz];
-            if (FILL && first[kz] >= 0) first[kz] = a.t.first2[first[kz]];   // entry of the ascending list
-            for (int j = first[kz]; j >= 0; j = FILL ? a.t.next2[j] : a.t.next[j]) ++c[kz];
+        want[kz] = kz < a.K && col >= 0 && zz >= 0 && zz < a.Z && (!FILL || ((seen >> kz) & 1u));
+        first[kz] = a.t.head[want[kz] ? col + zz : 0];
+    }
+#pragma unroll
+    for (int kz = 0; kz < KMAX; ++kz) first[kz] = want[kz] ? first[kz] : -1;
+    if (FILL) {   // entry of the ascending list
+        int e[KMAX];
+#pragma unroll
+        for (int kz = 0; kz < KMAX; ++kz) e[kz] = a.t.first2[max(first[kz], 0)];
+#pragma unroll
+        for (int kz = 0; kz < KMAX; ++kz) first[kz] = first[kz] >= 0 ? e[kz] : -1;
+    }
+    {
+        const int *nx = FILL ? a.t.next2 : a.t.next;
+#pragma unroll
+        for (int kz = 0; kz < KMAX; ++kz) second[kz] = nx[max(first[kz], 0)];
+#pragma unroll
+        for (int kz = 0; kz < KMAX; ++kz) {
+            second[kz] = first[kz] >= 0 ? second[kz] : -1;
+            c[kz] = first[kz] >= 0 ? 1u : 0u;
+            for (int j = second[kz]; j >= 0; j = nx[j]) ++c[kz];   // (cells with two or more points: rare)
         }
+    }
+#pragma unroll
+    for (int kz = 0; kz < KMAX; ++kz) {
         if (!FILL && c[kz]) seen |= 1u << kz;
         unsigned int v = c[kz];
 #pragma unroll
@@ -203,7 +226,10 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
         for (int w = 0; w < wave; ++w) before += s_w[kz][w];
         unsigned int slot = s_base[kz] + before;
         a.t.slot_first[(size_t)i * a.K3 + kxy * a.K + kz] = (int)slot;
-        for (int j = first[kz]; j >= 0; j = a.t.next2[j]) {
+        a.pair_in[slot] = first[kz];
+        a.pair_out[slot] = i;
+        ++slot;
+        for (int j = second[kz]; j >= 0; j = a.t.next2[j]) {
             a.pair_in[slot] = j;
             a.pair_out[slot] = i;
             ++slot;
