@@ -301,8 +301,39 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
             lo[2] = min(a.D, max(0, m2 - r2)); hi[2] = min(a.D, max(0, m2 + r2 + 1));
             if (a.range_flags) range_bits = range_of(c_in, sm_in, opa_in, r0, r1, r2);
         }
-    } else if (valid) {
-        gaussian_box(a.means_int, a.radii, a.per_axis, g, a.H, a.W, a.D, lo, hi);
+    }
+    // Large P (WAVES > 1): the same rule -- every global load of the wave is requested before the first value is used.  Per lane:
+    // the box inputs, mean and opacity of its own Gaussian (clamped index); per wave: the 64 semantics and covariance rows as
+    // coalesced 16-byte pieces (lane L of request k reads piece L + 64 k of the block).  Written the natural way (box() under
+    // `if (valid)`, a load-scatter loop per array, opacity and mean where the record is completed) the pass was six round trips
+    // in a row: 20 us at P = 144 000.
+    int rq0 = 0, rq1 = 0, rq2 = 0;
+    float4 sv4[5], cv4[2];
+    bool staged_fast = false;
+    if (WAVES > 1) {
+        const int gc = min(g, a.P - 1);
+        const int m0 = a.means_int[3 * gc], m1 = a.means_int[3 * gc + 1], m2 = a.means_int[3 * gc + 2];
+        rq0 = a.radii[a.per_axis ? 3 * gc : gc]; rq1 = a.radii[a.per_axis ? 3 * gc + 1 : gc]; rq2 = a.radii[a.per_axis ? 3 * gc + 2 : gc];
+        mean_in[0] = a.means3D[3 * gc]; mean_in[1] = a.means3D[3 * gc + 1]; mean_in[2] = a.means3D[3 * gc + 2];
+        opa_in = a.opacity[gc];
+        const int g0_ = word * 64;
+        staged_fast = g0_ + 64 <= a.P && (((uintptr_t)a.semantics | (uintptr_t)a.cov3D) & 15) == 0;   // (wave-uniform)
+        if (staged_fast) {
+            const float *sblk = a.semantics + (size_t)g0_ * kC, *cblk = a.cov3D + (size_t)g0_ * 6;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sv4[k] = *reinterpret_cast<const float4 *>(sblk + min(4 * lane + 256 * k, 64 * kC - 4));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) cv4[k] = *reinterpret_cast<const float4 *>(cblk + min(4 * lane + 256 * k, 64 * 6 - 4));
+        }
+        {
+            int mm0 = m0, mm1 = m1, mm2 = m2;
+            asm volatile("" : "+v"(mm0), "+v"(mm1), "+v"(mm2), "+v"(rq0), "+v"(rq1), "+v"(rq2), "+v"(mean_in[0]), "+v"(mean_in[1]), "+v"(mean_in[2]), "+v"(opa_in));
+        }
+        if (valid) {
+            lo[0] = min(a.H, max(0, m0 - rq0)); hi[0] = min(a.H, max(0, m0 + rq0 + 1));
+            lo[1] = min(a.W, max(0, m1 - rq1)); hi[1] = min(a.W, max(0, m1 + rq1 + 1));
+            lo[2] = min(a.D, max(0, m2 - rq2)); hi[2] = min(a.D, max(0, m2 + rq2 + 1));
+        }
     }
     const bool nonempty = valid && hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2];
     // Matrix-core backward: a Gaussian owns one row of the partial-gradient buffer per double brick (4 x 4 x 8 voxels) its box
@@ -396,8 +427,30 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 }
             }
         };
-        stage(a.semantics, kC, 12);
-        stage(a.cov3D, 6, 4);
+        if (staged_fast) {
+            // (the pieces requested at the top of the kernel: element e of the block belongs to Gaussian e / per, slot e % per)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float v[4] = {sv4[k].x, sv4[k].y, sv4[k].z, sv4[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * lane + 256 * k + j;
+                    if (e < 64 * kC) R[(e / kC) * kRecDwords + 12 + e % kC] = v[j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float v[4] = {cv4[k].x, cv4[k].y, cv4[k].z, cv4[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * lane + 256 * k + j;
+                    if (e < 64 * 6) R[(e / 6) * kRecDwords + 4 + e % 6] = v[j];
+                }
+            }
+        } else {
+            stage(a.semantics, kC, 12);
+            stage(a.cov3D, 6, 4);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (valid) {
@@ -412,15 +465,9 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 kdet = prob_kdet(c0, c1, c2, c3, c4, c5, a.exact_det);
             }
             float4 *rec = reinterpret_cast<float4 *>(row);
-            const float opa_g = a.opacity[g];
-            rec[0] = make_float4(a.means3D[3 * g], a.means3D[3 * g + 1], a.means3D[3 * g + 2], opa_g);
-            if (a.range_flags) {
-                int rr0 = 0, rr1 = 0, rr2 = 0;
-                if (a.range_theta_here) {   // (the radii only enter the theta bound)
-                    rr0 = a.radii[a.per_axis ? 3 * g : g]; rr1 = a.radii[a.per_axis ? 3 * g + 1 : g]; rr2 = a.radii[a.per_axis ? 3 * g + 2 : g];
-                }
-                range_bits = range_of(row + kRecCov, row + kRecSem, opa_g, rr0, rr1, rr2);
-            }
+            const float opa_g = opa_in;
+            rec[0] = make_float4(mean_in[0], mean_in[1], mean_in[2], opa_g);
+            if (a.range_flags) range_bits = range_of(row + kRecCov, row + kRecSem, opa_g, rq0, rq1, rq2);   // (the radii only enter the theta bound)
             if (a.prescale) {
                 // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
                 // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
