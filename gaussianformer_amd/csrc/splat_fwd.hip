@@ -1247,25 +1247,28 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     const int xcd = (int)(blockIdx.x & 7u);
     const int per_xcd = (a.ntiles_total + 7) >> 3;  // logical tiles per XCD (the last XCD's tail may be short)
 
+    // The prep launch's verdict words (point scans: 4 x 16 bytes per thread) and the records pass's range verdicts (four clamped
+    // 16-byte reads per thread: 4 096 words, P <= 262 144; longer rows add a loop) in ONE round trip: all eight loads are
+    // unconditional -- from the flag section, which always exists, where a verdict does not apply -- and masked afterwards.
+    // (Under `if (a.verify_dense)` / `if (a.range_flags)` each group was waited for inside its branch: two round trips at the
+    // start of every workgroup, before the first bitmask row is even requested.)
     uint4 vf = make_uint4(0, 0, 0, 0);
-    if (a.verify_dense) {
-        const uint4 *vp = reinterpret_cast<const uint4 *>(a.verify_flags) + 4 * tid;
-        const uint4 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
-        vf = make_uint4(v0.x | v1.x | v2.x | v3.x, v0.y | v1.y | v2.y | v3.y, v0.z | v1.z | v2.z | v3.z,
-                        v0.w | v1.w | v2.w | v3.w);
-    }
-    // the records pass's range verdicts, requested in the same round trip as the words above: four clamped 16-byte reads per
-    // thread (4096 words: P <= 262 144) issued together; longer rows add a loop
     uint32_t rangev = 0u;
-    if (a.range_flags) {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.range_flags);
-        const int last = a.nrange4 - 1;
-        const uint4 q0 = rp[min(tid, last)], q1 = rp[min(tid + kBlock, last)], q2 = rp[min(tid + 2 * kBlock, last)],
-                    q3 = rp[min(tid + 3 * kBlock, last)];
-        rangev = q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x | q2.y | q2.z | q2.w | q3.x | q3.y | q3.z | q3.w;
-        for (int k = tid + 4 * kBlock; k < a.nrange4; k += kBlock) {
-            const uint4 t4 = rp[k];
-            rangev |= t4.x | t4.y | t4.z | t4.w;
+    {
+        const uint4 *vp = reinterpret_cast<const uint4 *>(a.verify_flags) + 4 * tid;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.range_flags ? a.range_flags : a.verify_flags);
+        const int last = a.range_flags ? a.nrange4 - 1 : 0;
+        uint4 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
+        uint4 q0 = rp[min(tid, last)], q1 = rp[min(tid + kBlock, last)], q2 = rp[min(tid + 2 * kBlock, last)], q3 = rp[min(tid + 3 * kBlock, last)];
+        asm volatile("" : "+v"(v0.x), "+v"(v1.x), "+v"(v2.x), "+v"(v3.x), "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));
+        if (a.verify_dense)
+            vf = make_uint4(v0.x | v1.x | v2.x | v3.x, v0.y | v1.y | v2.y | v3.y, v0.z | v1.z | v2.z | v3.z, v0.w | v1.w | v2.w | v3.w);
+        if (a.range_flags) {
+            rangev = q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x | q2.y | q2.z | q2.w | q3.x | q3.y | q3.z | q3.w;
+            for (int k = tid + 4 * kBlock; k < a.nrange4; k += kBlock) {
+                const uint4 t4 = rp[k];
+                rangev |= t4.x | t4.y | t4.z | t4.w;
+            }
         }
     }
     int local = (int)(blockIdx.x >> 3);
