@@ -19,6 +19,8 @@ constexpr int kBwdRowDwords = 32;    // matrix-core backward: one 128-B row of p
 constexpr int kBwdBigRows = 512;     // ... a Gaussian with more rows than this is summed by whole workgroups (big list)
 constexpr int kBwdBigCap = 1024;     // ... waves of 64 Gaussians the layout words provide for (>= kWRow)
 constexpr int kBwdCounters = 5632;   // flag-section index of the matrix-core backward's per-XCD unit counters ([+ 64 x]; the forward's: 4608)
+constexpr int kBwdList = 256;       // candidate-list entries of the matrix-core backward (and of a list the forward publishes for it)
+constexpr int kListsBad = 8101;      // flag-section word: a supertile's list did not fit kBwdList (the backward then scans the bitmask rows itself)
 constexpr int kGenWord = 8100;       // generation word of a workspace: index into its flag section -- the same word whatever the call's
                                      // shape; every launch that rewrites the records (or the sections they share with other shapes) bumps it
 
@@ -56,6 +58,8 @@ struct SplatWorkspace {
     uint32_t *bwd_wave_total;  // [kBwdBigCap] matrix-core backward: rows needed by each wave of 64 Gaussians (bit 31: one needs > kBwdBigRows)
     uint32_t *bwd_row_local;   // [P] ... a Gaussian's offset among its wave's rows (records pass)
     uint32_t *bwd_row_first;   // [P] ... its first row in bwd_rows (0xFFFFFFFF: no room) = prefix of the totals + offset
+    uint32_t *bwd_lists;       // [nsuper][3][kBwdList] ... every supertile's candidate list (ids, packed box lo, packed box hi), published by the forward
+    uint32_t *bwd_list_len;    // [nsuper] ... its length
     float *bwd_rows;        // [bwd_cap][32] matrix-core backward: partial gradients per (Gaussian, double brick)
     uint32_t bwd_cap;       // rows available (0: the shape does not take the matrix-core backward)
     int nwords, nrow, nsx, nsy, nsuper;
@@ -98,6 +102,8 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.bwd_wave_total = (uint32_t *)(p + off); off += align256((size_t)kBwdBigCap * 4);
     ws.bwd_row_local = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? P : 0) * 4);
     ws.bwd_row_first = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? P : 0) * 4);
+    ws.bwd_lists = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? ws.nsuper : 0) * 3 * kBwdList * 4);
+    ws.bwd_list_len = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? ws.nsuper : 0) * 4);
     ws.bwd_rows = (float *)(p + off); off += align256((size_t)ws.bwd_cap * kBwdRowDwords * 4);
     ws.total_bytes = off;
     return ws;

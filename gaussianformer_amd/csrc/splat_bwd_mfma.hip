@@ -33,6 +33,8 @@
 // forward's state block says a matrix-core body rendered the call) and to rows of <= kWRow bitmask words.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "gf_common.hpp"
 
 #ifndef GF_TIMELINE
@@ -63,13 +65,16 @@ struct BwdMArgs {
     const uint32_t *gen_word;    // the workspace's generation word
     const uint32_t *row_first;   // [P] first row of each Gaussian in `rows` (0xFFFFFFFF: none, atomics instead)
     const uint32_t *wave_total;  // records pass: bit 31 = the wave of 64 Gaussians holds one with more than kBwdBigRows rows
+    const uint32_t *lists, *list_len;   // the forward's candidate lists per supertile ([3][kBwdList] ids / box lo / box hi) and their lengths
+    const uint32_t *lists_bad;   // != 0: some supertile's list was not published
     int P, N, nwords, nrow, H, W, D, nsx, nsy;
     int gate;                    // 1: run only if the forward's state says "matrix cores" (2: the set-up kernel wrote NaN gradients otherwise)
     int records_asserted;        // 1: no records pass ran -- stand down unless the workspace still holds the forward's (generation)
     unsigned long long *timeline;  // debug (GF_TIMELINE builds): 8 stamps per unit
 };
 
-constexpr int kMList = 256;      // candidate list entries (ids, packed box lo, packed box hi) in LDS
+static_assert(kBwdList == 256, "kMList");
+constexpr int kMList = kBwdList;      // candidate list entries (ids, packed box lo, packed box hi) in LDS
 constexpr int kMQCap = 128;      // hit queue (ring)
 constexpr int kMPitch16 = 136;   // halves per channel row of the staged dL: two f16 arrays (hi, lo) [18][136], column = block * 32 + voxel in block
 constexpr int kMDlDwords = kC * kMPitch16;   // both arrays: 2 x 18 x 136 halves
@@ -292,10 +297,21 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     // past the end of the array, are read from a clamped address and cleared when the rows are split.
     const bool dl_by16 = (a.D & 1) == 0;
     const size_t dl_last = (size_t)a.N * kC - (dl_by16 ? 4 : 1);   // (a 16-byte piece never straddles the end: an even number of rows is valid)
+    // The forward published every supertile's candidate list (GF_PREPARE_BACKWARD) and the workspace still holds it: the unit
+    // takes the list -- ids and packed boxes, 3 KB in three requests -- instead of the bitmask row, and skips the row scan and
+    // the box round trip (1.7 + ~1 us of a unit's 21.6).
+    const bool use_lists = a.lists && records_still_there(a.state, a.gen_word) && *a.lists_bad == 0u;
     auto request_unit = [&](int s_, int Xw_, int Y0_, int Zw_) {
         int wl = lane;
         asm volatile("" : "+v"(wl));
-        request_row(a.bitmask + (size_t)s_ * a.nrow, wl);
+        if (use_lists) {
+            const uint32_t *src = a.lists + (size_t)s_ * (3 * kMList) + 4 * wl;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                __builtin_amdgcn_global_load_lds((gptr)(src + kMList * k), (lptr)(s_lg + kMList * k), 16, 0, 0);
+        } else {
+            request_row(a.bitmask + (size_t)s_ * a.nrow, wl);
+        }
         const int per_col = dl_by16 ? 36 : 144, step_off = dl_by16 ? 28 : 64, step_col = dl_by16 ? 1 : 0, fl = dl_by16 ? 4 : 1;
         int col = wl >= per_col ? 1 : 0, off = wl - col * per_col;
         const int nreq = dl_by16 ? 9 : 36;
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
             // ---- the unit's bitmask row and gradient rows (request_unit)
             // (Requesting them from the previous unit's last group, ahead of its row stores, was built and measured: the row wait
             // disappears, but the 36 requests cost that group the same two microseconds of issue time -- 79 against 74 us.)
+            const uint32_t published_len = use_lists ? a.list_len[s] : 0u;   // (requested with the unit's other loads, used after their wait)
             request_unit(s, Xw, Y0, Zw);
             // (9 or 36 requests were issued behind the row's: "at most that many outstanding" = the row has landed)
             if (dl_by16) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -339,8 +356,14 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #endif
             int list_len = 0, qlen = 0, qhead = 0, npend = 0;
             int c = 0, sg = 0;
-            // ---- candidate list from the row: the forward's fast path (nonzero words compacted, bits extracted side by side)
-            {
+            // ---- candidate list: the forward's, as it landed -- or from the row: the forward's fast path (nonzero words compacted,
+            // bits extracted side by side)
+            bool have_boxes = false;
+            if (use_lists) {
+                list_len = min((int)published_len, kMList);
+                c = nchunk;
+                have_boxes = true;
+            } else {
                 constexpr int kWDense = kMList;
                 uint32_t *s_dw = s_u;
                 unsigned long long *s_db = reinterpret_cast<unsigned long long *>(s_u + kWDense);
@@ -629,13 +652,16 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // ---- packed boxes of the listed Gaussians, by LDS-DMA
-                for (int b0 = 0; b0 < list_len; b0 += 64) {
-                    const uint32_t id = s_lg[min(b0 + lane, list_len - 1)];
-                    __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0), 4, 0, 0);
+                // ---- packed boxes of the listed Gaussians, by LDS-DMA (a published list brought them along)
+                if (!have_boxes) {
+                    for (int b0 = 0; b0 < list_len; b0 += 64) {
+                        const uint32_t id = s_lg[min(b0 + lane, list_len - 1)];
+                        __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0), 4, 0, 0);
+                        __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0), 4, 0, 0);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                have_boxes = false;
                 stores_behind = false;
                 // ---- consume: hits of the double brick -> queue -> groups of 32, one-deep record pipeline
                 for (int base = 0; base < list_len || (last && base == 0); base += 64) {
@@ -1157,6 +1183,7 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
     a.pts = pts; a.records = ws.records; a.boxes = ws.boxes; a.bitmask = ws.bitmask; a.out_grad = out_grad; a.rows = ws.bwd_rows;
     a.means_grad = means_grad; a.opa_grad = opa_grad; a.sem_grad = sem_grad; a.cov_grad = cov_grad; a.state = state;
     a.tile_counters = ws.flags + kBwdCounters; a.gen_word = gen_word; a.row_first = ws.bwd_row_first; a.wave_total = ws.bwd_wave_total;
+    a.lists = getenv("GF_BWD_NO_LISTS") ? nullptr : ws.bwd_lists; a.list_len = ws.bwd_list_len; a.lists_bad = ws.flags + kListsBad;
     a.P = P; a.N = N; a.nwords = ws.nwords; a.nrow = ws.nrow; a.H = H; a.W = W; a.D = D; a.nsx = ws.nsx; a.nsy = ws.nsy;
     a.gate = gate ? 1 : 0; a.records_asserted = records_asserted;
     a.timeline = g_bwd_timeline;

@@ -351,6 +351,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         if (lane == 63) a.unit_totals[word] = (uint32_t)incl | (any_big ? 0x80000000u : 0u);
         if (valid) a.unit_local[g] = unit_first;
         if (blockIdx.x == 0 && threadIdx.x < 8) a.bwd_counters[64 * threadIdx.x] = a.bwd_counter_init;
+        if (blockIdx.x == 0 && threadIdx.x == 8) a.verify_flags[kListsBad - 64] = 0u;   // (verify_flags = flags + 64)
     }
     // supertile range touched by the box
     const int sx_lo = lo[0] / kSuper, sx_hi = nonempty ? (hi[0] - 1) / kSuper : -1;
@@ -565,6 +566,7 @@ struct RenderArgs {
     const uint32_t *unit_totals, *unit_local;   // the records pass's layout words ...
     uint32_t *unit_first;                       // ... [P] first row of every Gaussian, written by the wave kernel
     uint32_t unit_cap;                          // ... rows available
+    uint32_t *pub_lists, *pub_len;              // ... [nsuper][3][kBwdList] / [nsuper]: the candidate lists, published for the backward
 };
 
 // Words 3 and 4 of the state block: the workspace's generation (gf_splat_prep_kernel bumped it) and whether the records carry
@@ -1841,7 +1843,9 @@ static_assert(2 * 64 * kC <= 1536 + 3 * kWList, "output staging fits over the sl
 // LABELS: the head epilogue (gf_splat_forward_labels, argmax mode): the labels are taken from the staged rows -- the very fp32
 // values that would be stored -- and, without out_logits, the 46 MB of logits are never written.  A separate instantiation: the
 // default kernel's code is unchanged.
-template <bool LABELS>
+// PREP: the GF_PREPARE_BACKWARD variant (row layout + published candidate lists) -- an instantiation of its own, so that the plain
+// forward keeps its code and register allocation (as one kernel the extra paths cost it 0.8 us per step: 31 more spilled SGPRs).
+template <bool LABELS, bool PREP = false>
 __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(RenderArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_u[kWLdsDwords];
@@ -1909,7 +1913,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                   (__builtin_amdgcn_ballot_w64((rv & 4u) != 0u) ? 4 : 0) | (__builtin_amdgcn_ballot_w64((rv & 8u) != 0u) ? 8 : 0);
     }
     uint32_t rows_ready = 0u;
-    if (blockIdx.x < (unsigned)kRowLayoutBlocks && a.rows_valid && !verdict)   // (slot area of the LDS block: idle until the first list is built)
+    if (PREP && blockIdx.x < (unsigned)kRowLayoutBlocks && a.rows_valid && !verdict)   // (slot area of the LDS block: idle until the first list is built)
         rows_ready = finish_row_layout(a, s_u, lane) ? 1u : 0u;
     if (blockIdx.x == 0 && lane == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
@@ -1997,6 +2001,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
             const double Cx = p0x + ((double)Xw + 1.5) * sx, Cy = p0y + ((double)Y0 + 1.5) * sy, Cz = p0z + ((double)Zw + 3.5) * sz;
+            bool published = false;
             int list_len = 0, qlen = 0, qhead = 0, npend = 0;
             // A prefetched row is older than the previous unit's output stores and memory operations complete in order: with
             // exactly ten stores behind it, "at most ten outstanding" means the row has landed -- without waiting for the stores.
@@ -2182,6 +2187,22 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                     __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0), 4, 0, 0);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // GF_PREPARE_BACKWARD: quarter 0 / brick 0 of every supertile leaves the supertile's candidate list (ids and packed
+                // boxes, as it stands in LDS) for the matrix-core backward, whose units then skip the row scan and the box round
+                // trip -- a later kernel, so nothing has to be synchronised.  A list that did not come out of the row in one piece,
+                // or is longer than the backward's list area, raises a flag instead and the backward scans the rows itself.
+                if (PREP && a.rows_valid && r == 0 && !published) {
+                    published = true;
+                    if (last && list_len <= kBwdList) {
+                        uint32_t *dst = a.pub_lists + (size_t)s * (3 * kBwdList);
+                        for (int i = lane; i < list_len; i += 64) {
+                            dst[i] = s_lg[i]; dst[kBwdList + i] = s_blo[i]; dst[2 * kBwdList + i] = s_bhi[i];
+                        }
+                        if (lane == 0) a.pub_len[s] = (uint32_t)list_len;
+                    } else if (lane == 0) {
+                        atomicOr(const_cast<uint32_t *>(a.verify_flags) + (kListsBad - 64), 1u);
+                    }
+                }
 #if GF_TIMELINE
                 if (!tl[3]) tl[3] = wall_clock64();
 #endif
@@ -2550,6 +2571,8 @@ static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stre
     if (prof) (void)hipEventRecord(ev0, stream);
     if (mfma_by_wave(r.nrow) && r.out_labels)
         hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<true>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
+    else if (mfma_by_wave(r.nrow) && r.rows_valid)
+        hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, true>), dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
     else if (mfma_by_wave(r.nrow))
         hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<false>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
     else
@@ -2739,6 +2762,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.nrange4 = (ws.nwords + 3) / 4;
     ra.rows_valid = pa.unit_totals ? 1u : 0u;
     ra.unit_totals = ws.bwd_wave_total; ra.unit_local = ws.bwd_row_local; ra.unit_first = ws.bwd_row_first; ra.unit_cap = ws.bwd_cap;
+    ra.pub_lists = ws.bwd_lists; ra.pub_len = ws.bwd_list_len;
     if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);
     else if (variant == GF_SPLAT_BASE)

@@ -17,10 +17,10 @@ dev = torch.device("cuda:0")
 si = make_splat_inputs(config, seed=0)
 pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size, si.scale_multiplier)
 t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)]
-logits, _, _, _, state = splat_forward(0, *t, si.H, si.W, si.D)
+logits, _, _, _, state = splat_forward(0, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
 g = torch.randn(logits.shape, generator=torch.Generator().manual_seed(1)).to(dev)
 lib = _lib.load()
-run = lambda: splat_backward(0, *t, si.H, si.W, si.D, g, state=state, flags=_lib.GF_MFMA_SPLAT)
+run = lambda: splat_backward(0, *t, si.H, si.W, si.D, g, state=state, flags=_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID)
 for _ in range(5): run()
 torch.cuda.synchronize()
 nu = 8 * ((si.H + 7) // 8) * ((si.W + 7) // 8) * 4 * ((si.D + 7) // 8) // 8 + 64
