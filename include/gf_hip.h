@@ -83,8 +83,9 @@ extern "C" {
 #define GF_RECORDS_VALID 512
 /* gf_splat_forward only: a backward of this call will follow.  The records pass then also lays out the matrix-core backward's
  * partial-gradient rows (a scan per 64 Gaussians) and 64 waves of the render kernel finish the layout (a prefix over
- * <= 618 totals, one word per Gaussian) -- about 0.8 us of the forward at P = 25 601 -- so that gf_splat_backward starts with its
- * gradient kernel: no records pass, no set-up launch (GF_RECORDS_VALID), 18 us less.  Without it the forward does none of this and
+ * <= 618 totals, one word per Gaussian) and one unit per supertile publishes the supertile's candidate list -- about 1.3 us of the
+ * forward at P = 25 601 -- so that gf_splat_backward starts with its gradient kernel, whose units read those lists instead of
+ * scanning bitmask rows: no records pass, no set-up launch (GF_RECORDS_VALID), 25 us less.  Without it the forward does none of this and
  * the backward prepares everything itself.  Word 4 of the state block, bit 0: the layout is there and every row fits the
  * buffer.  Ignored where the matrix-core backward does not apply. */
 #define GF_PREPARE_BACKWARD 1024
