@@ -4,8 +4,9 @@
 // kernel of splat_bwd.hip does the same walk in parallel and gathers one 72-byte dL/dlogits row per (Gaussian, voxel) pair
 // -- 12.6 M pairs = 0.9 GB of L2 gather for 46 MB of distinct rows.  This file turns the walk round: VOXEL-major, on the
 // forward's work decomposition (gf_splat_render_mfma_wave_kernel, splat_fwd.hip): one wave per double brick (4 x 4 x 8
-// voxels = four blocks of 32), which loads its 128 gradient rows ONCE, finds the Gaussians that touch it from the supertile
-// bitmask and takes them in groups of 32.  Per group and block (32 Gaussians x 32 voxels), with
+// voxels = four blocks of 32), which loads its 128 gradient rows ONCE (coalesced LDS-DMA; scaled and split into f16 hi + lo once
+// per unit), finds the Gaussians that touch it -- from the candidate list the forward published for its supertile, or from the
+// supertile's bitmask row -- and takes them in groups of 32.  Per group and block (32 Gaussians x 32 voxels), with
 //     e[v,g] = exp(-1/2 d^T Sigma^-1 d),  d = mean_g - p_v        T[v,g] = sum_c dL[v,c] sem[g,c]
 // the gradient of backward.cu:72-87 is a set of contractions over voxels
 //     dopa[g]   = sum_v e T                      dsem[g,c] = opa sum_v e[v,g] dL[v,c]
@@ -21,16 +22,21 @@
 //                 rows, B = sem[g][c], both scaled by powers of two and split into f16 hi + lo;
 //   3. e = exp2(D'), K = e T'; both split into f16 hi + lo in registers (they ARE B operands already);
 //   4. moments    M += Phi^T (K_hi + K_lo): 4 MFMAs;   dsem  += dL^T (e_hi + e_lo), dL split hi + lo: 6 MFMAs.
-// Per Gaussian and double brick the 28 sums leave as ONE 128-byte row of a partial buffer (rows handed out by the records
-// pass, gf_splat_prep_kernel) and gf_splat_bwd_rows_kernel adds a Gaussian's rows up in a fixed order: no float atomics
-// (Gaussians with more than 512 rows -- the whole-grid "empty" Gaussian -- are summed by whole workgroups and combined
-// with atomics; Gaussians the buffer has no room for fall back to atomics).
+// Per Gaussian and double brick the 28 sums leave as ONE 128-byte row of a partial buffer.  The rows are laid out by a prefix sum,
+// not a cursor: the records pass (gf_splat_prep_kernel) leaves the rows each wave of 64 Gaussians needs and every Gaussian's
+// offset in its wave; the forward's render kernel (GF_PREPARE_BACKWARD: finish_row_layout) or gf_splat_bwd_setup_kernel turns them
+// into first rows.  gf_splat_bwd_rows_kernel adds a Gaussian's rows up in a fixed order and writes its gradients: no float atomics
+// (Gaussians with more than 512 rows -- the whole-grid "empty" Gaussian -- are summed 64 rows per work item and combined with
+// atomics; Gaussians the buffer has no room for fall back to atomics into gradients the set-up kernel zeroed).
+//
+// Launches: with the forward's records, lists and layout still in the workspace (generation word; GF_RECORDS_VALID) the gradient
+// kernel and the row sums; otherwise the records pass and the set-up kernel ahead of them.
 //
 // Ranges.  dL is scaled per double brick and the semantics per Gaussian by powers of two (exact) so that the f16 operands
 // stay in range whatever the loss scale is; undone in fp64 when the row is written.
 //
 // The kernel applies where the forward's matrix-core kernel does (dense exact lattice, theta in range: word 1 of the
-// forward's state block says a matrix-core body rendered the call) and to rows of <= kWRow bitmask words.
+// forward's state block says a matrix-core body rendered the call) and to rows of <= kWRow bitmask words (P <= 39 552).
 #include <algorithm>
 
 #include <stdlib.h>
