@@ -458,3 +458,60 @@ def test_backward_rows_of_whole_grid_gaussians_and_of_a_full_buffer(gpu, case):
         for a, b in zip(got, ref):
             assert np.isfinite(a).all()
             assert np.abs(a - b.reshape(a.shape)).max() <= 2e-4 * max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.gpu
+def test_backward_when_a_supertile_has_more_candidates_than_a_published_list_holds(gpu):
+    """GF_PREPARE_BACKWARD publishes every supertile's candidate list for the backward -- up to 256 entries.  Two thousand small
+    Gaussians inside one 8 x 8 column patch: that supertile's list does not fit, the forward raises the "not published" word (the
+    rows still fit, so the state block says "prepared"), and the backward scans the bitmask rows itself -- same gradients as
+    without any preparation, and as the oracle's."""
+    from gaussianformer_amd import _lib
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=25, P=2000, H=40, W=40, D=16)
+    rng = np.random.default_rng(26)
+    lo = np.asarray(si.pc_min, dtype=np.float64)
+    # (cells 16..23 x 16..23: one supertile; all heights)
+    si.means3D[:-1, 0] = (lo[0] + (16 + 8 * rng.random(2000)) * si.grid_size).astype(np.float32)
+    si.means3D[:-1, 1] = (lo[1] + (16 + 8 * rng.random(2000)) * si.grid_size).astype(np.float32)
+    pi, mi, radii, cov6 = prep(si)
+    g = np.random.default_rng(27).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
+    ref = oracle.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D, g)
+    _, t, state0, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    plain = _bwd(gpu, si, t, state0, g)
+    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_PREPARE_BACKWARD)
+    words = state.view(torch.int32)[:5].tolist()
+    assert words[1] == _lib.GF_PATH_MATRIX_CORE_WAVE and (words[4] & 1) == 1
+    got = _bwd(gpu, si, t, state, g, flags=_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID)
+    for a, b, c in zip(got, plain, ref):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+        assert np.abs(a - c.reshape(a.shape)).max() <= 2e-4 * max(np.abs(c).max(), 1e-30)
+
+
+@pytest.mark.gpu
+def test_module_training_steps_with_two_aggregators_sharing_the_stream(gpu):
+    """A few "training steps" through the autograd module, with a second aggregator call of another shape between a forward and its
+    backward (it is handed the same workspace): the module's bookkeeping (workspace stamps, state words on the host) must pass
+    GF_RECORDS_VALID only when nobody else used the workspace -- checked through the results, which have to match the exact
+    module in every step either way."""
+    from gaussianformer_amd.local_aggregate import LocalAggregator
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)[None]
+    cfg = dict(P=500, H=32, W=24, D=16)
+    other = make_splat_inputs("nuscenes_gs25600_solid", seed=40, P=300, H=16, W=16, D=8)
+    m_other = LocalAggregator(other.scale_multiplier, other.H, other.W, other.D, list(other.pc_min), other.grid_size).to(gpu)
+    for step in range(4):
+        si = make_splat_inputs("nuscenes_gs25600_solid", seed=41 + step, **cfg)
+        mods = [LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size, matrix_cores=mc).to(gpu)
+                for mc in (False, True)]
+        grads = []
+        for k, m in enumerate(mods):
+            leaves = [t(a).requires_grad_(True) for a in (si.means3D, si.opacities, si.semantics, si.cov3D)]
+            out = m(t(si.pts), leaves[0], leaves[1], leaves[2], t(si.scales), leaves[3])
+            if k == 1 and step % 2 == 1:   # someone else takes the stream's workspace between this forward and its backward
+                with torch.no_grad():
+                    m_other(t(other.pts), t(other.means3D), t(other.opacities), t(other.semantics), t(other.scales), t(other.cov3D))
+            g = torch.Generator(device="cpu").manual_seed(50 + step)
+            out.backward(torch.randn(out.shape, generator=g).to(gpu))
+            grads.append([x.grad.clone() for x in leaves])
+        for a, b in zip(*grads):
+            assert torch.isfinite(b).all()
+            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
