@@ -18,7 +18,8 @@
 //   1. exponent   D'[v,g] = phi(u_v) . theta(g) + box term -- the forward's four v_mfma_f32_32x32x16_f16 with the operands
 //                 SWAPPED (A = monomials / one-hot coordinates of the voxels, B = split theta of the Gaussians), so that the
 //                 result has lane = Gaussian, register = voxel: the B-operand layout of a contraction over voxels;
-//   2. T'[v,g]    six v_mfma_f32_32x32x16_f16 (K = 18 channels in two chunks; hi hi + hi lo + lo hi): A = dL[v][c] from the staged
+//   2. T'[v,g]    four v_mfma_f32_32x32x16_f16 (K = 18 channels: 16 as hi hi + hi lo + lo hi, the last two with their three products
+//                 packed into one instruction): A = dL[v][c] from the staged
 //                 rows, B = sem[g][c], both scaled by powers of two and split into f16 hi + lo;
 //   3. e = exp2(D'), K = e T'; both split into f16 hi + lo in registers (they ARE B operands already);
 //   4. moments    M += Phi^T (K_hi + K_lo): 4 MFMAs;   dsem  += dL^T (e_hi + e_lo), dL split hi + lo: 6 MFMAs.
@@ -749,6 +750,9 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                             }
 #pragma unroll
                             for (int j = 1; j < 4; ++j) { b1h.p[j] = zz; b1l.p[j] = zz; }
+                            // chunk 1 holds two channels only: its three products (hi hi + hi lo + lo hi) share ONE MFMA -- K elements
+                            // (0,1) = hi hi, (2,3) = hi lo, (4,5) = lo hi; operands: A = (a_hi, a_hi, a_lo, 0), B = (b_hi, b_lo, b_hi, 0)
+                            b1h.p[1] = b1l.p[0]; b1h.p[2] = b1h.p[0];
                         }
                         // ---- B operands of the exponent: theta in fp64, three f16 terms (the forward's A operands)
                         H8 t1, t2, t3;
@@ -817,8 +821,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                                 for (int j = 2; j < 8; ++j) { a1h.e[j] = zero16; a1l.e[j] = zero16; }
                                 T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l.v, b0h.v, T, 0, 0, 0);
                                 T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h.v, b0l.v, T, 0, 0, 0);
-                                T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l.v, b1h.v, T, 0, 0, 0);
-                                T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h.v, b1l.v, T, 0, 0, 0);
+                                a1h.p[1] = a1h.p[0]; a1h.p[2] = a1l.p[0];
                                 T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h.v, b1h.v, T, 0, 0, 0);
                                 T = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h.v, b0h.v, T, 0, 0, 0);
                             }
