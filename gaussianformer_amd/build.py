@@ -42,7 +42,7 @@ def build(force=False, verbose=False, extra_flags=(), lib_name=None):
     tag = "" if lib_name is None else "." + os.path.splitext(lib_name)[0]
     objs = []
     common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-              "-Wall", "-Wno-unused-function", *extra_flags]
+              "-Wall", "-Wno-unused-function", "-Wno-inline-asm", *extra_flags]
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))

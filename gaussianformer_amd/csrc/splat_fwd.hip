@@ -1225,6 +1225,20 @@ __device__ __forceinline__ void split3(double t, _Float16 &a, _Float16 &b, _Floa
     c = (_Float16)(r - (float)b);
 }
 
+// LDS-DMA issued from inline asm.  hipcc's waitcnt pass treats a global_load_lds it can see as a pending write to ALL of LDS and puts a
+// full `s_waitcnt vmcnt(0)` in front of the next LDS access -- in the wave-autonomous kernel that drained the record request of
+// group k + 1 before group k's S' rows were read, and the prefetched bitmask row before the epilogue's staging writes: the very
+// round trips those requests were issued early to hide (found in the ISA, round 5).  Issued from asm the request is invisible
+// to that pass, and every wait for it is an explicit `s_waitcnt vmcnt(N)` in the source.  The compiler's own vmcnt waits stay
+// safe: they count outstanding operations, which only makes them wait longer when these requests are in flight.
+__device__ __forceinline__ void lds_dma16(const __attribute__((address_space(1))) void *g, __attribute__((address_space(3))) void *l)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"((uint32_t)(uintptr_t)l) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma4(const __attribute__((address_space(1))) void *g, __attribute__((address_space(3))) void *l)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"((uint32_t)(uintptr_t)l) : "memory", "m0");
+}
 template <bool LABELS>
 __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderArgs a)
 {
@@ -1361,12 +1375,12 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         char *dst = reinterpret_cast<char *>(slot);
         using gptr = const __attribute__((address_space(1))) void *;
         using lptr = __attribute__((address_space(3))) void *;
-        __builtin_amdgcn_global_load_lds((gptr)(rec), (lptr)(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + 16), (lptr)(dst + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + 32), (lptr)(dst + 2048), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + o3), (lptr)(dst + 3072), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + o4), (lptr)(dst + 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + o5), (lptr)(dst + 5120), 16, 0, 0);
+        lds_dma16((gptr)(rec), (lptr)(dst));
+        lds_dma16((gptr)(rec + 16), (lptr)(dst + 1024));
+        lds_dma16((gptr)(rec + 32), (lptr)(dst + 2048));
+        lds_dma16((gptr)(rec + o3), (lptr)(dst + 3072));
+        lds_dma16((gptr)(rec + o4), (lptr)(dst + 4096));
+        lds_dma16((gptr)(rec + o5), (lptr)(dst + 5120));
     };
     for (;;) {  // tiles of this workgroup
 #if GF_TIMELINE
@@ -1424,8 +1438,7 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
             const int npieces = (a.nwords + 127) >> 7;
             for (int i = wave; i < npieces; i += 4) {
                 const int w0 = min(128 * i + 2 * lane, a.nrow - 2);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bm + w0),
-                                                 (__attribute__((address_space(3))) void *)(s_row + 128 * i), 16, 0, 0);
+                lds_dma16((const __attribute__((address_space(1))) void *)(bm + w0), (__attribute__((address_space(3))) void *)(s_row + 128 * i));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1532,8 +1545,8 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
                 const uint32_t id = s_lg[min(b0 + lane, list_len - 1)];
                 using gptr = const __attribute__((address_space(1))) void *;
                 using lptr = __attribute__((address_space(3))) void *;
-                __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0), 4, 0, 0);
+                lds_dma4((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0));
+                lds_dma4((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1881,7 +1894,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 const unsigned long long *bm0 = a.bitmask + (size_t)s0 * a.nrow;
                 for (int i = 0; 128 * i < a.nrow; ++i)
                     if (128 * i + 2 * lane < a.nrow)
-                        __builtin_amdgcn_global_load_lds((gptr)(bm0 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
+                        lds_dma16((gptr)(bm0 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
                 row_there = true;
             }
         }
@@ -1958,12 +1971,12 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
         const char *rec = reinterpret_cast<const char *>(a.records + (size_t)id * kRecDwords);
         const int o3 = (3 + 3 * h) * 16, o4 = (4 + 3 * h) * 16, o5 = (h ? 7 : 5) * 16;
         char *dst = reinterpret_cast<char *>(slot);
-        __builtin_amdgcn_global_load_lds((gptr)(rec), (lptr)(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + 16), (lptr)(dst + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + 32), (lptr)(dst + 2048), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + o3), (lptr)(dst + 3072), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + o4), (lptr)(dst + 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)(rec + o5), (lptr)(dst + 5120), 16, 0, 0);
+        lds_dma16((gptr)(rec), (lptr)(dst));
+        lds_dma16((gptr)(rec + 16), (lptr)(dst + 1024));
+        lds_dma16((gptr)(rec + 32), (lptr)(dst + 2048));
+        lds_dma16((gptr)(rec + o3), (lptr)(dst + 3072));
+        lds_dma16((gptr)(rec + o4), (lptr)(dst + 4096));
+        lds_dma16((gptr)(rec + o5), (lptr)(dst + 5120));
     };
 
     uint32_t *ctr = a.tile_counters + 64 * xcd;
@@ -1994,7 +2007,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             if (!row_there)
                 for (int i = 0; 128 * i < a.nrow; ++i)   // (rows are padded to an even word count)
                     if (128 * i + 2 * lane < a.nrow)
-                        __builtin_amdgcn_global_load_lds((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
+                        lds_dma16((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
             f32x16 acc[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
@@ -2183,8 +2196,8 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 // ---- the packed boxes of the listed Gaussians, by LDS-DMA (two 4-byte pieces per entry, gathered by id)
                 for (int b0 = 0; b0 < list_len; b0 += 64) {
                     const uint32_t id = s_lg[min(b0 + lane, list_len - 1)];
-                    __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0), 4, 0, 0);
+                    lds_dma4((gptr)(&a.boxes[id].x), (lptr)(s_blo + b0));
+                    lds_dma4((gptr)(&a.boxes[id].y), (lptr)(s_bhi + b0));
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // GF_PREPARE_BACKWARD: quarter 0 / brick 0 of every supertile leaves the supertile's candidate list (ids and packed
@@ -2367,7 +2380,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                         const unsigned long long *bm2 = a.bitmask + (size_t)s2 * a.nrow;
                         for (int i = 0; 128 * i < a.nrow; ++i)
                             if (128 * i + 2 * lane < a.nrow)
-                                __builtin_amdgcn_global_load_lds((gptr)(bm2 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i), 16, 0, 0);
+                                lds_dma16((gptr)(bm2 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
                         next_row = true;
                     }
                 }
