@@ -222,6 +222,7 @@ def main():
             names = {_lib.GF_PATH_EXACT_TILE: "gf_splat_render_kernel (exact-fp32 tile kernel)",
                      _lib.GF_PATH_MATRIX_CORE: "gf_splat_render_mfma_kernel (split-f16 MFMA, fp32 accumulate; one workgroup per tile)",
                      _lib.GF_PATH_MATRIX_CORE_WAVE: "gf_splat_render_mfma_wave_kernel (split-f16 MFMA, fp32 accumulate; one wave per double brick)",
+                     _lib.GF_PATH_MATRIX_CORE_PAIR: "gf_splat_render_mfma_pair_kernel (split-f16 MFMA, fp32 accumulate; two waves per double brick, one brick each)",
                      _lib.GF_PATH_ARBITRARY: "arbitrary-points body (FALL-BACK: a device verdict failed)"}
             return names.get(w[1], str(w[1])), w[2]
 
@@ -425,7 +426,7 @@ def main():
             logits, _, _, _, state = splat_forward(wl.variant, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
             torch.cuda.synchronize()
             words = state.view(torch.int32)[:5].tolist()
-            fast = words[0] == 0 and words[1] in (_lib.GF_PATH_MATRIX_CORE, _lib.GF_PATH_MATRIX_CORE_WAVE) and (words[4] & 1)
+            fast = words[0] == 0 and words[1] in _lib.GF_PATHS_MATRIX_CORE and (words[4] & 1)
             g = torch.randn(logits.shape, generator=torch.Generator().manual_seed(1)).to(dev)
             res = {}
             for name, flags in (("matrix_core", (_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if fast else 0), ("exact_fp32", _lib.GF_EXACT_FP32)):

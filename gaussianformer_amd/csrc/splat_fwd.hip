@@ -113,10 +113,12 @@ __device__ __forceinline__ uint32_t range_bits_of(const float *c, const float *s
     bool snan = false;
 #pragma unroll
     for (int j = 0; j < kC; ++j) {
-        const float v = fabsf(opa * sm[j]);
+        // (the pair kernel carries the opacity in the exponent and the RAW semantics as S': both magnitudes are bounded)
+        const float v = fmaxf(fabsf(opa * sm[j]), fabsf(sm[j]));
         snan |= !(v == v);
         smax = fmaxf(smax, v);
     }
+    snan |= !(opa >= 0.f);   // log2(opacity) in the exponent: a negative (or NaN) opacity takes the fall-back
     return ((!(bound < 3.0e4f) || !(Q < 1331.4f)) ? 4u : 0u) | ((snan || !(smax < kSemRangeMax)) ? 8u : 0u);
 }
 
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     if (a.gate_state) {
         // backward: the records of the forward that wrote this state block are still in the workspace (same generation) --
         // nothing to redo; or that forward was not rendered on the matrix cores -- the Gaussian-major kernels need no records
-        const bool mc = a.gate_state[0] == 0u && (a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE || a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE_WAVE);
+        const bool mc = a.gate_state[0] == 0u && (a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE || a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE_WAVE ||
+                                                  a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE_PAIR);
         if (!mc || (a.gate_state[3] == *a.gen_word && (a.gate_state[4] & 1u))) return;
     } else if (a.gen_word && blockIdx.x == 0 && threadIdx.x == 0) {
         *a.gen_word = *a.gen_word + 1u;   // (any start value will do: the word only has to change)
@@ -1206,6 +1209,7 @@ union H8 {
     h8 v;
     fp16x2 p[4];
     _Float16 e[8];
+    uint32_t u[4];
 };
 constexpr int kRowWords = 3072;  // bitmask row length up to which the matrix-core kernel's producer stages the whole row in LDS (P <= 196 608)
 constexpr int kListCapM = 2304;  // tile list entries of the matrix-core kernel: ids (4 B) + packed boxes (8 B) in LDS
@@ -2526,6 +2530,8 @@ static int mfma_wave_grid(int nunits)
     return 8 * std::min(per_xcd, std::max(1, 8 * cus / 8));
 }
 
+#include "splat_fwd_pair.inc"
+
 // ---------------------------------------------------------------------------------------
 struct BoxVolArgs {
     const int *means_int;
@@ -2577,12 +2583,23 @@ static bool mfma_by_wave(int nrow)
     return nrow <= kWRow && getenv("GF_MFMA_TILE") == nullptr;   // (read per call: a test runs both kernels in one process)
 }
 
+// ... and the pair kernel (round 5) wherever it applies: plain forward (no label epilogue, no backward preparation -- those stay
+// with the wave kernel), rows of <= kPRowMax words, depth a multiple of 4 (16-byte output pieces), ids that leave 12 mask bits.
+// GF_MFMA_WAVE / GF_MFMA_TILE in the environment keep the older kernels, for comparison.
+static bool mfma_by_pair(int nrow, int D, int P, bool labels, bool prepare_backward)
+{
+    return !labels && !prepare_backward && nrow <= kPRowMax && (D & 3) == 0 && P < (1 << 20) && getenv("GF_MFMA_TILE") == nullptr &&
+           getenv("GF_MFMA_WAVE") == nullptr;
+}
+
 static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stream)
 {
     hipEvent_t ev0, ev1;
     const bool prof = profile_slot(&ev0, &ev1);
     if (prof) (void)hipEventRecord(ev0, stream);
-    if (mfma_by_wave(r.nrow) && r.out_labels)
+    if (mfma_by_pair(r.nrow, r.D, r.P, r.out_labels != nullptr, r.rows_valid != 0u))
+        hipLaunchKernelGGL(gf_splat_render_mfma_pair_kernel, dim3(mfma_pair_grid(mfma_wave_units(nsuper, r.D), r.nrow)), dim3(128), pair_lds_bytes(r.nrow), stream, r);
+    else if (mfma_by_wave(r.nrow) && r.out_labels)
         hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<true>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
     else if (mfma_by_wave(r.nrow) && r.rows_valid)
         hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, true>), dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
@@ -2748,6 +2765,8 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.range_flags = mfma ? ws.range_flags : nullptr;
     pa.range_theta_here = (mfma && !verify) ? 1 : 0;   // (with the point scans running, their waves take the theta verdict)
     pa.tile_counter_init = !mfma ? 0u
+                           : mfma_by_pair(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr)
+                               ? (uint32_t)(mfma_pair_grid(mfma_wave_units(ws.nsuper, D), ws.nrow) / 8)
                            : mfma_by_wave(ws.nrow) ? (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8)
                                                    : (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8);
     const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);

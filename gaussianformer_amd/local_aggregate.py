@@ -347,7 +347,7 @@ class _LocalAggregate(torch.autograd.Function):
             bflags = _lib.GF_EXACT_FP32
         elif ctx.state_event is not None and ctx.state_event.query():
             words = ctx.state_host.tolist()
-            on_matrix_cores = words[0] == 0 and words[1] in (_lib.GF_PATH_MATRIX_CORE, _lib.GF_PATH_MATRIX_CORE_WAVE)
+            on_matrix_cores = words[0] == 0 and words[1] in _lib.GF_PATHS_MATRIX_CORE
             bflags = _lib.GF_MFMA_SPLAT if on_matrix_cores else _lib.GF_EXACT_FP32
             # the forward's records pass laid out the backward's rows as well (word 4); if nobody has been handed this stream's
             # workspace since, the backward does not repeat that pass

@@ -94,6 +94,7 @@ extern "C" {
 #define GF_PATH_EXACT_TILE 0     /* exact-fp32 tile kernel (dense grid) */
 #define GF_PATH_MATRIX_CORE 1    /* split-f16 MFMA kernel (dense exact lattice), one workgroup per tile: P > 39 552 */
 #define GF_PATH_MATRIX_CORE_WAVE 3 /* the same arithmetic (equal bits), one wave per double brick: P <= 39 552 */
+#define GF_PATH_MATRIX_CORE_PAIR 4 /* round 5: two waves per double brick, one brick each (opacity in the exponent); the default for rows of <= 1024 words */
 #define GF_PATH_ARBITRARY 2      /* arbitrary-points body (pts not the dense grid, or a failed lattice / range verdict) */
 
 int gf_abi_version(void);

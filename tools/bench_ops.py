@@ -57,7 +57,7 @@ for config in ("nuscenes_gs25600_solid", "nuscenes_gs144000", "prob_gs6400"):
     logits, bl, de, pr, state = splat_forward(variant, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
     torch.cuda.synchronize()
     words = state.view(torch.int32)[:5].tolist()
-    fast = words[0] == 0 and words[1] in (_lib.GF_PATH_MATRIX_CORE, _lib.GF_PATH_MATRIX_CORE_WAVE) and (words[4] & 1)
+    fast = words[0] == 0 and words[1] in _lib.GF_PATHS_MATRIX_CORE and (words[4] & 1)
     g = torch.randn(N, 18, device=dev)
     gb = torch.randn(N, device=dev) if variant else None
     sec = timed(lambda: splat_backward(variant, *t, si.H, si.W, si.D, g, fwd_outputs=(logits, bl, de, pr) if variant else None,
