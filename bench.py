@@ -223,6 +223,7 @@ def main():
                      _lib.GF_PATH_MATRIX_CORE: "gf_splat_render_mfma_kernel (split-f16 MFMA, fp32 accumulate; one workgroup per tile)",
                      _lib.GF_PATH_MATRIX_CORE_WAVE: "gf_splat_render_mfma_wave_kernel (split-f16 MFMA, fp32 accumulate; one wave per double brick)",
                      _lib.GF_PATH_MATRIX_CORE_PAIR: "gf_splat_render_mfma_pair_kernel (split-f16 MFMA, fp32 accumulate; two waves per double brick, one brick each)",
+                     _lib.GF_PATH_MATRIX_CORE_SOLO: "gf_splat_render_mfma_solo_kernel (split-f16 MFMA, fp32 accumulate; one wave per double brick, round-5 instruction diet)",
                      _lib.GF_PATH_ARBITRARY: "arbitrary-points body (FALL-BACK: a device verdict failed)"}
             return names.get(w[1], str(w[1])), w[2]
 

@@ -24,8 +24,9 @@ GF_MFMA_SPLAT = 128
 GF_EXACT_FP32 = 256
 GF_RECORDS_VALID = 512
 GF_PREPARE_BACKWARD = 1024
-GF_PATH_EXACT_TILE, GF_PATH_MATRIX_CORE, GF_PATH_ARBITRARY, GF_PATH_MATRIX_CORE_WAVE, GF_PATH_MATRIX_CORE_PAIR = 0, 1, 2, 3, 4
-GF_PATHS_MATRIX_CORE = (GF_PATH_MATRIX_CORE, GF_PATH_MATRIX_CORE_WAVE, GF_PATH_MATRIX_CORE_PAIR)
+GF_WORKSPACE_ZEROED = 2048
+GF_PATH_EXACT_TILE, GF_PATH_MATRIX_CORE, GF_PATH_ARBITRARY, GF_PATH_MATRIX_CORE_WAVE, GF_PATH_MATRIX_CORE_PAIR, GF_PATH_MATRIX_CORE_SOLO = 0, 1, 2, 3, 4, 5
+GF_PATHS_MATRIX_CORE = (GF_PATH_MATRIX_CORE, GF_PATH_MATRIX_CORE_WAVE, GF_PATH_MATRIX_CORE_PAIR, GF_PATH_MATRIX_CORE_SOLO)
 
 _vp, _i, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
 

@@ -21,6 +21,8 @@ constexpr int kBwdBigCap = 1024;     // ... waves of 64 Gaussians the layout wor
 constexpr int kBwdCounters = 5632;   // flag-section index of the matrix-core backward's per-XCD unit counters ([+ 64 x]; the forward's: 4608)
 constexpr int kBwdList = 256;       // candidate-list entries of the matrix-core backward (and of a list the forward publishes for it)
 constexpr int kListsBad = 8101;      // flag-section word: a supertile's list did not fit kBwdList (the backward then scans the bitmask rows itself)
+constexpr int kFusedCounters = 6144; // flag-section index of the fused forward's per-XCD counter blocks ([+ 128 x] dwords = 64 64-bit words each)
+constexpr int kFusedRowMax = 1024;   // bitmask row words up to which a workspace carries the fused forward's per-XCD copies
 constexpr int kGenWord = 8100;       // generation word of a workspace: index into its flag section -- the same word whatever the call's
                                      // shape; every launch that rewrites the records (or the sections they share with other shapes) bumps it
 
@@ -62,6 +64,10 @@ struct SplatWorkspace {
     uint32_t *bwd_list_len;    // [nsuper] ... its length
     float *bwd_rows;        // [bwd_cap][32] matrix-core backward: partial gradients per (Gaussian, double brick)
     uint32_t bwd_cap;       // rows available (0: the shape does not take the matrix-core backward)
+    float *x_records;       // [8][P][32] fused single-launch forward (round 5): every XCD's own copy of the records ...
+    uint2 *x_boxes;         // [8][P] ... of the packed boxes ...
+    unsigned long long *x_bitmask;  // [8][nsuper][nrow] ... and of the bitmask (each XCD fills the rows of its own supertiles); null: shape not taken
+    unsigned long long *x_flags;    // [8][2][kFusedRowMax] ... per XCD and pass, one "done" word per 64 Gaussians, tagged with the launch id
     int nwords, nrow, nsx, nsy, nsuper;
     size_t total_bytes;
 };
@@ -105,6 +111,13 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.bwd_lists = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? ws.nsuper : 0) * 3 * kBwdList * 4);
     ws.bwd_list_len = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? ws.nsuper : 0) * 4);
     ws.bwd_rows = (float *)(p + off); off += align256((size_t)ws.bwd_cap * kBwdRowDwords * 4);
+    {
+        const bool fused_ok = P > 0 && P < 65536 && ws.nrow <= kFusedRowMax;
+        ws.x_records = fused_ok ? (float *)(p + off) : nullptr; off += align256(fused_ok ? (size_t)8 * P * kRecDwords * 4 : 0);
+        ws.x_boxes = fused_ok ? (uint2 *)(p + off) : nullptr; off += align256(fused_ok ? (size_t)8 * P * 8 : 0);
+        ws.x_bitmask = fused_ok ? (unsigned long long *)(p + off) : nullptr; off += align256(fused_ok ? (size_t)8 * ws.nsuper * ws.nrow * 8 : 0);
+        ws.x_flags = fused_ok ? (unsigned long long *)(p + off) : nullptr; off += align256(fused_ok ? (size_t)8 * 2 * kFusedRowMax * 8 : 0);
+    }
     ws.total_bytes = off;
     return ws;
 }

@@ -67,7 +67,7 @@ __device__ __forceinline__ bool gated_off(const BwdArgs &a)
 {
     if (!a.gate || a.state == nullptr) return false;
     const uint32_t w = a.state[1];
-    return a.state[0] == 0u && (w == (uint32_t)GF_PATH_MATRIX_CORE || w == (uint32_t)GF_PATH_MATRIX_CORE_WAVE || w == (uint32_t)GF_PATH_MATRIX_CORE_PAIR);
+    return a.state[0] == 0u && (w == (uint32_t)GF_PATH_MATRIX_CORE || w == (uint32_t)GF_PATH_MATRIX_CORE_WAVE || w == (uint32_t)GF_PATH_MATRIX_CORE_PAIR || w == (uint32_t)GF_PATH_MATRIX_CORE_SOLO);
 }
 
 constexpr int kBwdMaxBlk = 1024;  // LDS prefix capacity: P <= 262 144 Gaussians

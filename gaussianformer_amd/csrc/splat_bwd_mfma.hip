@@ -138,7 +138,7 @@ __device__ __forceinline__ void split16(const f32x16 &d, H8 (&hi)[2], H8 (&lo)[2
 __device__ __forceinline__ bool state_is_matrix_core(const uint32_t *state)
 {
     const uint32_t w = state[1];
-    return state[0] == 0u && (w == (uint32_t)GF_PATH_MATRIX_CORE || w == (uint32_t)GF_PATH_MATRIX_CORE_WAVE || w == (uint32_t)GF_PATH_MATRIX_CORE_PAIR);
+    return state[0] == 0u && (w == (uint32_t)GF_PATH_MATRIX_CORE || w == (uint32_t)GF_PATH_MATRIX_CORE_WAVE || w == (uint32_t)GF_PATH_MATRIX_CORE_PAIR || w == (uint32_t)GF_PATH_MATRIX_CORE_SOLO);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -28,11 +28,16 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 
 #include "gf_common.hpp"
 
 #ifndef GF_TIMELINE
 #define GF_TIMELINE 0  // -DGF_TIMELINE=1: per-workgroup timestamps of the render kernel (tools/timeline.py)
+#endif
+#ifndef GF_X
+#define GF_X 0   // development: timing experiments in the solo kernel (tools/xbuild.sh); 0 in the product
 #endif
 
 namespace gf {
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         // backward: the records of the forward that wrote this state block are still in the workspace (same generation) --
         // nothing to redo; or that forward was not rendered on the matrix cores -- the Gaussian-major kernels need no records
         const bool mc = a.gate_state[0] == 0u && (a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE || a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE_WAVE ||
-                                                  a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE_PAIR);
+                                                  a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE_PAIR || a.gate_state[1] == (uint32_t)GF_PATH_MATRIX_CORE_SOLO);
         if (!mc || (a.gate_state[3] == *a.gen_word && (a.gate_state[4] & 1u))) return;
     } else if (a.gen_word && blockIdx.x == 0 && threadIdx.x == 0) {
         *a.gen_word = *a.gen_word + 1u;   // (any start value will do: the word only has to change)
@@ -2531,6 +2536,7 @@ static int mfma_wave_grid(int nunits)
 }
 
 #include "splat_fwd_pair.inc"
+#include "splat_fwd_solo.inc"
 
 // ---------------------------------------------------------------------------------------
 struct BoxVolArgs {
@@ -2586,18 +2592,30 @@ static bool mfma_by_wave(int nrow)
 // ... and the pair kernel (round 5) wherever it applies: plain forward (no label epilogue, no backward preparation -- those stay
 // with the wave kernel), rows of <= kPRowMax words, depth a multiple of 4 (16-byte output pieces), ids that leave 12 mask bits.
 // GF_MFMA_WAVE / GF_MFMA_TILE in the environment keep the older kernels, for comparison.
-static bool mfma_by_pair(int nrow, int D, int P, bool labels, bool prepare_backward)
+// kind of the forward's matrix-core kernel for a call: 0 tile, 1 wave (round 3), 2 pair, 3 solo (round 5).  The round-5 kernels take
+// plain forwards only (no label epilogue, no backward preparation), rows of <= kPRowMax words, a depth that is a multiple of 4
+// (16-byte output pieces) and ids that leave room for the box mask beside them.  GF_MFMA_SOLO / GF_MFMA_PAIR in the environment
+// select them (read per call: tests run several kernels in one process); GF_MFMA_TILE keeps the tile kernel.
+static int mfma_kind(int nrow, int D, int P, bool labels, bool prepare_backward)
 {
-    return !labels && !prepare_backward && nrow <= kPRowMax && (D & 3) == 0 && P < (1 << 20) && getenv("GF_MFMA_TILE") == nullptr &&
-           getenv("GF_MFMA_WAVE") == nullptr;
+    const bool plain = !labels && !prepare_backward && nrow <= kPRowMax && (D & 3) == 0 && getenv("GF_MFMA_TILE") == nullptr;
+    if (plain && getenv("GF_MFMA_PAIR") != nullptr && P < (1 << 20)) return 2;
+    if (plain && getenv("GF_MFMA_SOLO") != nullptr && P < (1 << 16)) return 3;
+    return mfma_by_wave(nrow) ? 1 : 0;
 }
+static int solo_waves() { const char *e = getenv("GF_SOLO_WAVES"); return e && e[0] == '3' ? 3 : 2; }
 
 static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stream)
 {
     hipEvent_t ev0, ev1;
     const bool prof = profile_slot(&ev0, &ev1);
     if (prof) (void)hipEventRecord(ev0, stream);
-    if (mfma_by_pair(r.nrow, r.D, r.P, r.out_labels != nullptr, r.rows_valid != 0u))
+    const int kind = mfma_kind(r.nrow, r.D, r.P, r.out_labels != nullptr, r.rows_valid != 0u);
+    if (kind == 3 && solo_waves() == 3)
+        hipLaunchKernelGGL((gf_splat_render_mfma_solo_kernel<3, false>), dim3(mfma_solo_grid<3>(mfma_wave_units(nsuper, r.D), r.nrow)), dim3(64), solo_lds_bytes(r.nrow), stream, r, FusedArgs{});
+    else if (kind == 3)
+        hipLaunchKernelGGL((gf_splat_render_mfma_solo_kernel<2, false>), dim3(mfma_solo_grid<2>(mfma_wave_units(nsuper, r.D), r.nrow)), dim3(64), solo_lds_bytes(r.nrow), stream, r, FusedArgs{});
+    else if (kind == 2)
         hipLaunchKernelGGL(gf_splat_render_mfma_pair_kernel, dim3(mfma_pair_grid(mfma_wave_units(nsuper, r.D), r.nrow)), dim3(128), pair_lds_bytes(r.nrow), stream, r);
     else if (mfma_by_wave(r.nrow) && r.out_labels)
         hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<true>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
@@ -2693,6 +2711,39 @@ extern "C" size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D)
 extern "C" size_t gf_splat_state_bytes(void) { return 256; }
 
 namespace gf {
+__global__ void gf_xcc_census_kernel(uint32_t *out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (uint32_t)physical_xcc();
+}
+// One-time check of what the fused forward's work partition relies on for COVERAGE (not for coherence): workgroup b runs on XCD
+// b % 8, so every XCD receives waves of any grid that is a multiple of 8.  HIP does not promise it; a device where the census
+// fails keeps the two-launch forward.  (Synchronises once, at the first call that could fuse.)
+static bool xcc_census_ok()
+{
+    static int state = 0;   // 0 unknown, 1 ok, -1 not ok
+    if (state == 0) {
+        state = -1;
+        uint32_t *d = nullptr;
+        constexpr int kBlocks = 256;
+        if (hipMalloc(&d, kBlocks * sizeof(uint32_t)) == hipSuccess) {
+            uint32_t h[kBlocks];
+            hipLaunchKernelGGL(gf_xcc_census_kernel, dim3(kBlocks), dim3(64), 0, 0, d);
+            if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                bool ok = true;
+                for (int b = 0; b < kBlocks; ++b) ok = ok && h[b] == (uint32_t)(b & 7);
+                state = ok ? 1 : -1;
+            }
+            (void)hipFree(d);
+        }
+    }
+    return state == 1;
+}
+static bool stream_is_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) return true;   // (be conservative)
+    return st != hipStreamCaptureStatusNone;
+}
 struct LabelOpts {
     long long *labels;  // null: plain forward
     int mode, empty_label;
@@ -2765,11 +2816,24 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.range_flags = mfma ? ws.range_flags : nullptr;
     pa.range_theta_here = (mfma && !verify) ? 1 : 0;   // (with the point scans running, their waves take the theta verdict)
     pa.tile_counter_init = !mfma ? 0u
-                           : mfma_by_pair(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr)
+                           : mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr) == 3
+                               ? (uint32_t)((solo_waves() == 3 ? mfma_solo_grid<3>(mfma_wave_units(ws.nsuper, D), ws.nrow)
+                                                               : mfma_solo_grid<2>(mfma_wave_units(ws.nsuper, D), ws.nrow)) / 8)
+                           : mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr) == 2
                                ? (uint32_t)(mfma_pair_grid(mfma_wave_units(ws.nsuper, D), ws.nrow) / 8)
                            : mfma_by_wave(ws.nrow) ? (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8)
                                                    : (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8);
-    const int prep_grid = pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
+    // The fused single-launch forward (splat_fwd_solo.inc, FusedArgs): plain base forward on a grid the caller vouches for, a
+    // workspace whose flag section was zeroed once, a shape the solo kernel takes, not under stream capture (a replayed launch would
+    // repeat its launch id), and a device whose workgroup -> XCD placement passed the one-time census.
+    // MEASURED AND NOT THE DEFAULT (GF_FUSED=1 in the environment selects it): correct, bit-identical to the
+    // two-launch solo kernel, but 57 against 43.5 us per step -- eight XCDs each reading and writing the whole record set land their
+    // first inputs at 8 us and hand off at 15 us, later than the separate records pass finishes.
+    const bool fused = mfma && !verify && (flags & GF_WORKSPACE_ZEROED) && ws.x_records != nullptr && getenv("GF_FUSED") != nullptr &&
+                       getenv("GF_MFMA_PAIR") == nullptr && getenv("GF_MFMA_TILE") == nullptr && getenv("GF_MFMA_WAVE") == nullptr &&
+                       !lab.labels && pa.unit_totals == nullptr && ws.nrow <= kPRowMax && (D & 3) == 0 && P < (1 << 16) &&
+                       !stream_is_capturing(stream) && xcc_census_ok();
+    const int prep_grid = fused ? 0 : pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
                                 (prep_waves > 1 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
@@ -2795,7 +2859,26 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.rows_valid = pa.unit_totals ? 1u : 0u;
     ra.unit_totals = ws.bwd_wave_total; ra.unit_local = ws.bwd_row_local; ra.unit_first = ws.bwd_row_first; ra.unit_cap = ws.bwd_cap;
     ra.pub_lists = ws.bwd_lists; ra.pub_len = ws.bwd_list_len;
-    if (mfma)
+    if (fused) {
+        // (unique per launch; the low 32 bits count from 1 -- the unit counters' tags must grow --, the bits above are a per-process
+        // salt, so that item flags a previous process left in recycled device memory cannot pass for this launch's)
+        static std::atomic<unsigned long long> launch_id{((unsigned long long)(std::chrono::steady_clock::now().time_since_epoch().count() & 0xFFFFFF) << 32) | 1ull};
+        FusedArgs fa;
+        fa.means3D = means3D; fa.means_int = means3D_int; fa.opacity = opacity; fa.semantics = semantics; fa.radii = radii; fa.cov3D = cov3D;
+        fa.x_records = ws.x_records; fa.x_boxes = ws.x_boxes; fa.x_bitmask = ws.x_bitmask; fa.x_flags = ws.x_flags;
+        fa.ctrs = reinterpret_cast<unsigned long long *>(ws.flags + kFusedCounters);
+        fa.gen_word = ws.flags + kGenWord;
+        fa.launch_id = launch_id.fetch_add(1ull) & 0x00FFFFFFFFFFFFFFull;
+        fa.per_axis = radii_per_axis ? 1 : 0;
+        ra.range_flags = nullptr; ra.verify_dense = 0;
+        hipEvent_t ev0, ev1;
+        const bool prof = profile_slot(&ev0, &ev1);
+        if (prof) (void)hipEventRecord(ev0, stream);
+        const int nunits = mfma_wave_units(ws.nsuper, D);
+        // (two waves per SIMD: the records pass stages through 20 KB of LDS per wave, eight waves per CU)
+        hipLaunchKernelGGL((gf_splat_render_mfma_solo_kernel<2, true>), dim3(mfma_solo_grid<2>(nunits, ws.nrow, true)), dim3(64), solo_lds_bytes(ws.nrow, true), stream, ra, fa);
+        if (prof) (void)hipEventRecord(ev1, stream);
+    } else if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);
     else if (variant == GF_SPLAT_BASE)
         launch_render_exp<GF_SPLAT_BASE>(flags, dense_candidate, ra, stream);

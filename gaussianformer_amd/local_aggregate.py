@@ -32,7 +32,7 @@ class _Workspace:
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = cls._cache.pop(key, None)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)   # (zeroed once: GF_WORKSPACE_ZEROED)
         cls._cache[key] = buf              # most recently used last
         while len(cls._cache) > cls.MAX_STREAMS:
             cls._cache.pop(next(iter(cls._cache)))
@@ -130,7 +130,7 @@ def splat_forward(variant, pts, points_int, means3D, means3D_int, opacities, sem
     ws = _Workspace.get(dev, nbytes)
     with torch.cuda.device(dev):
         rc = lib.gf_splat_forward(
-            variant, per_axis, flags, P, N, C, H, W, D,
+            variant, per_axis, flags | _lib.GF_WORKSPACE_ZEROED, P, N, C, H, W, D,
             _lib.ptr(pts), _lib.ptr(points_int), _lib.ptr(means3D), _lib.ptr(means3D_int), _lib.ptr(opacities),
             _lib.ptr(semantics), _lib.ptr(radii), _lib.ptr(cov3D),
             _lib.ptr(logits), _lib.ptr(bin_logits), _lib.ptr(density), _lib.ptr(probability), _lib.ptr(state),
@@ -196,8 +196,9 @@ class SplatForwardPlan:
         self.density = torch.empty(N, dtype=f32, device=self.device) if prob else None
         self.probability = torch.empty(N, dtype=f32, device=self.device) if prob else None
         self.state = torch.empty(self.lib.gf_splat_state_bytes(), dtype=torch.uint8, device=self.device)
-        self.workspace = torch.empty(self.lib.gf_splat_workspace_bytes(P, N, H, W, D), dtype=torch.uint8,
-                                     device=self.device)
+        self.workspace = torch.zeros(self.lib.gf_splat_workspace_bytes(P, N, H, W, D), dtype=torch.uint8,
+                                     device=self.device)   # (zeroed once: GF_WORKSPACE_ZEROED)
+        flags |= _lib.GF_WORKSPACE_ZEROED
         self.args = [variant, int(radii.dim() == 2), flags, P, N, C, H, W, D,
                      *[_lib.ptr(t) for t in self.inputs],
                      _lib.ptr(self.logits), _lib.ptr(self.bin_logits), _lib.ptr(self.density),

@@ -89,12 +89,18 @@ extern "C" {
  * the backward prepares everything itself.  Word 4 of the state block, bit 0: the layout is there and every row fits the
  * buffer.  Ignored where the matrix-core backward does not apply. */
 #define GF_PREPARE_BACKWARD 1024
+/* The caller promises that the workspace's first 32 KB (its flag section) were zero when the workspace was first handed to the
+ * library (e.g. allocated with hipMemset / torch.zeros) and have since only been written by the library.  With this flag and
+ * GF_PTS_ASSUME_DENSE a plain base forward on the matrix cores runs as ONE launch (records pass and render fused, round 5): its
+ * device-side counters are tagged by launch and need that one-time zero.  Without the flag nothing changes. */
+#define GF_WORKSPACE_ZEROED 2048
 
 /* values of word 1 of the state block after gf_splat_forward: which body rendered the call */
 #define GF_PATH_EXACT_TILE 0     /* exact-fp32 tile kernel (dense grid) */
 #define GF_PATH_MATRIX_CORE 1    /* split-f16 MFMA kernel (dense exact lattice), one workgroup per tile: P > 39 552 */
 #define GF_PATH_MATRIX_CORE_WAVE 3 /* the same arithmetic (equal bits), one wave per double brick: P <= 39 552 */
 #define GF_PATH_MATRIX_CORE_PAIR 4 /* round 5: two waves per double brick, one brick each (opacity in the exponent); the default for rows of <= 1024 words */
+#define GF_PATH_MATRIX_CORE_SOLO 5 /* round 5: one wave per double brick again, with the instruction diet (mask table, transposed semantics gather, opacity in the exponent): the default */
 #define GF_PATH_ARBITRARY 2      /* arbitrary-points body (pts not the dense grid, or a failed lattice / range verdict) */
 
 int gf_abi_version(void);

@@ -22,10 +22,12 @@ configs = args or ["nuscenes_gs25600_solid"]
 
 
 def run(si, flags, env=None, steps=0):
-    for k in ("GF_MFMA_WAVE", "GF_MFMA_TILE"):
+    for k in ("GF_MFMA_SOLO", "GF_MFMA_TILE", "GF_MFMA_PAIR", "GF_SOLO_WAVES", "GF_NO_FUSED"):
         os.environ.pop(k, None)
     if env:
-        os.environ[env] = "1"
+        for e in env.split(","):
+            k, _, v = e.partition("=")
+            os.environ[k] = v or "1"
     pi, mi, radii, cov6 = prep(si)
     t = to_dev(dev, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
     plan = SplatForwardPlan(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=flags)
@@ -65,18 +67,18 @@ if small:
 for config, kw in cases:
     si = make_splat_inputs(config, seed=kw.pop("seed", 0), **kw)
     steps = 200 if not kw else 0
-    o_pair, w_pair, t_pair, r_pair = run(si, 0, None, steps)
-    o_wave, w_wave, t_wave, r_wave = run(si, 0, "GF_MFMA_WAVE", steps)
-    o_ex, w_ex, t_ex, _ = run(si, _lib.GF_EXACT_FP32, None, 0)
-    print(f"{config} P={si.means3D.shape[0]} grid {si.H}x{si.W}x{si.D}: paths pair {w_pair} wave {w_wave} exact {w_ex}; "
-          f"reproducible pair {r_pair} wave {r_wave}; us/step pair {t_pair} wave {t_wave}", flush=True)
-    print(f"   pair vs wave (scaled, abs) {err(o_pair, o_wave)}; pair vs exact {err(o_pair, o_ex)}; wave vs exact {err(o_wave, o_ex)}; "
-          f"finite {bool(torch.isfinite(o_pair).all())}", flush=True)
+    res = {}
+    for name, flags, env in (("fused", 1, None), ("fused3", 1, "GF_SOLO_WAVES=3"), ("solo", 0, "GF_MFMA_SOLO"), ("solo3", 0, "GF_MFMA_SOLO,GF_SOLO_WAVES=3"), ("wave", 0, None), ("wave_dense", 1, "GF_NO_FUSED"), ("exact", _lib.GF_EXACT_FP32, None)):
+        res[name] = run(si, flags, env, steps if name != "exact" else 0)
+    print(f"{config} P={si.means3D.shape[0]} grid {si.H}x{si.W}x{si.D}: " + "; ".join(f"{k} path {v[1][1]} bits {v[1][2]:#x} repro {v[3]}" + (f" {v[2]:.2f} us" if v[2] else "") for k, v in res.items()), flush=True)
+    ex = res["exact"][0]
+    print("   vs exact (scaled, abs): " + "; ".join(f"{k} ({err(v[0], ex)[0]:.2e}, {err(v[0], ex)[1]:.2e})" for k, v in res.items() if k != "exact") +
+          f"; solo3 == solo {bool(torch.equal(res['solo'][0], res['solo3'][0]))}; finite {bool(torch.isfinite(res['solo'][0]).all())}", flush=True)
     if not kw:
         try:
             from oracle import ref
             pi, mi, radii, cov6 = prep(si)
             r = torch.from_numpy(ref.splat_forward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D)["logits"])
-            print(f"   vs oracle/_ref (scaled, abs): pair {err(o_pair.cpu(), r)} wave {err(o_wave.cpu(), r)} exact {err(o_ex.cpu(), r)}", flush=True)
+            print("   vs oracle/_ref (scaled, abs): " + "; ".join(f"{k} ({err(v[0].cpu(), r)[0]:.2e}, {err(v[0].cpu(), r)[1]:.2e})" for k, v in res.items()), flush=True)
         except Exception as exc:
             print("   no oracle/_ref:", exc)
