@@ -136,6 +136,21 @@ def main():
                          "otherwise mix the extras' launches into the headline's)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): re-exec under torch.distributed.run, one
+    # rank per GPU -- the same command line the driver uses for N > 1; rank 0 of the child prints the one JSON line (VERDICT r4:
+    # this form used to warn and measure ONE GPU, reporting n_gpus 1).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
     import oracle  # checker side only: host pre-processing restatement + cpu_baseline legs
@@ -260,14 +275,20 @@ def main():
 
     # ---- headline: exactly K steps, nothing else on the stream (no event records: a hipEvent pair costs ~3 us of
     # stream time, which at --steps 20 used to bracket every timed launch)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    # The loop is run LOOPS times (each: barrier + synchronize, exactly K steps, synchronize + barrier, max over ranks); the line
+    # reports the MEDIAN loop and, in `timing`, every loop's time (a single 0.9 ms sample said nothing about spread).
+    LOOPS = 5
+    loop_s = []
+    for _ in range(LOOPS):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        loop_s.append(max_over_ranks(time.perf_counter() - t0))
+    elapsed = sorted(loop_s)[LOOPS // 2]
 
     # ---- the dominant kernel, timed live in a SEPARATE loop after the headline: hipEvents around every launch of
     # KERNEL_SAMPLES further steps of the same workload, on the stream the kernel is launched on
@@ -338,6 +359,7 @@ def main():
             ref_out = wl.plan.run(wl.stream).clone()
             got = plan.run(wl.stream)
             err = float(((got - ref_out).abs() / got.abs().clamp(min=1.0)).max())
+            err_abs = float((got - ref_out).abs().max())
             for _ in range(max(2, args.warmup // 2)):
                 plan.run(wl.stream)
             torch.cuda.synchronize()
@@ -347,7 +369,8 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t4
             return {"value": P / (dt / args.steps), "unit": "Gaussians/s", "ms_per_step": dt / args.steps * 1e3,
-                    "max_scaled_diff_of_the_default_kernel": err,
+                    "max_scaled_diff_of_the_default_kernel": err, "max_abs_diff_of_the_default_kernel": err_abs,
+                    "max_abs_logit": float(got.abs().max()),
                     "note": "same K steps with GF_EXACT_FP32: the exact-fp32 VALU tile kernel (2e-6 from the reference)"}
 
         def frames():
@@ -624,6 +647,8 @@ def main():
             "metric": headline_metric(),
             "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "timing": {"loops": LOOPS, "reported": "median loop", "ms_per_step_of_each_loop": [t / args.steps * 1e3 for t in loop_s],
+                       "min": min(loop_s) / args.steps * 1e3, "max": max(loop_s) / args.steps * 1e3},
             "dtype": "f32",
             # what the arithmetic of the kernel that ran is (inputs, outputs and accumulators are fp32 in every case)
             "arithmetic": ("split-f16 operands (hi + lo) on v_mfma_f32_32x32x16_f16, fp32 accumulate; exponent coefficients "

@@ -78,6 +78,8 @@ struct BwdMArgs {
     int gate;                    // 1: run only if the forward's state says "matrix cores" (2: the set-up kernel wrote NaN gradients otherwise)
     int records_asserted;        // 1: no records pass ran -- stand down unless the workspace still holds the forward's (generation)
     unsigned long long *timeline;  // debug (GF_TIMELINE builds): 8 stamps per unit
+    uint32_t cap;                // rows in `rows`: a row index beyond it is never written (defence in depth: a first row read from a layout
+                                 // that was not completed would otherwise be an out-of-bounds store)
 };
 
 static_assert(kBwdList == 256, "kMList");
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                             const int nby = ((uy(ghi) - 1) >> 2) - by0 + 1, nbz = ((uz(ghi) - 1) >> 3) - bz0 + 1;
                             const int nbx = ((ux(ghi) - 1) >> 2) - bx0 + 1;
                             const int idx = (((Xw >> 2) - bx0) * nby + ((Y0 >> 2) - by0)) * nbz + ((Zw >> 3) - bz0);
-                            const bool has_row = live && first != 0xFFFFFFFFu;
+                            const bool has_row = live && first != 0xFFFFFFFFu && (unsigned long long)first + (unsigned long long)(uint32_t)idx < (unsigned long long)a.cap;
                             if (has_row) {
                                 // SIX store instructions per group, whatever the lanes hold (the counted wait above relies on it):
                                 // two that both halves take part in, four of half 0
@@ -1196,6 +1198,7 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
     a.P = P; a.N = N; a.nwords = ws.nwords; a.nrow = ws.nrow; a.H = H; a.W = W; a.D = D; a.nsx = ws.nsx; a.nsy = ws.nsy;
     a.gate = gate ? 1 : 0; a.records_asserted = records_asserted;
     a.timeline = g_bwd_timeline;
+    a.cap = ws.bwd_cap;
     hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel, dim3(grid), dim3(64), 0, stream, a);
     BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, ws.bwd_row_first, gen_word,
                   ws.flags + kBwdCounters, state, (uint32_t)(grid / 8), P, gate, (P + 31) / 32, records_asserted};

@@ -1908,6 +1908,22 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             }
         }
     }
+    // the lattice constants (four scalar loads from pts, cold in every cache on a GF_PTS_ASSUME_DENSE call) are requested here, next to
+    // the verdict words, not after them: they used to be a round trip of their own between the verdict and the first unit
+    // (as VECTOR loads from a laundered pointer, so that they are waited for with the verdict words by one vmcnt: as scalar loads
+    // hipcc put each of the three conditional ones in a branch of its own with its own wait -- four cold round trips in a row)
+    float q0x, q0y, q0z, q1x, q1y, q1z;
+    {
+        const float *pp = a.pts;
+        asm volatile("" : "+v"(pp));
+        const size_t ix = a.H > 1 ? 3 * (size_t)a.W * a.D : 0, iy = a.W > 1 ? 3 * (size_t)a.D + 1 : 1, iz = a.D > 1 ? 3 + 2 : 2;
+        // (issued from asm: a compiler-visible load is sunk to its first use, below the verdict; waited for with the verdict words)
+        asm volatile("global_load_dword %0, %6, off\n\tglobal_load_dword %1, %6, off offset:4\n\tglobal_load_dword %2, %6, off offset:8\n\t"
+                     "global_load_dword %3, %7, off\n\tglobal_load_dword %4, %8, off\n\tglobal_load_dword %5, %9, off"
+                     : "=&v"(q0x), "=&v"(q0y), "=&v"(q0z), "=&v"(q1x), "=&v"(q1y), "=&v"(q1z)
+                     : "v"(pp), "v"(pp + ix), "v"(pp + iy), "v"(pp + iz)
+                     : "memory");
+    }
     // verdicts of the prep launch (see gf_splat_render_mfma_kernel): the point scans' (GF_PTS_AUTO) and the records pass's range
     // verdicts (every call, GF_PTS_ASSUME_DENSE included).  All loads first, then the ballots: ONE memory round trip.  (The range
     // words: three clamped 16-byte reads per lane cover the <= 618 + 4 words of the rows this kernel takes -- no loop: as a loop
@@ -1934,6 +1950,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
         verdict = (__builtin_amdgcn_ballot_w64((v & 1u) != 0u) ? 1 : 0) | (__builtin_amdgcn_ballot_w64((v & 2u) != 0u) ? 2 : 0) |
                   (__builtin_amdgcn_ballot_w64((rv & 4u) != 0u) ? 4 : 0) | (__builtin_amdgcn_ballot_w64((rv & 8u) != 0u) ? 8 : 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0x), "+v"(q0y), "+v"(q0z), "+v"(q1x), "+v"(q1y), "+v"(q1z)::"memory");   // (landed with the verdict words)
     uint32_t rows_ready = 0u;
     if (PREP && blockIdx.x < (unsigned)kRowLayoutBlocks && a.rows_valid && !verdict)   // (slot area of the LDS block: idle until the first list is built)
         rows_ready = finish_row_layout(a, s_u, lane) ? 1u : 0u;
@@ -1951,13 +1968,17 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     const int n = lane & 31, h = lane >> 5;
     for (int i = lane; i < (kC + 1) * kSRow; i += 64) S[i] = 0.f;
 
-    // lattice of the voxel centres (fp64): position of voxel index i along an axis = p0 + i * step
-    using cflt_t = const float __attribute__((address_space(4))) *;
-    cflt_t cp = (cflt_t)(uintptr_t)a.pts;
-    const double p0x = cp[0], p0y = cp[1], p0z = cp[2];
-    const double sx = a.H > 1 ? (double)cp[3 * (size_t)a.W * a.D] - p0x : 1.0;
-    const double sy = a.W > 1 ? (double)cp[3 * (size_t)a.D + 1] - p0y : 1.0;
-    const double sz = a.D > 1 ? (double)cp[3 + 2] - p0z : 1.0;
+    // lattice of the voxel centres (fp64): position of voxel index i along an axis = p0 + i * step (loaded at the top of the kernel)
+    q0x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q0x)));
+    q0y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q0y)));
+    q0z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q0z)));
+    q1x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q1x)));
+    q1y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q1y)));
+    q1z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q1z)));
+    const double p0x = q0x, p0y = q0y, p0z = q0z;
+    const double sx = a.H > 1 ? (double)q1x - p0x : 1.0;
+    const double sy = a.W > 1 ? (double)q1y - p0y : 1.0;
+    const double sz = a.D > 1 ? (double)q1z - p0z : 1.0;
 
     // B operands of the exponent MFMAs: monomials and one-hot coordinates of this lane's voxel in each of the four blocks
     h8 phi[4], hot[4];
@@ -2808,7 +2829,11 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     // GF_PREPARE_BACKWARD: the matrix-core backward's row layout rides along (a scan per wave of 64 Gaussians here, a prefix in
     // eight waves of the render kernel); a backward that finds the workspace untouched (generation word) then starts with its
     // gradient kernel
-    pa.unit_totals = (mfma && ws.bwd_cap > 0u && !lab.labels && (flags & GF_PREPARE_BACKWARD)) ? ws.bwd_wave_total : nullptr;
+    // (the layout is finished by workgroups 0 .. kRowLayoutBlocks - 1 of the render launch, finish_row_layout: a grid with fewer
+    // workgroups -- a few supertiles -- would leave Gaussians without their first row, so such a call prepares nothing and the
+    // backward lays its rows out itself)
+    const bool layout_ok = mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) >= kRowLayoutBlocks;
+    pa.unit_totals = (mfma && ws.bwd_cap > 0u && !lab.labels && (flags & GF_PREPARE_BACKWARD) && layout_ok) ? ws.bwd_wave_total : nullptr;
     pa.unit_local = ws.bwd_row_local; pa.bwd_counters = ws.flags + kBwdCounters;
     pa.bwd_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);   // (the backward kernel's grid is the forward's)
     pa.gen_word = ws.flags + kGenWord; pa.gate_state = nullptr;

@@ -106,6 +106,8 @@ __global__ __launch_bounds__(256) void gf_subm_grid_kernel(SubmArgs a)
 // K offsets along z (k = kxy*K + kz, x-major / z fastest like a [K,K,K] kernel tensor): the index
 // row is read once and the K neighbour cells are consecutive ints of the table.
 // FILL = false counts, FILL = true writes the pairs.
+constexpr int kSubmRelinkMax = 4096;   // points of one cell beyond which the rulebook refuses the input (see the count pass)
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
 {
@@ -138,10 +140,15 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
                 const int h = a.t.head[own];
                 int succ = 0x7fffffff;
                 bool smallest = true;
-                for (int j = h; j >= 0; j = a.t.next[j]) {
+                int steps = 0;
+                for (int j = h; j >= 0 && steps <= kSubmRelinkMax; j = a.t.next[j], ++steps) {
                     if (j > i && j < succ) succ = j;
                     smallest = smallest && j >= i;
                 }
+                // (every point of a cell walks the cell's whole list: O(L^2) dependent loads per cell.  The encoder's cells hold one
+                // or two points; a degenerate input with thousands of duplicates per cell is refused -- the same bit an overfull
+                // 16-bit count raises -- instead of turning the rulebook into billions of loads)
+                if (steps > kSubmRelinkMax) atomicOr(a.t.total + 1, 1ull);
                 a.t.next2[i] = succ == 0x7fffffff ? -1 : succ;
                 if (smallest) a.t.first2[h] = i;
             }

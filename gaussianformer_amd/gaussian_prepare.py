@@ -201,10 +201,13 @@ class GaussianArgs(nn.Module):
             opa_in = None if (origi_opa is None or origi_opa.numel() == 0) else origi_opa
             empty_host = None
             if self.with_emtpy:
-                if self._empty_host is None:   # the buffers are constants of the head: read once
-                    self._empty_host = [self.empty_mean.flatten().tolist(), self.empty_scale.flatten().tolist(),
-                                        self.empty_rot.flatten().tolist()]
-                empty_host = self._empty_host
+                # the buffers are constants of the head: read once -- and again when one of them has been assigned or written in
+                # place since (load_state_dict, .copy_(), .to(): storage pointer / version counter), ADVICE r4
+                key = tuple((t.data_ptr(), t._version) for t in (self.empty_mean, self.empty_scale, self.empty_rot))
+                if self._empty_host is None or self._empty_host[0] != key:
+                    self._empty_host = (key, [self.empty_mean.flatten().tolist(), self.empty_scale.flatten().tolist(),
+                                              self.empty_rot.flatten().tolist()])
+                empty_host = self._empty_host[1]
             means, scales, rotations, sem, origi_opa = _GaussianPack.apply(
                 means, scales, rotations, sem, opa_in, self.empty_scalar if self.with_emtpy else None, empty_host,
                 self.num_classes, kitti, self.with_emtpy, not self.with_emtpy, self.empty_label)

@@ -82,9 +82,11 @@ def cov_inverse(scales, quats):
 
 
 def make_splat_inputs(config="nuscenes_gs25600_solid", seed=0, P=None, H=None, W=None, D=None,
-                      dense_pts=True, N=None, C=18):
+                      dense_pts=True, N=None, C=18, clustered=False):
     """Synthetic splat inputs.  ``P``/``H``/``W``/``D`` override the config for small cases;
-    ``dense_pts=False`` draws ``N`` random query points instead of all voxel centres."""
+    ``dense_pts=False`` draws ``N`` random query points instead of all voxel centres; ``clustered=True`` draws the
+    centres as sigmoid(N(0, 1)) of the range per axis -- the lifter's initial anchors (model/lifter/gaussian_lifter.py:
+    28-33), denser towards the middle of the scene like real nuScenes Gaussians -- instead of uniformly."""
     cfg = SPLAT_CONFIGS[config]
     rng = np.random.default_rng(seed)
     H = H or GRID["H"]
@@ -94,7 +96,11 @@ def make_splat_inputs(config="nuscenes_gs25600_solid", seed=0, P=None, H=None, W
     P = cfg["P"] if P is None else P
     ext = np.array([H, W, D], dtype=np.float64) * gs
     lo = np.array(pc_min, dtype=np.float64)
-    means = (lo + (0.001 + 0.998 * rng.random((P, 3))) * ext).astype(np.float32)
+    if clustered:
+        u = 1.0 / (1.0 + np.exp(-rng.standard_normal((P, 3))))
+        means = (lo + np.clip(u, 0.001, 0.999) * ext).astype(np.float32)
+    else:
+        means = (lo + (0.001 + 0.998 * rng.random((P, 3))) * ext).astype(np.float32)
     smin, smax = cfg["scale_range"]
     scales = (smin + (smax - smin) * rng.random((P, 3))).astype(np.float32)
     quats = rng.standard_normal((P, 4))

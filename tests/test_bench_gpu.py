@@ -74,3 +74,18 @@ def test_bench_two_rank_strong_scaling_path(gpu):
         assert "error" not in sp, sp
         assert sp["check_bit_identical_to_single_device"] is True      # no reduction: the gathered grid IS the single-GPU grid
         assert sp["splat_only"]["ms_per_step"] <= sp["all_gather_logits"]["ms_per_step"]
+
+
+def test_bench_gpus_n_spawns_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) re-executes itself under
+    torch.distributed.run -- one line, printed by rank 0, with n_gpus 2 -- instead of warning and measuring one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(GF_BENCH_SHARED_GPU="1", GF_BENCH_CHECK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["P_per_gpu"] == 12801
+    assert b["check_max_scaled_err_vs_single_device"] <= 1e-4

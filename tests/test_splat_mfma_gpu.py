@@ -432,6 +432,35 @@ def test_backward_takes_the_forward_records_when_the_workspace_still_holds_them(
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2000, 16, 16, 8), (3000, 8, 8, 16), (700, 24, 16, 8)])
+def test_backward_after_a_prepared_forward_on_a_grid_of_few_workgroups(gpu, shape):
+    """the forward finishes the backward's row layout in workgroups 0 .. 63 of its render launch; a grid with fewer
+    workgroups than that (a few supertiles) and more than 64 waves of Gaussians used to leave Gaussians without their first row and
+    still say "prepared".  Such a call now prepares nothing (word 4 of the state block = 0) and the backward lays its rows out
+    itself: gradients as the oracle's, equal bit for bit to those behind an unprepared forward."""
+    from gaussianformer_amd import _lib
+    P, H, W, D = shape
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=31, P=P, H=H, W=W, D=D)
+    pi, mi, radii, cov6 = prep(si)
+    g = np.random.default_rng(9).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
+    ref = oracle.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D, g)
+    outs = []
+    for fflags in (0, _lib.GF_PREPARE_BACKWARD):
+        _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=fflags)
+        words = state.view(torch.int32)[:5].tolist()
+        nwg = 8 * -(-(-(-H // 8) * -(-W // 8) * 4 * -(-D // 8)) // 8)
+        if fflags and nwg < 64:
+            assert (words[4] & 1) == 0, words
+        got = _bwd(gpu, si, t, state, g)
+        outs.append(got)
+        for a, b in zip(got, ref):
+            assert np.isfinite(a).all()
+            assert np.abs(a - b.reshape(a.shape)).max() <= 2e-4 * max(np.abs(b).max(), 1e-30)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["several_whole_grid", "buffer_full"])
 def test_backward_rows_of_whole_grid_gaussians_and_of_a_full_buffer(gpu, case):
     """The row layout without atomics at its edges: Gaussians with more rows than one workgroup sums (648 double bricks each,

@@ -39,7 +39,7 @@ def run(si, tag, grad_scale=1.0):
             scale = float(a64.abs().max()) + 1e-30
             err = float((a64 - b64).abs().max()) / scale
             fin = bool(torch.isfinite(b).all())
-            line = f"{tag}: {name:5s} {names[k]:10s} max err / max|exact| = {err:.3e}  finite {fin}"
+            line = f"{tag}: {name:5s} {names[k]:10s} max err / max|exact| = {err:.3e}  (absolute {err * scale:.3e}, max|exact| {scale:.3e})  finite {fin}"
             if err > 1e-3 or not fin:
                 d = (a64 - b64).abs().reshape(a.shape[0], -1)
                 worst = int(d.max(dim=1)[0].argmax())
@@ -52,7 +52,8 @@ def run(si, tag, grad_scale=1.0):
             rg = ref.splat_backward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D, g.cpu().numpy())
             for name in ("exact", "auto"):
                 errs = [float(np.abs(o.cpu().numpy().reshape(w.shape).astype(np.float64) - w).max() / max(np.abs(w).max(), 1e-30)) for o, w in zip(outs[name], rg)]
-                print(f"{tag}: {name:5s} vs oracle/_ref: " + ", ".join(f"{n} {e:.2e}" for n, e in zip(names, errs)), flush=True)
+                aerr = [float(np.abs(o.cpu().numpy().reshape(w.shape).astype(np.float64) - w).max()) for o, w in zip(outs[name], rg)]
+                print(f"{tag}: {name:5s} vs oracle/_ref (scaled by max|ref| / absolute): " + ", ".join(f"{n} {e:.2e} / {ae:.2e}" for n, e, ae in zip(names, errs, aerr)), flush=True)
     except Exception as exc:
         print("no oracle/_ref:", type(exc).__name__, exc)
     return t, state, g

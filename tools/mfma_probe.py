@@ -37,13 +37,15 @@ for config in configs:
         print(f"{config} {name}: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per step", flush=True)
     a, b = outs["exact"].double(), outs["mfma"].double()
     err = ((a - b).abs() / a.abs().clamp(min=1.0)).max().item()
-    print(f"{config}: mfma vs exact max scaled err {err:.3e}; finite {bool(torch.isfinite(outs['mfma']).all())}")
+    print(f"{config}: mfma vs exact max scaled err {err:.3e}, max ABSOLUTE err {(a - b).abs().max().item():.3e} (max |logit| {a.abs().max().item():.2f}); "
+          f"finite {bool(torch.isfinite(outs['mfma']).all())}")
     try:
         from oracle import ref
         if ref.available() or os.path.isdir(os.path.join(ROOT, "oracle", "_ref")):
             r = ref.splat_forward("base", si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6, si.H, si.W, si.D)["logits"].astype(np.float64)
             for name in outs:
                 g = outs[name].cpu().numpy().astype(np.float64)
-                print(f"{config}: {name} vs oracle/_ref max scaled err {(np.abs(g - r) / np.maximum(1.0, np.abs(r))).max():.3e}")
+                print(f"{config}: {name} vs oracle/_ref max scaled err {(np.abs(g - r) / np.maximum(1.0, np.abs(r))).max():.3e}, "
+                      f"max ABSOLUTE err {np.abs(g - r).max():.3e} (max |logit| {np.abs(r).max():.2f})")
     except Exception as exc:
         print("no oracle/_ref:", exc)
