@@ -49,6 +49,9 @@ SIGNATURES = {
     "gf_subm_rulebook_count": (_i, [_i] * 6 + [_vp, _vp, _sz, _vp]),
     "gf_subm_rulebook_fill": (_i, [_i] * 6 + [_vp] * 4 + [_vp]),
     "gf_subm_rulebook_build": (_i, [_i] * 6 + [_vp, _vp, _sz, _vp, _vp, ctypes.c_longlong, _vp]),
+    "gf_subm_rulebook_count_range": (_i, [_i] * 8 + [_vp, _vp, _sz, _vp]),
+    "gf_subm_rulebook_fill_range": (_i, [_i] * 8 + [_vp] * 4 + [_vp]),
+    "gf_subm_rulebook_build_range": (_i, [_i] * 8 + [_vp, _vp, _sz, _vp, _vp, ctypes.c_longlong, _vp]),
     "gf_subm_conv_apply": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
     "gf_subm_conv_weight_grad": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
     "gf_feature_maps_format": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),

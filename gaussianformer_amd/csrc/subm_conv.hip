@@ -59,6 +59,8 @@ struct SubmArgs {
     int N, batch, X, Y, Z, K, K3, Cin, Cout;
     long long cells;
     long long pair_capacity;  // > 0: the pair arrays hold this many entries; a larger rulebook raises total[1] bit 2 and stays empty
+    int out_lo, out_hi;       // output points [out_lo, out_hi): only they get pairs; EVERY point is a neighbour (anchor-sharded frame: a rank
+                              // computes its own anchors' rows from the all-gathered set, spconv3d_module.py:10-83 run 1/world times)
 };
 
 constexpr unsigned long long kSubmOverCapacity = 4ull;  // bit of total[1]
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void gf_subm_pairs_kernel(SubmArgs a)
     if (i < a.N) {
         const int4 c = *reinterpret_cast<const int4 *>(a.indices + 4 * (size_t)i);
         const long long own = subm_cell(a, c.x, c.y, c.z, c.w);
-        if (own >= 0) {
+        if (own >= 0 && i >= a.out_lo && i < a.out_hi) {
             col = subm_cell(a, c.x, c.y + kxy / a.K - r, c.z + kxy % a.K - r, 0);
             z = c.w;
         }
@@ -655,6 +657,7 @@ static SubmArgs subm_args(int N, int batch, int X, int Y, int Z, int K, const in
     a.N = N; a.batch = batch; a.X = X; a.Y = Y; a.Z = Z; a.K = K; a.K3 = K * K * K;
     a.cells = (long long)batch * X * Y * Z;
     a.indices = indices;
+    a.out_lo = 0; a.out_hi = N;
     size_t bytes;
     a.t = subm_carve(tables, N, a.cells, a.K3, &bytes);
     return a;
@@ -672,7 +675,7 @@ extern "C" size_t gf_subm_tables_bytes(int N, int batch, int X, int Y, int Z, in
 }
 
 static int subm_rulebook_count_impl(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
-                                    size_t tables_bytes, long long pair_capacity, void *stream_)
+                                    size_t tables_bytes, long long pair_capacity, void *stream_, int out_lo = 0, int out_hi = -1)
 {
     using namespace gf;
     hipStream_t stream = (hipStream_t)stream_;
@@ -682,6 +685,10 @@ static int subm_rulebook_count_impl(int N, int batch, int X, int Y, int Z, int K
     GF_CHECK_ARG(((uintptr_t)indices & 15) == 0 && ((uintptr_t)tables & 255) == 0, "indices must be 16-byte and tables 256-byte aligned");
     SubmArgs a = subm_args(N, batch, X, Y, Z, K, indices, tables);
     a.pair_capacity = pair_capacity;
+    if (out_hi >= 0) {
+        GF_CHECK_ARG(out_lo >= 0 && out_lo <= out_hi && out_hi <= N, "output range outside [0, N]");
+        a.out_lo = out_lo; a.out_hi = out_hi;
+    }
     if (hipMemsetAsync(a.t.head, 0xFF, (size_t)a.cells * 4, stream) != hipSuccess ||
         hipMemsetAsync(a.t.cnt, 0, (size_t)N * a.K3 * 2, stream) != hipSuccess ||
         hipMemsetAsync(a.t.total, 0, 16, stream) != hipSuccess ||
@@ -705,7 +712,7 @@ extern "C" int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int
 }
 
 static int subm_rulebook_fill_impl(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
-                                   int *pair_in, int *pair_out, long long pair_capacity, void *stream_)
+                                   int *pair_in, int *pair_out, long long pair_capacity, void *stream_, int out_lo = 0, int out_hi = -1)
 {
     using namespace gf;
     hipStream_t stream = (hipStream_t)stream_;
@@ -715,6 +722,10 @@ static int subm_rulebook_fill_impl(int N, int batch, int X, int Y, int Z, int K,
     SubmArgs a = subm_args(N, batch, X, Y, Z, K, indices, tables);
     a.pair_capacity = pair_capacity;
     a.pair_in = pair_in; a.pair_out = pair_out;
+    if (out_hi >= 0) {
+        GF_CHECK_ARG(out_lo >= 0 && out_lo <= out_hi && out_hi <= N, "output range outside [0, N]");
+        a.out_lo = out_lo; a.out_hi = out_hi;
+    }
     hipLaunchKernelGGL(gf_subm_pairs_kernel<true>, dim3((N + 255) / 256, K * K), dim3(256), 0, stream, a);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -732,6 +743,34 @@ extern "C" int gf_subm_rulebook_build(int N, int batch, int X, int Y, int Z, int
     GF_CHECK_ARG(pair_capacity > 0 && pair_capacity < (1ll << 31), "pair_capacity out of range");
     if (int rc = subm_rulebook_count_impl(N, batch, X, Y, Z, K, indices, tables, tables_bytes, pair_capacity, stream)) return rc;
     return subm_rulebook_fill_impl(N, batch, X, Y, Z, K, indices, tables, pair_in, pair_out, pair_capacity, stream);
+}
+
+// The same three entry points with an OUTPUT RANGE: pairs are made for the output points [out_lo, out_hi) only, every point of the
+// set stays a neighbour.  What an anchor-sharded frame needs: rank r all-gathers anchors and features, builds this rulebook for its
+// own slice and applies it -- its rows of the replicated convolution at 1 / world of the gather-GEMM work (the apply and reduce
+// kernels only see the pairs there are; rows of points outside the range come out as zeros).
+extern "C" int gf_subm_rulebook_count_range(int N, int batch, int X, int Y, int Z, int K, int out_lo, int out_hi, const int *indices,
+                                            void *tables, size_t tables_bytes, void *stream)
+{
+    GF_CHECK_ARG(out_lo >= 0 && out_lo <= out_hi && out_hi <= N, "output range outside [0, N]");
+    return subm_rulebook_count_impl(N, batch, X, Y, Z, K, indices, tables, tables_bytes, 0, stream, out_lo, out_hi);
+}
+
+extern "C" int gf_subm_rulebook_fill_range(int N, int batch, int X, int Y, int Z, int K, int out_lo, int out_hi, const int *indices,
+                                           void *tables, int *pair_in, int *pair_out, void *stream)
+{
+    GF_CHECK_ARG(out_lo >= 0 && out_lo <= out_hi && out_hi <= N, "output range outside [0, N]");
+    return subm_rulebook_fill_impl(N, batch, X, Y, Z, K, indices, tables, pair_in, pair_out, 0, stream, out_lo, out_hi);
+}
+
+extern "C" int gf_subm_rulebook_build_range(int N, int batch, int X, int Y, int Z, int K, int out_lo, int out_hi, const int *indices,
+                                            void *tables, size_t tables_bytes, int *pair_in, int *pair_out, long long pair_capacity,
+                                            void *stream)
+{
+    GF_CHECK_ARG(pair_capacity > 0 && pair_capacity < (1ll << 31), "pair_capacity out of range");
+    GF_CHECK_ARG(out_lo >= 0 && out_lo <= out_hi && out_hi <= N, "output range outside [0, N]");
+    if (int rc = subm_rulebook_count_impl(N, batch, X, Y, Z, K, indices, tables, tables_bytes, pair_capacity, stream, out_lo, out_hi)) return rc;
+    return subm_rulebook_fill_impl(N, batch, X, Y, Z, K, indices, tables, pair_in, pair_out, pair_capacity, stream, out_lo, out_hi);
 }
 
 #define GF_SUBM_DISPATCH(CALL)                                         \

@@ -26,11 +26,18 @@ class Rulebook:
     has completed).  Note the memory side of a generous capacity: ``apply`` sizes its partial-row buffer
     ``[pair_capacity, Cout]`` by it (32 KB per point at ``pairs_per_point=64``, Cout = 128)."""
 
-    def __init__(self, indices, batch_size, spatial_shape, kernel_size, pair_capacity=None):
+    def __init__(self, indices, batch_size, spatial_shape, kernel_size, pair_capacity=None, out_range=None):
+        """``out_range=(lo, hi)``: pairs only for the output points ``[lo, hi)`` (every point stays a neighbour) -- the rows an
+        anchor-sharded rank owns, at ``(hi - lo) / N`` of the gather-GEMM work; the other rows of ``apply`` are zeros."""
         _lib.require_gpu(indices)
         lib = _lib.load()
         self.indices = indices.detach().to(i32).contiguous()
         self.N = self.indices.shape[0]
+        self.out_range = None if out_range is None else (int(out_range[0]), int(out_range[1]))
+        rng = () if self.out_range is None else self.out_range
+        count_fn = lib.gf_subm_rulebook_count if self.out_range is None else lib.gf_subm_rulebook_count_range
+        fill_fn = lib.gf_subm_rulebook_fill if self.out_range is None else lib.gf_subm_rulebook_fill_range
+        build_fn = lib.gf_subm_rulebook_build if self.out_range is None else lib.gf_subm_rulebook_build_range
         self.dims = (self.N, int(batch_size), int(spatial_shape[0]), int(spatial_shape[1]), int(spatial_shape[2]),
                      int(kernel_size))
         dev = self.indices.device
@@ -45,7 +52,7 @@ class Rulebook:
                 self.total = max(int(pair_capacity), 1)
                 self.pair_in = torch.empty(self.total, dtype=i32, device=dev)
                 self.pair_out = torch.empty(self.total, dtype=i32, device=dev)
-                rc = lib.gf_subm_rulebook_build(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes,
+                rc = build_fn(*self.dims, *rng, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes,
                                                 _lib.ptr(self.pair_in), _lib.ptr(self.pair_out), self.total, _lib.current_stream(dev))
                 _lib.check(rc, "gf_subm_rulebook_build")
                 # deferred check: status -> pinned host memory on the same stream, event behind the copy
@@ -57,15 +64,14 @@ class Rulebook:
                     self._status_event = torch.cuda.Event()
                     self._status_event.record(torch.cuda.current_stream(dev))
                 return
-            rc = lib.gf_subm_rulebook_count(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes,
-                                            _lib.current_stream(dev))
+            rc = count_fn(*self.dims, *rng, _lib.ptr(self.indices), _lib.ptr(self.tables), nbytes, _lib.current_stream(dev))
             _lib.check(rc, "gf_subm_rulebook_count")
             total = self.check()   # the one host read
             self.total = int(total)
             self.pair_in = torch.empty(max(self.total, 1), dtype=i32, device=dev)
             self.pair_out = torch.empty(max(self.total, 1), dtype=i32, device=dev)
-            rc = lib.gf_subm_rulebook_fill(*self.dims, _lib.ptr(self.indices), _lib.ptr(self.tables),
-                                           _lib.ptr(self.pair_in), _lib.ptr(self.pair_out), _lib.current_stream(dev))
+            rc = fill_fn(*self.dims, *rng, _lib.ptr(self.indices), _lib.ptr(self.tables),
+                         _lib.ptr(self.pair_in), _lib.ptr(self.pair_out), _lib.current_stream(dev))
             _lib.check(rc, "gf_subm_rulebook_fill")
 
     def representative_mask(self):
@@ -178,6 +184,9 @@ def subm_conv3d(features, indices, weight, batch_size, spatial_shape, kernel_siz
     if duplicates not in DUPLICATES:
         raise ValueError(f"duplicates must be one of {DUPLICATES}")
     rb = rulebook if rulebook is not None else Rulebook(indices, batch_size, spatial_shape, kernel_size)
+    if rb.out_range is not None and torch.is_grad_enabled() and (features.requires_grad or weight.requires_grad):
+        # (the backward relies on the neighbour relation being symmetric: a rulebook restricted to a range of output points is not)
+        raise RuntimeError("a Rulebook with out_range is inference-only")
     if duplicates == "last":
         features = features * rb.representative_mask()
     return _SubMConv.apply(features, weight, rb)
@@ -253,10 +262,24 @@ class SparseConv3D(nn.Module):
         bidx = torch.arange(bs, device=idx.device, dtype=torch.int32).repeat_interleave(g)[:, None]
         return torch.cat([bidx, idx], dim=-1)
 
-    def forward(self, instance_feature, anchor):
+    def forward(self, instance_feature, anchor, out_range=None):
+        """``out_range=(lo, hi)`` (extra keyword, inference, batch size 1, single-layer blocks): ``instance_feature`` / ``anchor``
+        are the WHOLE (all-gathered) anchor set, the block is evaluated for the anchors ``[lo, hi)`` only and returns
+        ``[1, hi - lo, C]`` -- the rows an anchor-sharded rank owns, bit-identical to the same rows of the whole block, at
+        ``(hi - lo) / g`` of the gather-GEMM and projection work."""
         bs, g, _ = instance_feature.shape
         indices = self.voxel_indices(anchor)
         feats = instance_feature.flatten(0, 1)
+        if out_range is not None:
+            if bs != 1 or not isinstance(self.layer, SubMConv3d):
+                raise RuntimeError("out_range needs batch size 1 and a single-layer block")
+            lo, hi = int(out_range[0]), int(out_range[1])
+            cap = None if self.pairs_per_point is None else int(self.pairs_per_point) * max(hi - lo, 1)
+            rb = self.last_rulebook = Rulebook(indices, bs, self._spatial, self.kernel_size, pair_capacity=cap, out_range=(lo, hi))
+            if cap is not None and not rb.checked and rb._status_event is not None:
+                self._unchecked.append(rb)
+            out = self.layer(feats, indices, bs, self._spatial, rulebook=rb)
+            return self.output_proj(out[lo:hi])[None]
         cap = None if self.pairs_per_point is None else int(self.pairs_per_point) * indices.shape[0]
         # refusals of earlier calls surface here, without blocking: a refused rulebook already produced NaN features,
         # this names the cause as soon as its status has reached the host

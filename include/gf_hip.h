@@ -358,6 +358,17 @@ int gf_subm_rulebook_fill(int N, int batch, int X, int Y, int Z, int K, const in
                           int *pair_in, int *pair_out, void *stream);
 int gf_subm_rulebook_build(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
                            size_t tables_bytes, int *pair_in, int *pair_out, long long pair_capacity, void *stream);
+/* The same three with an OUTPUT RANGE (round 5; the anchor-sharded frame, where the reference would run the whole SparseConv3D,
+ * spconv3d_module.py:10-83, on every replica): pairs are made for the output points [out_lo, out_hi) only, every point of the set
+ * stays a neighbour.  gf_subm_conv_apply on such a rulebook computes those rows (the others come out as zeros) with
+ * (out_hi - out_lo) / N of the gather-GEMM work; the pair count at the end of `tables` counts the range's pairs. */
+int gf_subm_rulebook_count_range(int N, int batch, int X, int Y, int Z, int K, int out_lo, int out_hi, const int *indices,
+                                 void *tables, size_t tables_bytes, void *stream);
+int gf_subm_rulebook_fill_range(int N, int batch, int X, int Y, int Z, int K, int out_lo, int out_hi, const int *indices,
+                                void *tables, int *pair_in, int *pair_out, void *stream);
+int gf_subm_rulebook_build_range(int N, int batch, int X, int Y, int Z, int K, int out_lo, int out_hi, const int *indices,
+                                 void *tables, size_t tables_bytes, int *pair_in, int *pair_out, long long pair_capacity,
+                                 void *stream);
 int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
                        const float *features, const float *weight, const void *tables, const int *pair_in,
                        float *partial, float *out, void *stream);

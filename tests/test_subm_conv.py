@@ -392,3 +392,46 @@ def test_subm_conv_last_duplicate_mode():
     assert m.layer.duplicates == "last"
     with pytest.raises(ValueError):
         SparseConv3D(32, 32, [0, 0, 0, 5, 6, 3], [1.0, 1.0, 1.0], duplicates="first")
+
+
+@pytest.mark.parametrize("pairs_per_point", [None, 64])
+def test_sparse_conv3d_output_range(pairs_per_point):
+    """Round 5 (the anchor-sharded frame): ``out_range=(lo, hi)`` evaluates the block for a slice of the anchors against the WHOLE
+    set as neighbourhood.  The rows are those of the whole block bit for bit (same pairs in the same order per output row), for
+    every slice of a partition; the rulebook holds that slice's pairs only; autograd through such a rulebook is refused."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gaussianformer_amd.sparse_conv import Rulebook, SparseConv3D, subm_conv3d
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    m = SparseConv3D(128, 128, pc_range=[-50.0, -50.0, -5.0, 50.0, 50.0, 3.0], grid_size=[0.5, 0.5, 0.5], use_out_proj=True,
+                     pairs_per_point=pairs_per_point).to(dev).eval()
+    g = 9000
+    anchor = 0.6 * torch.randn(1, g, 11, device=dev)      # (crowded enough for cells with several anchors)
+    feat = torch.randn(1, g, 128, device=dev)
+    with torch.no_grad():
+        whole = m(feat, anchor)
+        total_whole = m.last_rulebook.check()
+        idx0 = m.voxel_indices(anchor)
+        conv_whole = subm_conv3d(feat[0], idx0, m.layer.weight, 1, m._spatial, 5)
+        bounds = [0, 1, 1125, 4000, 4001, 8999, g]
+        pairs = 0
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            part = m(feat, anchor, out_range=(lo, hi))
+            assert part.shape == (1, hi - lo, 128)
+            # (the output projection is a torch GEMM whose tiling changes with the row count: last-bit differences)
+            assert torch.allclose(part, whole[:, lo:hi], rtol=1e-5, atol=1e-5), (lo, hi)
+            pairs += m.last_rulebook.check()
+            # the convolution itself: the slice's rows bit for bit, zeros elsewhere
+            conv = subm_conv3d(feat[0], idx0, m.layer.weight, 1, m._spatial, 5, rulebook=m.last_rulebook)
+            assert torch.equal(conv[lo:hi], conv_whole[lo:hi]), (lo, hi)
+            assert float(conv[:lo].abs().sum()) == 0.0 and float(conv[hi:].abs().sum()) == 0.0
+        assert pairs == total_whole                        # the slices' rulebooks partition the whole rulebook
+        empty = m(feat, anchor, out_range=(77, 77))
+        assert empty.shape == (1, 0, 128)
+    idx = m.voxel_indices(anchor)
+    rb = Rulebook(idx, 1, m._spatial, 5, out_range=(10, 20))
+    with pytest.raises(RuntimeError):
+        subm_conv3d(feat[0].clone().requires_grad_(True), idx, m.layer.weight, 1, m._spatial, 5, rulebook=rb)
+    with pytest.raises(RuntimeError):
+        Rulebook(idx, 1, m._spatial, 5, out_range=(5, g + 1))

@@ -227,8 +227,9 @@ class Frame(nn.Module):
             if op == "deformable":
                 feat = layer(feat, anchor, embed, table, pm, wh)
             elif op == "spconv":
-                full = layer(gather(feat, 1), gather(anchor, 1))
-                feat = full[:, lo:hi].contiguous()
+                # the whole anchor set is the neighbourhood, the rank's own slice the output (round 5: the block used to run
+                # replicated on every rank -- Amdahl's share of the sharded frame)
+                feat = layer(gather(feat, 1), gather(anchor, 1), out_range=(lo, hi)).contiguous()
             elif op == "refine":
                 anchor = layer(feat, anchor, embed)
                 embed = self.anchor_encoder(anchor)
