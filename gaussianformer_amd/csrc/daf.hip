@@ -707,6 +707,412 @@ __global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: grad_mc_ms_feat REGION-major.  The tile formulation above sorts TAPS by runs of 64 pixel rows of one level: a sample
+// point's sixteen taps (four levels x four corners) land in up to sixteen different work items, each of which fetches the point's
+// 512-byte grad_output row again, in pixel order -- 1.7 GB (projected cameras) / 5.1 GB (uniform locations) through the fabric for
+// 118 MB of rows (profiles/traffic_daf_r04.json).  But the sixteen taps of a sample sit at ONE place of the image in every level.
+// So here the visible SAMPLES (point, camera) are bucketed by image region -- 8 x 8 pixels of level 0 and the pixels under them in
+// the coarser levels (+ the bilinear halo) -- and a work item is a region's samples (<= kRegItem): it stages 64 samples' grad_output
+// rows and weights in LDS at a time (each row is read from memory ONCE per sample), generates their taps, sorts them by pixel of
+// the region (<= kRegRows rows over all levels) and gives every row to a lane group that keeps the row's sum in REGISTERS across all
+// the item's samples; the sums leave as one atomic row add per (row, item).  The bucket passes move one id per sample instead of
+// sixteen per sample.
+constexpr int kRegRows = 192;     // pixel rows of a region over all levels (8 lane groups x 24 accumulators)
+constexpr int kRegSub = 64;       // samples staged in LDS at a time
+constexpr int kRegItem = 512;     // samples per work item
+constexpr int kRegMaxL = 4;
+
+// The level sizes live in device memory (spatial_shape), so the regions' geometry is made on the device, by one thread, into the
+// workspace: regions of (8 << shift)^2 level-0 pixels (shift > 0 only for pyramids with more than kDafMaxTiles such regions), each
+// level's rectangle under a region (+ the bilinear halo), capped so that a region has at most kRegRows pixel rows -- taps that fall
+// outside a capped rectangle (pyramids whose coarser levels are not ~ 1/2, 1/4, 1/8 of level 0) take the slow per-tap path.
+struct DafRegionGeom {
+    int RX, RY, shift, nregions;  // regions per camera along w / h, log2(region size / 8), cams * RX * RY
+    int rw[kRegMaxL], rh[kRegMaxL], roff[kRegMaxL + 1];   // a region's pixel rectangle per level (width, height) and its first local row
+    float rho_w[kRegMaxL], rho_h[kRegMaxL];               // level size / level-0 size
+};
+struct DafRegionArgs {
+    DafSortArgs s;                // taps[] holds sample ids ((point << cam_bits) | cam); tile = region
+    DafRegionGeom *geom;
+};
+
+__global__ void gf_daf_region_geom_kernel(DafRegionArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DafRegionGeom g;
+    const int h0 = a.s.spatial_shape[0], w0 = a.s.spatial_shape[1];
+    g.shift = 0;
+    while (true) {
+        const int sz = 8 << g.shift;
+        g.RX = w0 / sz + 1; g.RY = h0 / sz + 1;
+        if ((long long)a.s.cams * g.RX * g.RY <= kDafMaxTiles || g.shift >= 20) break;
+        ++g.shift;
+    }
+    g.nregions = a.s.cams * g.RX * g.RY;
+    const float span = (float)(8 << g.shift) + 1.f;   // level-0 tap positions of a region: [size rx - 1, size rx + size]
+    for (int s = 0; s < kRegMaxL; ++s) {
+        g.rw[s] = g.rh[s] = 0; g.rho_w[s] = g.rho_h[s] = 0.f;
+        if (s < a.s.L) {
+            const int h = a.s.spatial_shape[2 * s], w = a.s.spatial_shape[2 * s + 1];
+            g.rho_w[s] = (float)w / (float)w0; g.rho_h[s] = (float)h / (float)h0;
+            const int rw = s == 0 ? (8 << g.shift) + 2 : (int)ceilf(span * g.rho_w[s] + 1e-3f) + 2;
+            const int rh = s == 0 ? (8 << g.shift) + 2 : (int)ceilf(span * g.rho_h[s] + 1e-3f) + 2;
+            g.rw[s] = max(1, min(rw, w + 2)); g.rh[s] = max(1, min(rh, h + 2));
+        }
+    }
+    // cap (pyramids whose levels do not shrink like the reference's): the largest rectangle gives up a line until the rows fit
+    while (true) {
+        int total = 0, big = 0;
+        for (int s = 0; s < a.s.L; ++s) {
+            total += g.rw[s] * g.rh[s];
+            if (g.rw[s] * g.rh[s] > g.rw[big] * g.rh[big]) big = s;
+        }
+        if (total <= kRegRows) break;
+        if (g.rw[big] >= g.rh[big] && g.rw[big] > 1) --g.rw[big];
+        else if (g.rh[big] > 1) --g.rh[big];
+        else break;
+    }
+    int off = 0;
+    for (int s = 0; s < kRegMaxL; ++s) {
+        g.roff[s] = off;
+        off += g.rw[s] * g.rh[s];
+    }
+    g.roff[kRegMaxL] = off;
+    *a.geom = g;
+    a.s.header[1] = (uint32_t)g.nregions;
+}
+
+__device__ __forceinline__ int daf_region_of(const DafRegionGeom &g, const DafSortArgs &a, float loc_w, float loc_h, uint32_t cam)
+{
+    const int h0 = a.spatial_shape[0], w0 = a.spatial_shape[1];
+    const int wl = (int)floorf(loc_w * w0 - 0.5f), hl = (int)floorf(loc_h * h0 - 0.5f);   // the level-0 tap's own arithmetic
+    const int rx = min(max(wl + 1, 0) >> (3 + g.shift), g.RX - 1);
+    const int ry = min(max(hl + 1, 0) >> (3 + g.shift), g.RY - 1);
+    return ((int)cam * g.RY + ry) * g.RX + rx;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(1024) void gf_daf_rbucket_kernel(DafRegionArgs a)
+{
+    __shared__ uint32_t s_bin[kDafMaxTiles];
+    const DafRegionGeom g = *a.geom;
+    const int ntiles = g.nregions;
+    const int wg = blockIdx.x;
+    uint32_t *row = a.s.M + (size_t)wg * kDafMaxTiles;   // (rows of kDafMaxTiles entries: the region count is not known to the host)
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) s_bin[t] = FILL ? a.s.tile_start[t] + row[t] : 0u;
+    __syncthreads();
+    const long long per = (a.s.samples + gridDim.x - 1) / gridDim.x;
+    const long long s0 = min(a.s.samples, (long long)wg * per), s1 = min(a.s.samples, s0 + per);
+    for (long long q = s0 + threadIdx.x; q < s1; q += blockDim.x) {
+        const float2 lc = *reinterpret_cast<const float2 *>(a.s.loc + 2 * q);
+        if (!(lc.x > 0 && lc.x < 1 && lc.y > 0 && lc.y < 1)) continue;  // deformable_aggregation_cuda.cu:166
+        const uint32_t pt = (uint32_t)(q / a.s.cams), cam = (uint32_t)(q - (long long)pt * a.s.cams);
+        const int reg = daf_region_of(g, a.s, lc.x, lc.y, cam);
+        if (FILL) a.s.taps[atomicAdd(&s_bin[reg], 1u)] = (pt << a.s.cam_bits) | cam;
+        else atomicAdd(&s_bin[reg], 1u);
+    }
+    if (!FILL) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < ntiles; t += blockDim.x) row[t] = s_bin[t];
+    }
+}
+
+// gf_daf_colscan_kernel for the regions (rows of kDafMaxTiles entries, the region count read from the device)
+__global__ __launch_bounds__(256) void gf_daf_rcolscan_kernel(DafSortArgs a)
+{
+    constexpr int kParts = 8, kPer = kDafBucketWgs / kParts;
+    const int ntiles = (int)a.header[1];
+    const int gidx = blockIdx.x * 256 + threadIdx.x;
+    const int t = gidx / kParts, part = gidx % kParts;
+    const bool live = t < ntiles;
+    const int tc = live ? t : ntiles - 1;
+    uint32_t c[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) c[j] = a.M[(size_t)(part * kPer + j) * kDafMaxTiles + tc];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t v = c[j];
+        c[j] = sum;
+        sum += v;
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < kParts; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, kParts);
+        if (part >= d) incl += up;
+    }
+    const uint32_t base = incl - sum;
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) a.M[(size_t)(part * kPer + j) * kDafMaxTiles + t] = base + c[j];
+    if (part == kParts - 1) a.tile_start[t] = incl;
+}
+
+// prefix over the regions and the work-item table: gf_daf_tilescan_kernel with items of kRegItem samples
+__global__ __launch_bounds__(1024) void gf_daf_regionscan_kernel(DafSortArgs a_)
+{
+    DafSortArgs a = a_;
+    a.ntiles = (int)a.header[1];
+    __shared__ uint32_t s_t[1024], s_i[1024];
+    const int tid = threadIdx.x;
+    const int per = (a.ntiles + 1023) / 1024;
+    const int t0 = min(a.ntiles, tid * per), t1 = min(a.ntiles, t0 + per);
+    uint32_t st = 0, si = 0;
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t c = a.tile_start[t];
+        st += c;
+        si += (c + kRegItem - 1) / kRegItem;
+    }
+    s_t[tid] = st; s_i[tid] = si;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t ut = tid >= d ? s_t[tid - d] : 0u, ui = tid >= d ? s_i[tid - d] : 0u;
+        __syncthreads();
+        s_t[tid] += ut; s_i[tid] += ui;
+        __syncthreads();
+    }
+    uint32_t run_t = s_t[tid] - st, run_i = s_i[tid] - si;
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t c = a.tile_start[t];
+        const uint32_t ni = (c + kRegItem - 1) / kRegItem;
+        a.tile_start[t] = run_t;
+        a.item_start[t] = run_i;
+        for (uint32_t i = 0; i < ni; ++i) a.item_tile[run_i + i] = (uint32_t)t;
+        run_t += c;
+        run_i += ni;
+    }
+    if (tid == 1023) {
+        a.tile_start[a.ntiles] = s_t[1023];
+        a.item_start[a.ntiles] = s_i[1023];
+        a.header[0] = s_i[1023];
+        a.header[2] = 0u;   // the accumulation's item counter
+    }
+}
+
+template <int LPT>
+__global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArgs a)
+{
+    constexpr int T = 512;                            // threads per workgroup
+    constexpr int NG = T / LPT;                       // lane groups per workgroup
+    constexpr int RPG = (kRegRows + NG - 1) / NG;     // rows (register accumulators) per lane group
+    constexpr int C = 4 * LPT;
+    constexpr int TAPS = kRegSub * 4 * kRegMaxL;      // taps of a staged batch
+    constexpr int PER = TAPS / T;
+    constexpr int SPG = kRegSub / NG;                 // samples whose rows a lane group stages per batch
+    static_assert(TAPS % T == 0 && kRegSub % NG == 0 && (kRegSub * 16) % T == 0, "shapes");
+    __shared__ __attribute__((aligned(16))) float s_rows[kRegSub * C];
+    __shared__ float s_w[kRegSub * 16];               // [sample][level][group] (L * G <= 16)
+    __shared__ uint32_t s_sid[kRegItem];              // the item's samples ...
+    __shared__ float2 s_loc[kRegItem];                // ... and their sampling locations
+    __shared__ uint32_t s_key[TAPS];                  // sorted taps: byte offset of the sample's staged row
+    __shared__ __attribute__((aligned(16))) float s_cw[TAPS * 4];   // ... and bilinear coefficient x weight, per group (G <= 4)
+    __shared__ uint32_t s_item;
+    __shared__ uint32_t s_cnt[kRegRows + 2];
+    __shared__ int s_geo[8 * kRegMaxL];               // per level: x0, y0, rw, rh, roff, h, w, scale_start (read by runtime level)
+    const int tid = threadIdx.x;
+    const int gi = tid / LPT, cl = tid - gi * LPT;
+    const int c0 = 4 * cl;
+    const int L = a.s.L, G = a.s.G;
+    const int lg = L * G;
+    const int group = c0 / (C / G);
+    const uint32_t cam_mask = (1u << a.s.cam_bits) - 1u;
+    const uint32_t nitems = a.s.header[0];
+    const DafRegionGeom *gp = a.geom;                  // (read in place: a by-value copy indexed by a runtime level lives in scratch)
+    const int gRX = gp->RX, gRY = gp->RY, gshift = gp->shift;
+    const int LR = gp->roff[kRegMaxL];                 // local rows of a region
+    for (;;) {
+        // items are CLAIMED (header[2], zeroed by the scan kernel): their sizes run from one sample to kRegItem, and a static
+        // stride left the workgroups that drew the full ones working alone at the end
+        __syncthreads();   // (the previous item's last reads of the shared arrays)
+        if (tid == 0) s_item = atomicAdd(a.s.header + 2, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= nitems) break;
+        const uint32_t reg = a.s.item_tile[item];
+        const uint32_t chunk = item - a.s.item_start[reg];
+        const uint32_t seg1 = a.s.tile_start[reg + 1];
+        const uint32_t t0 = a.s.tile_start[reg] + chunk * kRegItem, t1 = min(seg1, t0 + kRegItem);
+        const int nitem = (int)(t1 - t0);
+        const int rx = (int)(reg % (uint32_t)gRX), ry = (int)((reg / (uint32_t)gRX) % (uint32_t)gRY);
+        const uint32_t cam = reg / (uint32_t)(gRX * gRY);
+        const float rsz = (float)(8 << gshift);
+        // the region's rectangle per level: first pixel (x0, y0); widths / heights / local offsets come from the geometry block
+        if (tid < L) {
+            const int s = tid;
+            s_geo[8 * s] = s == 0 ? (int)rsz * rx - 1 : (int)floorf((rsz * rx - 0.5f) * gp->rho_w[s] - 0.5f - 1e-3f);
+            s_geo[8 * s + 1] = s == 0 ? (int)rsz * ry - 1 : (int)floorf((rsz * ry - 0.5f) * gp->rho_h[s] - 0.5f - 1e-3f);
+            s_geo[8 * s + 2] = gp->rw[s]; s_geo[8 * s + 3] = gp->rh[s]; s_geo[8 * s + 4] = gp->roff[s];
+            s_geo[8 * s + 5] = a.s.spatial_shape[2 * s]; s_geo[8 * s + 6] = a.s.spatial_shape[2 * s + 1]; s_geo[8 * s + 7] = a.s.scale_start[s];
+        }
+        // the item's sample ids and locations (clamped: slots past the end repeat the last sample and are never used as taps)
+        {
+            const uint32_t sid = a.s.taps[min(t0 + (uint32_t)tid, t1 - 1)];
+            const size_t sample = (size_t)(sid >> a.s.cam_bits) * a.s.cams + (sid & cam_mask);
+            s_sid[tid] = sid;
+            s_loc[tid] = *reinterpret_cast<const float2 *>(a.s.loc + 2 * sample);
+        }
+        static_assert(kRegItem == T, "one sample id per thread");
+        __syncthreads();
+        float4 acc[RPG];
+#pragma unroll
+        for (int k = 0; k < RPG; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t touched = 0u;   // rows of the group that received a tap
+        // The grad_output rows and weights of a batch of kRegSub samples are REQUESTED one batch ahead, into registers: their
+        // round trip travels under the previous batch's sort and row walks.
+        float4 prow[SPG];
+        float pw[kRegSub * 16 / T];
+        auto prefetch = [&](int b0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < SPG; ++u) {
+                const uint32_t pt = s_sid[min(b0 + gi + NG * u, kRegItem - 1)] >> a.s.cam_bits;
+                prow[u] = *reinterpret_cast<const float4 *>(a.s.grad_out + (size_t)pt * C + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < kRegSub * 16 / T; ++u) {
+                const int i = tid + T * u, sm = i >> 4, j = i & 15;
+                const uint32_t sid = s_sid[min(b0 + sm, kRegItem - 1)];
+                const size_t sample = (size_t)(sid >> a.s.cam_bits) * a.s.cams + (sid & cam_mask);
+                pw[u] = a.s.weights[sample * lg + min(j, lg - 1)];
+            }
+        };
+        prefetch(0);
+        for (int b0 = 0; b0 < nitem; b0 += kRegSub) {
+            const int ns = min(kRegSub, nitem - b0);
+            __syncthreads();   // the previous batch has been consumed
+#pragma unroll
+            for (int u = 0; u < SPG; ++u) *reinterpret_cast<float4 *>(s_rows + (gi + NG * u) * C + c0) = prow[u];
+#pragma unroll
+            for (int u = 0; u < kRegSub * 16 / T; ++u) s_w[tid + T * u] = pw[u];
+            if (tid <= kRegRows + 1) s_cnt[tid] = 0u;
+            __syncthreads();
+            if (b0 + kRegSub < nitem) prefetch(b0 + kRegSub);
+            // ---- taps of the batch: coefficient, local row, rank within the row
+            uint32_t tkey[PER], rank[PER];
+            int lrow[PER];
+            float cw[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int ti = tid + T * j;
+                const int sm = ti / (4 * kRegMaxL), sl = (ti / 4) % kRegMaxL, k = ti & 3;
+                lrow[j] = -1;
+                const float2 lc = s_loc[b0 + sm];
+                if (sm < ns && sl < L) {
+                    const int h = s_geo[8 * sl + 5], w = s_geo[8 * sl + 6];
+                    const float h_im = lc.y * h - 0.5f, w_im = lc.x * w - 0.5f;
+                    const float fh = floorf(h_im), fw = floorf(w_im);
+                    const float lh = h_im - fh, lw = w_im - fw, hh = 1 - lh, hw = 1 - lw;
+                    cw[j] = k == 0 ? hh * hw : k == 1 ? hh * lw : k == 2 ? lh * hw : lh * lw;
+                    const int py = (int)fh + (k >> 1), px = (int)fw + (k & 1);
+                    if (py >= 0 && py <= h - 1 && px >= 0 && px <= w - 1) {      // ok1 .. ok4 of make_taps
+                        const int lx = px - s_geo[8 * sl], ly = py - s_geo[8 * sl + 1], rw = s_geo[8 * sl + 2];
+                        if (lx >= 0 && lx < rw && ly >= 0 && ly < s_geo[8 * sl + 3]) {
+                            lrow[j] = s_geo[8 * sl + 4] + ly * rw + lx;
+                            tkey[j] = (uint32_t)sm | ((uint32_t)sl << 8);
+                            rank[j] = atomicAdd(&s_cnt[lrow[j]], 1u);
+                        } else {
+                            // outside the rectangle the region's geometry promises (pyramids whose rectangles were capped; never
+                            // with the reference's): kept correct, not fast -- the tap's contribution goes straight to its pixel row
+                            const uint32_t sid = s_sid[b0 + sm];
+                            const uint32_t pt = sid >> a.s.cam_bits;
+                            const size_t sample = (size_t)pt * a.s.cams + (sid & cam_mask);
+                            float *dst = a.s.grad_feat + ((size_t)cam * a.s.num_feat + s_geo[8 * sl + 7] + (size_t)py * w + px) * C;
+                            for (int ch = 0; ch < C; ++ch)
+                                unsafeAtomicAdd(dst + ch, cw[j] * (a.s.grad_out[(size_t)pt * C + ch] * a.s.weights[(sample * L + sl) * G + ch / (C / G)]));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {   // exclusive scan of the <= 192 row counts: three per lane
+                const uint32_t ca = s_cnt[3 * tid], cb = s_cnt[3 * tid + 1], cc = s_cnt[3 * tid + 2];
+                uint32_t incl = ca + cb + cc;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(incl, d, 64);
+                    if (tid >= d) incl += up;
+                }
+                const uint32_t excl = incl - (ca + cb + cc);
+                s_cnt[3 * tid] = excl;
+                s_cnt[3 * tid + 1] = excl + ca;
+                s_cnt[3 * tid + 2] = excl + ca + cb;
+                if (tid == 63) s_cnt[kRegRows] = incl;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (lrow[j] < 0) continue;
+                const uint32_t pos = s_cnt[lrow[j]] + rank[j];
+                const int sm = (int)(tkey[j] & 255u), sl = (int)(tkey[j] >> 8);
+                s_key[pos] = (uint32_t)(sm * C * 4);
+                // top_grad = grad_output * weight (:84), then the bilinear coefficient (:92-110): the two scalars multiplied here, once
+                float4 v;
+                v.x = cw[j] * s_w[sm * 16 + sl * G];
+                v.y = G > 1 ? cw[j] * s_w[sm * 16 + sl * G + 1] : 0.f;
+                v.z = G > 2 ? cw[j] * s_w[sm * 16 + sl * G + 2] : 0.f;
+                v.w = G > 3 ? cw[j] * s_w[sm * 16 + sl * G + 3] : 0.f;
+                *reinterpret_cast<float4 *>(s_cw + 4 * pos) = v;
+            }
+            __syncthreads();
+            // ---- every lane group walks the taps of ITS rows: sums stay in registers across the item's batches
+            const char *rows_b = reinterpret_cast<const char *>(s_rows) + 4 * c0;
+            const float *cw_g = s_cw + group;
+#pragma unroll
+            for (int k = 0; k < RPG; ++k) {
+                const int r = gi + NG * k;
+                if (r >= LR) continue;
+                uint32_t pb = s_cnt[r];
+                const uint32_t p1 = s_cnt[r + 1];
+                touched |= (p1 > pb ? 1u : 0u) << k;
+                for (; pb + 4 <= p1; pb += 4) {
+                    uint32_t key[4];
+                    float wt[4];
+                    float4 go[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { key[u] = s_key[pb + u]; wt[u] = cw_g[4 * (pb + u)]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) go[u] = *reinterpret_cast<const float4 *>(rows_b + key[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[k].x += wt[u] * go[u].x; acc[k].y += wt[u] * go[u].y; acc[k].z += wt[u] * go[u].z; acc[k].w += wt[u] * go[u].w;
+                    }
+                }
+                for (; pb < p1; ++pb) {
+                    const float wt = cw_g[4 * pb];
+                    const float4 go = *reinterpret_cast<const float4 *>(rows_b + s_key[pb]);
+                    acc[k].x += wt * go.x; acc[k].y += wt * go.y; acc[k].z += wt * go.z; acc[k].w += wt * go.w;
+                }
+            }
+        }
+        // ---- the item's row sums: one atomic row add each (rows of neighbouring regions' halos and of a region's other items
+        // overlap).  The adds are issued with CONSECUTIVE channels on consecutive lanes -- a lane's four channels, added as
+        // four strided instructions, cost the memory side four times the requests -- so a row passes through the group's
+        // slot of the (now idle) staging buffer first.
+        __syncthreads();
+        float *slot = s_rows + gi * C;
+#pragma unroll
+        for (int k = 0; k < RPG; ++k) {
+            const int r = gi + NG * k;
+            if (r >= LR || !((touched >> k) & 1u)) continue;
+            int sl = 0;
+#pragma unroll
+            for (int s = 1; s < kRegMaxL; ++s) sl += (s < L && r >= s_geo[8 * s + 4]) ? 1 : 0;
+            const int q = r - s_geo[8 * sl + 4], rw = s_geo[8 * sl + 2];
+            const int ly = q / rw, lx = q - ly * rw;
+            const int w = s_geo[8 * sl + 6];
+            float *dst = a.s.grad_feat + ((size_t)cam * a.s.num_feat + s_geo[8 * sl + 7] + (size_t)(s_geo[8 * sl + 1] + ly) * w + (s_geo[8 * sl] + lx)) * C + cl;
+            *reinterpret_cast<float4 *>(slot + c0) = acc[k];
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = slot[LPT * j + cl];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dst + LPT * j, v[j]);
+        }
+    }
+}
+
 static int bits_for(int n)
 {
     int b = 0;
@@ -715,6 +1121,7 @@ static int bits_for(int n)
 }
 
 struct DafSortPlan {
+    bool region_ok;   // the region-major accumulation applies (set by daf_region_plan)
     bool eligible;
     int cam_bits, lvl_bits, tile_rows, ntiles;
     unsigned long long max_taps, max_items;
@@ -737,12 +1144,17 @@ static DafSortPlan daf_sort_plan(int cams, int num_feat, int C, int L, int pts, 
                  p.max_taps < (1ull << 32) && ((unsigned long long)pts << id_bits) <= (1ull << 32);
     p.ntiles = (int)ntiles;
     p.max_items = p.max_taps / kDafChunk + ntiles + 1;
-    size_t off = 256;  // header
+    // the region-major accumulation (round 5): what the host can tell without the level sizes, which are device data
+    p.region_ok = p.eligible && L <= kRegMaxL && (lpt == 16 || lpt == 32) && L * G <= 16 && G <= 4;
+    // (one workspace serves both formulations: the region count is only known on the device, so its tables are sized for kDafMaxTiles)
+    const unsigned long long nt_max = p.region_ok ? std::max<unsigned long long>(ntiles, kDafMaxTiles) : ntiles;
+    const unsigned long long items_max = p.region_ok ? std::max<unsigned long long>(p.max_items, (unsigned long long)pts * cams / kRegItem + kDafMaxTiles + 1) : p.max_items;
+    size_t off = 256;  // header: [0] work items, [1] regions, [2] the region accumulation's item counter; the regions' geometry from byte 64
     auto take = [&](size_t n) { const size_t o = off; off += (n + 255) & ~(size_t)255; return o; };
-    p.off_M = take((size_t)kDafBucketWgs * ntiles * 4);
-    p.off_tile_start = take((ntiles + 1) * 4);
-    p.off_item_start = take((ntiles + 1) * 4);
-    p.off_item_tile = take(p.max_items * 4);
+    p.off_M = take((size_t)kDafBucketWgs * nt_max * 4);
+    p.off_tile_start = take((nt_max + 1) * 4);
+    p.off_item_start = take((nt_max + 1) * 4);
+    p.off_item_tile = take(items_max * 4);
     p.off_taps = take(p.max_taps * 4);
     p.bytes = off;
     return p;
@@ -905,11 +1317,26 @@ extern "C" int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, 
     sa.cams = num_cams; sa.num_feat = num_feat; sa.C = C; sa.L = L; sa.pts = num_pts; sa.G = G;
     sa.cam_bits = p.cam_bits; sa.lvl_bits = p.lvl_bits; sa.tile_rows = p.tile_rows; sa.ntiles = p.ntiles;
     sa.samples = (long long)num_pts * num_cams;
+    static_assert(sizeof(DafRegionGeom) <= 192, "the regions' geometry fits the workspace header");
+    const bool by_region = p.region_ok && getenv("GF_DAF_TILES") == nullptr;   // (GF_DAF_TILES=1: the tile formulation of round 1, for comparison)
     for (int b = 0; b < B; ++b) {
         sa.loc = sampling_location + (size_t)b * num_pts * num_cams * 2;
         sa.weights = weights + (size_t)b * num_pts * num_cams * L * G;
         sa.grad_out = grad_output + (size_t)b * num_pts * C;
         sa.grad_feat = grad_mc_ms_feat + (size_t)b * num_cams * num_feat * C;
+        if (by_region) {
+            DafRegionArgs ra{sa, reinterpret_cast<DafRegionGeom *>(ws + 64)};
+            hipLaunchKernelGGL(gf_daf_region_geom_kernel, dim3(1), dim3(64), 0, stream, ra);
+            hipLaunchKernelGGL(gf_daf_rbucket_kernel<false>, dim3(kDafBucketWgs), dim3(1024), 0, stream, ra);
+            hipLaunchKernelGGL(gf_daf_rcolscan_kernel, dim3((kDafMaxTiles * 8 + 255) / 256), dim3(256), 0, stream, sa);
+            hipLaunchKernelGGL(gf_daf_regionscan_kernel, dim3(1), dim3(1024), 0, stream, sa);
+            hipLaunchKernelGGL(gf_daf_rbucket_kernel<true>, dim3(kDafBucketWgs), dim3(1024), 0, stream, ra);
+            const unsigned rblocks = 256 * 2;   // persistent, item-strided: two 512-thread workgroups per CU (54 KB of LDS, <= 128 VGPRs)
+            if (lpp == 16) hipLaunchKernelGGL(gf_daf_raccumulate_kernel<16>, dim3(rblocks), dim3(512), 0, stream, ra);
+            else hipLaunchKernelGGL(gf_daf_raccumulate_kernel<32>, dim3(rblocks), dim3(512), 0, stream, ra);
+            GF_CHECK_LAUNCH();
+            continue;
+        }
         hipLaunchKernelGGL(gf_daf_bucket_kernel<false>, dim3(kDafBucketWgs), dim3(1024), 0, stream, sa);
         hipLaunchKernelGGL(gf_daf_colscan_kernel, dim3((p.ntiles * 8 + 255) / 256), dim3(256), 0, stream, sa);
         hipLaunchKernelGGL(gf_daf_tilescan_kernel, dim3(1), dim3(1024), 0, stream, sa);

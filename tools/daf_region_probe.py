@@ -1,0 +1,55 @@
+"""Development probe (GPU box): the region-major accumulation of the deformable aggregation backward (default) against the tile
+formulation (GF_DAF_TILES=1) -- gradients equal? times?   python tools/daf_region_probe.py [uniform|projected ...]"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+from gaussianformer_amd.deformable_aggregation import deformable_aggregation_backward
+from gaussianformer_amd.synthetic import make_daf_inputs
+
+dev = torch.device("cuda:0")
+pts = int(os.environ.get("GF_PROBE_PTS", "230400"))
+for dist in (sys.argv[1:] or ["projected", "uniform"]):
+    d = make_daf_inputs(num_pts=pts, seed=0)
+    feat, ss, st, loc, w = (torch.from_numpy(d[k]).to(dev) for k in ("mc_ms_feat", "spatial_shape", "scale_start_index", "sampling_location", "weights"))
+    if dist == "projected":
+        import bench_frame
+        from gaussianformer_amd.deformable_prepare import deformable_prepare
+        g = torch.Generator(device="cpu").manual_seed(1)
+        A = pts // 9
+        lo = torch.tensor(bench_frame.PC_RANGE[:3]); hi = torch.tensor(bench_frame.PC_RANGE[3:])
+        centre = lo + (hi - lo) * torch.rand(1, A, 3, generator=g)
+        offs = torch.tensor(bench_frame.FIX_SCALE + [[0.3, 0.3, 0.0], [-0.3, 0.3, 0.0]]) * 0.35
+        kp = (centre[:, :, None] + offs[None, None]).to(dev)
+        pm, wh = bench_frame.cameras(dev)
+        raw = torch.randn(1, A, 6, 4, 9, 4, generator=g).to(dev)
+        loc, w = deformable_prepare(kp, pm, wh, raw)
+        loc, w = loc.contiguous(), w.contiguous()
+    go = torch.randn(1, loc.shape[1], 128, device=dev)
+    out = {}
+    for mode in ("regions", "tiles"):
+        os.environ.pop("GF_DAF_TILES", None)
+        if mode == "tiles":
+            os.environ["GF_DAF_TILES"] = "1"
+        def run():
+            gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(loc), torch.zeros_like(w)
+            deformable_aggregation_backward(feat, ss, st, loc, w, go, gf, gl, gw)
+            return gf, gl, gw
+        res = run()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        out[mode] = (res, e0.elapsed_time(e1) / 10 * 1e3)
+    a, b = out["regions"][0][0].double(), out["tiles"][0][0].double()
+    err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+    same_rest = all(torch.equal(x, y) for x, y in zip(out["regions"][0][1:], out["tiles"][0][1:]))
+    print(f"{dist}: backward (three zero fills included) regions {out['regions'][1]:.0f} us, tiles {out['tiles'][1]:.0f} us; grad_mc_ms_feat max err / max {err:.2e} "
+          f"(max |grad| {float(b.abs().max()):.3e}); grad_loc / grad_weights equal {same_rest}; finite {bool(torch.isfinite(a).all())}", flush=True)
