@@ -715,11 +715,14 @@ __global__ __launch_bounds__(256) void gf_daf_accumulate_kernel(DafSortArgs a)
 // 118 MB of rows (profiles/traffic_daf_r04.json).  But the sixteen taps of a sample sit at ONE place of the image in every level.
 // So here the visible SAMPLES (point, camera) are bucketed by image region -- 8 x 8 pixels of level 0 and the pixels under them in
 // the coarser levels (+ the bilinear halo) -- and a work item is a region's samples (<= kRegItem): it stages 64 samples' grad_output
-// rows and weights in LDS at a time (each row is read from memory ONCE per sample), generates their taps, sorts them by pixel of
-// the region (<= kRegRows rows over all levels) and gives every row to a lane group that keeps the row's sum in REGISTERS across all
-// the item's samples; the sums leave as one atomic row add per (row, item).  The bucket passes move one id per sample instead of
-// sixteen per sample.
-constexpr int kRegRows = 192;     // pixel rows of a region over all levels (8 lane groups x 24 accumulators)
+// rows and weights in LDS at a time (each row is read from memory ONCE per sample, by LDS-DMA: the round trip passes under the
+// batch's tap generation), generates their taps, sorts them by pixel of the region (<= kRegRows rows over all levels) and gives
+// every row to a lane group that keeps the row's sum in REGISTERS across all the item's samples; the sums leave as one atomic row
+// add per (row, item), consecutive channels on consecutive lanes.  The bucket passes move one id per sample instead of sixteen.
+// Measured (tools/timeline_daf.py, profiles/daf_region_r05.txt): a batch of 64 samples takes a workgroup ~8-10 us, half of it the
+// row walks, which run at the LDS read rate (every tap reads its sample's 512-byte row); an item's header (claim, table entry,
+// ids, locations: four dependent round trips) ~6 us and its row adds ~4 us.
+constexpr int kRegRows = 192;     // pixel rows of a region over all levels (16 lane groups x 12 accumulators at C = 128)
 constexpr int kRegSub = 64;       // samples staged in LDS at a time
 constexpr int kRegItem = 512;     // samples per work item
 constexpr int kRegMaxL = 4;
@@ -851,46 +854,73 @@ __global__ __launch_bounds__(256) void gf_daf_rcolscan_kernel(DafSortArgs a)
     if (part == kParts - 1) a.tile_start[t] = incl;
 }
 
-// prefix over the regions and the work-item table: gf_daf_tilescan_kernel with items of kRegItem samples
+// prefix over the regions and the work-item table.  Items hold up to kRegItem samples of one region; the table lists the FULL
+// items first and the regions' remainders after them, both in region order (the accumulation claims items in table order: full
+// ones at the end left their workgroups working alone; a finer ordering by size balanced better and lost as much again to the
+// scattered row adds of items that are no longer neighbours in the image).  An entry is region | chunk << 16.
 __global__ __launch_bounds__(1024) void gf_daf_regionscan_kernel(DafSortArgs a_)
 {
     DafSortArgs a = a_;
     a.ntiles = (int)a.header[1];
-    __shared__ uint32_t s_t[1024], s_i[1024];
+    __shared__ uint32_t s_t[1024], s_f[1024], s_p[1024];
     const int tid = threadIdx.x;
     const int per = (a.ntiles + 1023) / 1024;
     const int t0 = min(a.ntiles, tid * per), t1 = min(a.ntiles, t0 + per);
-    uint32_t st = 0, si = 0;
+    uint32_t st = 0, sf = 0, sp = 0;
     for (int t = t0; t < t1; ++t) {
         const uint32_t c = a.tile_start[t];
         st += c;
-        si += (c + kRegItem - 1) / kRegItem;
+        sf += c / kRegItem;
+        sp += c % kRegItem ? 1u : 0u;
     }
-    s_t[tid] = st; s_i[tid] = si;
+    s_t[tid] = st; s_f[tid] = sf; s_p[tid] = sp;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t ut = tid >= d ? s_t[tid - d] : 0u, ui = tid >= d ? s_i[tid - d] : 0u;
+        const uint32_t ut = tid >= d ? s_t[tid - d] : 0u, uf = tid >= d ? s_f[tid - d] : 0u, up = tid >= d ? s_p[tid - d] : 0u;
         __syncthreads();
-        s_t[tid] += ut; s_i[tid] += ui;
+        s_t[tid] += ut; s_f[tid] += uf; s_p[tid] += up;
         __syncthreads();
     }
-    uint32_t run_t = s_t[tid] - st, run_i = s_i[tid] - si;
+    const uint32_t nfull = s_f[1023];
+    uint32_t run_t = s_t[tid] - st, run_f = s_f[tid] - sf, run_p = nfull + s_p[tid] - sp;
     for (int t = t0; t < t1; ++t) {
         const uint32_t c = a.tile_start[t];
-        const uint32_t ni = (c + kRegItem - 1) / kRegItem;
+        const uint32_t nf = c / kRegItem;
         a.tile_start[t] = run_t;
-        a.item_start[t] = run_i;
-        for (uint32_t i = 0; i < ni; ++i) a.item_tile[run_i + i] = (uint32_t)t;
+        for (uint32_t i = 0; i < nf; ++i) a.item_tile[run_f + i] = (uint32_t)t | (i << 16);
+        if (c % kRegItem) a.item_tile[run_p++] = (uint32_t)t | (nf << 16);
         run_t += c;
-        run_i += ni;
+        run_f += nf;
     }
     if (tid == 1023) {
         a.tile_start[a.ntiles] = s_t[1023];
-        a.item_start[a.ntiles] = s_i[1023];
-        a.header[0] = s_i[1023];
+        a.header[0] = nfull + s_p[1023];
         a.header[2] = 0u;   // the accumulation's item counter
     }
 }
+
+// memory -> LDS without passing registers (M0 = the wave's LDS base; lane i lands at base + i * size).  Issued from asm: the
+// compiler waits for every outstanding load before the next LDS access when it can see one of these in flight.
+__device__ __forceinline__ void daf_lds_dma16(const void *g, const void *l)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"((uint32_t)(uintptr_t)l) : "memory", "m0");
+}
+__device__ __forceinline__ void daf_lds_dma4(const void *g, const void *l)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"((uint32_t)(uintptr_t)l) : "memory", "m0");
+}
+
+#ifdef GF_DAF_TL
+__device__ unsigned long long gf_daf_tl[8 * 16384];   // development: per item, wall-clock stamps of the accumulation's phases
+#define GF_DAF_STAMP(i) do { if (tid == 0 && item < 16384u) gf_daf_tl[8 * item + (i)] = wall_clock64(); } while (0)
+#else
+#define GF_DAF_STAMP(i) do { } while (0)
+#endif
+#ifdef GF_DAF_TL
+#define GF_DAF_PH(i) do { const unsigned long long now_ = wall_clock64(); ph[i] += now_ - phl; phl = now_; } while (0)
+#else
+#define GF_DAF_PH(i) do { } while (0)
+#endif
 
 template <int LPT>
 __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArgs a)
@@ -901,16 +931,15 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
     constexpr int C = 4 * LPT;
     constexpr int TAPS = kRegSub * 4 * kRegMaxL;      // taps of a staged batch
     constexpr int PER = TAPS / T;
-    constexpr int SPG = kRegSub / NG;                 // samples whose rows a lane group stages per batch
-    static_assert(TAPS % T == 0 && kRegSub % NG == 0 && (kRegSub * 16) % T == 0, "shapes");
+    static_assert(TAPS % T == 0 && kRegSub % (T / 64) == 0 && (kRegSub / (T / 64)) % 4 == 0, "shapes");
     __shared__ __attribute__((aligned(16))) float s_rows[kRegSub * C];
     __shared__ float s_w[kRegSub * 16];               // [sample][level][group] (L * G <= 16)
     __shared__ uint32_t s_sid[kRegItem];              // the item's samples ...
     __shared__ float2 s_loc[kRegItem];                // ... and their sampling locations
-    __shared__ uint32_t s_key[TAPS];                  // sorted taps: byte offset of the sample's staged row
+    __shared__ uint32_t s_key[TAPS];                // sorted taps: byte offset of the sample's staged row
     __shared__ __attribute__((aligned(16))) float s_cw[TAPS * 4];   // ... and bilinear coefficient x weight, per group (G <= 4)
     __shared__ uint32_t s_item;
-    __shared__ uint32_t s_cnt[kRegRows + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[2][kRegRows + 4];       // row counts / offsets of the batch; the other half is zeroed for the next
     __shared__ int s_geo[8 * kRegMaxL];               // per level: x0, y0, rw, rh, roff, h, w, scale_start (read by runtime level)
     const int tid = threadIdx.x;
     const int gi = tid / LPT, cl = tid - gi * LPT;
@@ -931,8 +960,9 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
         __syncthreads();
         const uint32_t item = s_item;
         if (item >= nitems) break;
-        const uint32_t reg = a.s.item_tile[item];
-        const uint32_t chunk = item - a.s.item_start[reg];
+        GF_DAF_STAMP(0);
+        const uint32_t entry = a.s.item_tile[item];
+        const uint32_t reg = entry & 0xffffu, chunk = entry >> 16;
         const uint32_t seg1 = a.s.tile_start[reg + 1];
         const uint32_t t0 = a.s.tile_start[reg] + chunk * kRegItem, t1 = min(seg1, t0 + kRegItem);
         const int nitem = (int)(t1 - t0);
@@ -948,47 +978,53 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
             s_geo[8 * s + 5] = a.s.spatial_shape[2 * s]; s_geo[8 * s + 6] = a.s.spatial_shape[2 * s + 1]; s_geo[8 * s + 7] = a.s.scale_start[s];
         }
         // the item's sample ids and locations (clamped: slots past the end repeat the last sample and are never used as taps)
-        {
-            const uint32_t sid = a.s.taps[min(t0 + (uint32_t)tid, t1 - 1)];
+#pragma unroll
+        for (int u = 0; u < kRegItem / T; ++u) {
+            const uint32_t sid = a.s.taps[min(t0 + (uint32_t)(tid + T * u), t1 - 1)];
             const size_t sample = (size_t)(sid >> a.s.cam_bits) * a.s.cams + (sid & cam_mask);
-            s_sid[tid] = sid;
-            s_loc[tid] = *reinterpret_cast<const float2 *>(a.s.loc + 2 * sample);
+            s_sid[tid + T * u] = sid;
+            s_loc[tid + T * u] = *reinterpret_cast<const float2 *>(a.s.loc + 2 * sample);
         }
-        static_assert(kRegItem == T, "one sample id per thread");
+        static_assert(kRegItem % T == 0, "sample ids per thread");
+        if (tid <= kRegRows + 1) s_cnt[0][tid] = 0u;
         __syncthreads();
         float4 acc[RPG];
 #pragma unroll
         for (int k = 0; k < RPG; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t touched = 0u;   // rows of the group that received a tap
-        // The grad_output rows and weights of a batch of kRegSub samples are REQUESTED one batch ahead, into registers: their
-        // round trip travels under the previous batch's sort and row walks.
-        float4 prow[SPG];
-        float pw[kRegSub * 16 / T];
-        auto prefetch = [&](int b0) __attribute__((always_inline)) {
+        // The grad_output rows and weights of a batch travel from memory straight into LDS (no registers, nobody waits at the
+        // request): requested when the batch starts, the weights awaited before the scatter that multiplies them in, the rows
+        // before the row walks -- their round trip passes under the batch's tap generation and sort.
+        auto request = [&](int b0) __attribute__((always_inline)) {
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            constexpr int SPW = kRegSub / (T / 64);   // samples per wave
 #pragma unroll
-            for (int u = 0; u < SPG; ++u) {
-                const uint32_t pt = s_sid[min(b0 + gi + NG * u, kRegItem - 1)] >> a.s.cam_bits;
-                prow[u] = *reinterpret_cast<const float4 *>(a.s.grad_out + (size_t)pt * C + c0);
-            }
-#pragma unroll
-            for (int u = 0; u < kRegSub * 16 / T; ++u) {
-                const int i = tid + T * u, sm = i >> 4, j = i & 15;
+            for (int u = 0; u < SPW / 4; ++u) {       // weights: 16 slots per sample, four samples per request
+                const int sm = wv * SPW + 4 * u + (lane >> 4), j = lane & 15;
                 const uint32_t sid = s_sid[min(b0 + sm, kRegItem - 1)];
                 const size_t sample = (size_t)(sid >> a.s.cam_bits) * a.s.cams + (sid & cam_mask);
-                pw[u] = a.s.weights[sample * lg + min(j, lg - 1)];
+                daf_lds_dma4(a.s.weights + sample * lg + min(j, lg - 1), s_w + (wv * SPW + 4 * u) * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < SPW / (64 / LPT); ++u) {   // rows: 64 / LPT samples per request
+                const int sm = wv * SPW + u * (64 / LPT) + lane / LPT;
+                const uint32_t pt = s_sid[min(b0 + sm, kRegItem - 1)] >> a.s.cam_bits;
+                daf_lds_dma16(a.s.grad_out + (size_t)pt * C + c0, s_rows + (wv * SPW + u * (64 / LPT)) * C);
             }
         };
-        prefetch(0);
+        GF_DAF_STAMP(1);
+#ifdef GF_DAF_TL
+        unsigned long long ph[5] = {0, 0, 0, 0, 0}, phl = wall_clock64();
+#endif
+#ifdef GF_DAF_TL
+        if (tid == 0 && item < 16384u) { gf_daf_tl[8 * item + 4] = (unsigned long long)nitem | ((unsigned long long)blockIdx.x << 32); gf_daf_tl[8 * item + 5] = reg; }
+#endif
         for (int b0 = 0; b0 < nitem; b0 += kRegSub) {
             const int ns = min(kRegSub, nitem - b0);
+            uint32_t *cnt = s_cnt[(b0 / kRegSub) & 1], *cnt_next = s_cnt[((b0 / kRegSub) & 1) ^ 1];
             __syncthreads();   // the previous batch has been consumed
-#pragma unroll
-            for (int u = 0; u < SPG; ++u) *reinterpret_cast<float4 *>(s_rows + (gi + NG * u) * C + c0) = prow[u];
-#pragma unroll
-            for (int u = 0; u < kRegSub * 16 / T; ++u) s_w[tid + T * u] = pw[u];
-            if (tid <= kRegRows + 1) s_cnt[tid] = 0u;
-            __syncthreads();
-            if (b0 + kRegSub < nitem) prefetch(b0 + kRegSub);
+            request(b0);
+            GF_DAF_PH(0);
             // ---- taps of the batch: coefficient, local row, rank within the row
             uint32_t tkey[PER], rank[PER];
             int lrow[PER];
@@ -1011,7 +1047,7 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
                         if (lx >= 0 && lx < rw && ly >= 0 && ly < s_geo[8 * sl + 3]) {
                             lrow[j] = s_geo[8 * sl + 4] + ly * rw + lx;
                             tkey[j] = (uint32_t)sm | ((uint32_t)sl << 8);
-                            rank[j] = atomicAdd(&s_cnt[lrow[j]], 1u);
+                            rank[j] = atomicAdd(&cnt[lrow[j]], 1u);
                         } else {
                             // outside the rectangle the region's geometry promises (pyramids whose rectangles were capped; never
                             // with the reference's): kept correct, not fast -- the tap's contribution goes straight to its pixel row
@@ -1026,8 +1062,9 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
                 }
             }
             __syncthreads();
+            GF_DAF_PH(1);
             if (tid < 64) {   // exclusive scan of the <= 192 row counts: three per lane
-                const uint32_t ca = s_cnt[3 * tid], cb = s_cnt[3 * tid + 1], cc = s_cnt[3 * tid + 2];
+                const uint32_t ca = cnt[3 * tid], cb = cnt[3 * tid + 1], cc = cnt[3 * tid + 2];
                 uint32_t incl = ca + cb + cc;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
@@ -1035,16 +1072,19 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
                     if (tid >= d) incl += up;
                 }
                 const uint32_t excl = incl - (ca + cb + cc);
-                s_cnt[3 * tid] = excl;
-                s_cnt[3 * tid + 1] = excl + ca;
-                s_cnt[3 * tid + 2] = excl + ca + cb;
-                if (tid == 63) s_cnt[kRegRows] = incl;
+                cnt[3 * tid] = excl;
+                cnt[3 * tid + 1] = excl + ca;
+                cnt[3 * tid + 2] = excl + ca + cb;
+                if (tid == 63) cnt[kRegRows] = incl;
             }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRegSub / (T / 64) / (64 / LPT)) : "memory");   // the weights have landed
             __syncthreads();
+            if (tid <= kRegRows + 1) cnt_next[tid] = 0u;   // (last read by the previous batch's row walks)
+            GF_DAF_PH(2);
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 if (lrow[j] < 0) continue;
-                const uint32_t pos = s_cnt[lrow[j]] + rank[j];
+                const uint32_t pos = cnt[lrow[j]] + rank[j];
                 const int sm = (int)(tkey[j] & 255u), sl = (int)(tkey[j] >> 8);
                 s_key[pos] = (uint32_t)(sm * C * 4);
                 // top_grad = grad_output * weight (:84), then the bilinear coefficient (:92-110): the two scalars multiplied here, once
@@ -1055,16 +1095,19 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
                 v.w = G > 3 ? cw[j] * s_w[sm * 16 + sl * G + 3] : 0.f;
                 *reinterpret_cast<float4 *>(s_cw + 4 * pos) = v;
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows have landed
             __syncthreads();
-            // ---- every lane group walks the taps of ITS rows: sums stay in registers across the item's batches
+            GF_DAF_PH(3);
+            // ---- every lane group walks the taps of ITS rows: sums stay in registers across the item's batches.  (What bounds
+            // this phase is LDS bandwidth: every tap reads its sample's staged row, 16 B per lane.)
             const char *rows_b = reinterpret_cast<const char *>(s_rows) + 4 * c0;
             const float *cw_g = s_cw + group;
 #pragma unroll
             for (int k = 0; k < RPG; ++k) {
                 const int r = gi + NG * k;
                 if (r >= LR) continue;
-                uint32_t pb = s_cnt[r];
-                const uint32_t p1 = s_cnt[r + 1];
+                uint32_t pb = cnt[r];
+                const uint32_t p1 = cnt[r + 1];
                 touched |= (p1 > pb ? 1u : 0u) << k;
                 for (; pb + 4 <= p1; pb += 4) {
                     uint32_t key[4];
@@ -1085,12 +1128,18 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
                     acc[k].x += wt * go.x; acc[k].y += wt * go.y; acc[k].z += wt * go.z; acc[k].w += wt * go.w;
                 }
             }
+            GF_DAF_PH(4);
         }
         // ---- the item's row sums: one atomic row add each (rows of neighbouring regions' halos and of a region's other items
         // overlap).  The adds are issued with CONSECUTIVE channels on consecutive lanes -- a lane's four channels, added as
         // four strided instructions, cost the memory side four times the requests -- so a row passes through the group's
         // slot of the (now idle) staging buffer first.
         __syncthreads();
+        GF_DAF_STAMP(2);
+#ifdef GF_DAF_TL
+        if (tid == 0 && item < 16384u) gf_daf_tl[8 * item + 6] = (ph[0] & 0xffff) | ((ph[1] & 0xffff) << 16) | ((ph[2] & 0xffff) << 32) | ((ph[3] & 0xffff) << 48);
+        if (tid == 0 && item < 16384u) gf_daf_tl[8 * item + 7] = ph[4];
+#endif
         float *slot = s_rows + gi * C;
 #pragma unroll
         for (int k = 0; k < RPG; ++k) {
@@ -1110,8 +1159,20 @@ __global__ __launch_bounds__(512, 4) void gf_daf_raccumulate_kernel(DafRegionArg
 #pragma unroll
             for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dst + LPT * j, v[j]);
         }
+#ifdef GF_DAF_TL
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        GF_DAF_STAMP(3);
+#endif
     }
 }
+
+#ifdef GF_DAF_TL
+extern "C" int gf_debug_daf_timeline(unsigned long long *host, int words)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gf_daf_tl), (size_t)words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 static int bits_for(int n)
 {
@@ -1145,7 +1206,7 @@ static DafSortPlan daf_sort_plan(int cams, int num_feat, int C, int L, int pts, 
     p.ntiles = (int)ntiles;
     p.max_items = p.max_taps / kDafChunk + ntiles + 1;
     // the region-major accumulation (round 5): what the host can tell without the level sizes, which are device data
-    p.region_ok = p.eligible && L <= kRegMaxL && (lpt == 16 || lpt == 32) && L * G <= 16 && G <= 4;
+    p.region_ok = p.eligible && L <= kRegMaxL && (lpt == 16 || lpt == 32) && L * G <= 16 && G <= 4 && (unsigned long long)pts * cams / kRegItem < 65536ull && kDafMaxTiles <= 65536;   // (the item table packs region | chunk << 16)
     // (one workspace serves both formulations: the region count is only known on the device, so its tables are sized for kDafMaxTiles)
     const unsigned long long nt_max = p.region_ok ? std::max<unsigned long long>(ntiles, kDafMaxTiles) : ntiles;
     const unsigned long long items_max = p.region_ok ? std::max<unsigned long long>(p.max_items, (unsigned long long)pts * cams / kRegItem + kDafMaxTiles + 1) : p.max_items;
