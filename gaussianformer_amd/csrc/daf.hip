@@ -355,6 +355,24 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
             const long long wi = wbase + (long long)(cam * a.L + s) * a.G;
             const float wt = a.weights[wi];
             float gw = 0.f, gh_part = 0.f, gw_part = 0.f;
+            if constexpr (!FEAT) {
+                // The three sums over the channels (:119-121) are linear in the corner values, and with w1 + .. + w4 = 1 they
+                // need four dot products, taken on corner DIFFERENCES (neighbouring pixels are close: differencing after the
+                // summation would cancel):  s1 = go.v1, sa = go.(v2 - v1), sb = go.(v4 - v3), sc = go.(v3 - v1)
+                //   value        = v1 + lw (v2 - v1) + lh (v3 - v1) + lh lw ((v4 - v3) - (v2 - v1))
+                //   d value / dw = hh (v2 - v1) + lh (v4 - v3)          d value / dh = hw (v3 - v1) + lw (v4 - v2)
+                // (corners outside the image hold zeros: the reference's `if (ok)` terms vanish the same way)
+                float s1 = 0.f, sa = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float d21 = v2[j] - v1[j], d43 = v4[j] - v3[j], d31 = v3[j] - v1[j];
+                    s1 += go[j] * v1[j]; sa += go[j] * d21; sb += go[j] * d43; sc += go[j] * d31;
+                }
+                const float sd = sc + (sb - sa);                       // go.(v4 - v2)
+                gw = s1 + t.lw * sa + t.lh * (sc + t.lw * (sb - sa));  // :119
+                gw_part = w * wt * (t.hh * sa + t.lh * sb);            // :120 (top = go * weight, :84)
+                gh_part = h * wt * (t.hw * sc + t.lw * sd);            // :121
+            } else
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float top = go[j] * wt;  // top_grad_mc_ms_feat, :84
