@@ -568,3 +568,45 @@ def test_forward_and_backward_are_reproducible_bit_for_bit_at_the_full_shape(gpu
             ref = cur
         else:
             assert all(torch.equal(a, b) for a, b in zip(cur, ref))
+
+
+# Round 5: three more organisations of the matrix-core forward, kept behind development switches (the wave kernel stayed the
+# fastest: DESIGN round 5).  They take a double brick's hits in blocks of 32 like the wave kernel but fold the opacity into the
+# exponent, so they agree with it to rounding, not bit for bit.
+_EXPERIMENTAL = [
+    ("pair", {"GF_MFMA_PAIR": "1"}, 0, "GF_PATH_MATRIX_CORE_PAIR"),
+    ("solo", {"GF_MFMA_SOLO": "1"}, 0, "GF_PATH_MATRIX_CORE_SOLO"),
+    ("solo, three waves per SIMD", {"GF_MFMA_SOLO": "1", "GF_SOLO_WAVES": "3"}, 0, "GF_PATH_MATRIX_CORE_SOLO"),
+    ("fused records pass", {"GF_FUSED": "1"}, 1, "GF_PATH_MATRIX_CORE_SOLO"),
+]
+
+
+@pytest.mark.parametrize("name,env,assume_dense,path", _EXPERIMENTAL)
+def test_mfma_development_kernels_match_the_oracle_and_repeat_themselves(gpu, name, env, assume_dense, path, monkeypatch):
+    from gaussianformer_amd import _lib
+    for k in ("GF_MFMA_PAIR", "GF_MFMA_SOLO", "GF_SOLO_WAVES", "GF_FUSED", "GF_MFMA_TILE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    flags = _lib.GF_MFMA_SPLAT | (_lib.GF_PTS_ASSUME_DENSE if assume_dense else 0)
+    shapes = [dict(), dict(P=300, H=16, W=16, D=8), dict(P=2000, H=40, W=40, D=16), dict(P=777, H=20, W=36, D=12),
+              dict(P=64, H=8, W=8, D=4), dict(P=1, H=8, W=8, D=8), dict(P=3000, H=30, W=50, D=16)]
+    for seed, kw in enumerate(shapes):
+        si = make_splat_inputs("nuscenes_gs25600_solid", seed=seed + 1, **kw)
+        pi, mi, radii, cov6 = prep(si)
+        got, _, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
+        words = state[:12].view(torch.int32).cpu().tolist()
+        assert words[1] == getattr(_lib, path), (name, kw, words[:3])
+        assert np.isfinite(got["logits"]).all()
+        ref = _oracle_logits(si, pi, mi, radii, cov6) if kw else None
+        if ref is None:   # the full shape: the wave kernel (itself held to the oracle above) stands in for the CPU oracle
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+            ref = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)[0]["logits"]
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            assert_logits_close(got["logits"], ref, tol=5e-5)
+        else:
+            assert_logits_close(got["logits"], ref, tol=1e-4)
+        again, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
+        assert np.array_equal(got["logits"], again["logits"]), (name, kw)

@@ -22,7 +22,7 @@ configs = args or ["nuscenes_gs25600_solid"]
 
 
 def run(si, flags, env=None, steps=0):
-    for k in ("GF_MFMA_SOLO", "GF_MFMA_TILE", "GF_MFMA_PAIR", "GF_SOLO_WAVES", "GF_NO_FUSED"):
+    for k in ("GF_MFMA_SOLO", "GF_MFMA_TILE", "GF_MFMA_PAIR", "GF_SOLO_WAVES", "GF_FUSED"):
         os.environ.pop(k, None)
     if env:
         for e in env.split(","):
@@ -68,7 +68,7 @@ for config, kw in cases:
     si = make_splat_inputs(config, seed=kw.pop("seed", 0), **kw)
     steps = 200 if not kw else 0
     res = {}
-    for name, flags, env in (("fused", 1, None), ("fused3", 1, "GF_SOLO_WAVES=3"), ("solo", 0, "GF_MFMA_SOLO"), ("solo3", 0, "GF_MFMA_SOLO,GF_SOLO_WAVES=3"), ("wave", 0, None), ("wave_dense", 1, "GF_NO_FUSED"), ("exact", _lib.GF_EXACT_FP32, None)):
+    for name, flags, env in (("fused", 1, "GF_FUSED"), ("fused3", 1, "GF_FUSED,GF_SOLO_WAVES=3"), ("solo", 0, "GF_MFMA_SOLO"), ("solo3", 0, "GF_MFMA_SOLO,GF_SOLO_WAVES=3"), ("wave", 0, None), ("wave_dense", 1, None), ("exact", _lib.GF_EXACT_FP32, None)):
         res[name] = run(si, flags, env, steps if name != "exact" else 0)
     print(f"{config} P={si.means3D.shape[0]} grid {si.H}x{si.W}x{si.D}: " + "; ".join(f"{k} path {v[1][1]} bits {v[1][2]:#x} repro {v[3]}" + (f" {v[2]:.2f} us" if v[2] else "") for k, v in res.items()), flush=True)
     ex = res["exact"][0]
