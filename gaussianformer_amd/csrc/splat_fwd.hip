@@ -2736,8 +2736,8 @@ __global__ void gf_xcc_census_kernel(uint32_t *out)
 {
     if (threadIdx.x == 0) out[blockIdx.x] = (uint32_t)physical_xcc();
 }
-// One-time check of what the fused forward's work partition relies on for COVERAGE (not for coherence): workgroup b runs on XCD
-// b % 8, so every XCD receives waves of any grid that is a multiple of 8.  HIP does not promise it; a device where the census
+// One-time check of what the fused forward's work partition relies on for COVERAGE (not for coherence): workgroups are dealt to the
+// XCDs round-robin (workgroup b on XCD (b + c) % 8), so every eight consecutive workgroups of a grid cover the eight XCDs.  HIP does not promise it; a device where the census
 // fails keeps the two-launch forward.  (Synchronises once, at the first call that could fuse.)
 static bool xcc_census_ok()
 {
@@ -2748,10 +2748,13 @@ static bool xcc_census_ok()
         constexpr int kBlocks = 256;
         if (hipMalloc(&d, kBlocks * sizeof(uint32_t)) == hipSuccess) {
             uint32_t h[kBlocks];
+            (void)hipDeviceSynchronize();   // (once: with other kernels in flight the dispatcher does not start a grid at XCD 0)
             hipLaunchKernelGGL(gf_xcc_census_kernel, dim3(kBlocks), dim3(64), 0, 0, d);
             if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
                 bool ok = true;
-                for (int b = 0; b < kBlocks; ++b) ok = ok && h[b] == (uint32_t)(b & 7);
+                // (any rotation: the dispatcher's round-robin position carries over from the previous grid; what the fused pass
+                // needs is that every eight consecutive workgroups cover the eight XCDs)
+                for (int b = 0; b < kBlocks; ++b) ok = ok && h[b] < 8u && h[b] == ((h[0] + (uint32_t)b) & 7u);
                 state = ok ? 1 : -1;
             }
             (void)hipFree(d);
@@ -2858,6 +2861,10 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
                        getenv("GF_MFMA_PAIR") == nullptr && getenv("GF_MFMA_TILE") == nullptr && getenv("GF_MFMA_WAVE") == nullptr &&
                        !lab.labels && pa.unit_totals == nullptr && ws.nrow <= kPRowMax && (D & 3) == 0 && P < (1 << 16) &&
                        !stream_is_capturing(stream) && xcc_census_ok();
+    if (!fused && getenv("GF_FUSED") != nullptr && getenv("GF_FUSED_WHY") != nullptr)   // development: which precondition said no
+        fprintf(stderr, "GF_FUSED not taken: mfma %d verify %d zeroed %d x_records %d labels %d unit_totals %d nrow %d D %d P %d capturing %d census %d\n",
+                (int)mfma, (int)verify, (int)((flags & GF_WORKSPACE_ZEROED) != 0), (int)(ws.x_records != nullptr), (int)(lab.labels != nullptr),
+                (int)(pa.unit_totals != nullptr), ws.nrow, D, P, (int)stream_is_capturing(stream), (int)xcc_census_ok());
     const int prep_grid = fused ? 0 : pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +

@@ -9,6 +9,8 @@ and error behaviour as
 so ``GaussianHead`` (model/head/gaussian_head.py:30-39) can import these unchanged.
 The compute goes through the C ABI of ``libgf_hip.so``; there is no CPU path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -32,10 +34,26 @@ class _Workspace:
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = cls._cache.pop(key, None)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)   # (zeroed once: GF_WORKSPACE_ZEROED)
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         cls._cache[key] = buf              # most recently used last
         while len(cls._cache) > cls.MAX_STREAMS:
             cls._cache.pop(next(iter(cls._cache)))
+        cls._uses += 1
+        return buf
+
+    _zeroed = {}
+
+    @classmethod
+    def get_zeroed(cls, device, nbytes, shape):
+        """A buffer of its own per (stream, problem shape), zeroed when created and never handed to another shape: what
+        ``GF_WORKSPACE_ZEROED`` promises (the development switch GF_FUSED=1 needs it: its flags and counters are tagged per
+        launch instead of being reset, which only holds in memory no other layout has written)."""
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, nbytes, shape)
+        buf = cls._zeroed.get(key)
+        if buf is None:
+            if len(cls._zeroed) >= cls.MAX_STREAMS:
+                cls._zeroed.pop(next(iter(cls._zeroed)))
+            buf = cls._zeroed[key] = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         cls._uses += 1
         return buf
 
@@ -127,10 +145,14 @@ def splat_forward(variant, pts, points_int, means3D, means3D_int, opacities, sem
         probability = torch.empty(N, dtype=f32, device=dev)
     state = torch.empty(lib.gf_splat_state_bytes(), dtype=torch.uint8, device=dev)
     nbytes = lib.gf_splat_workspace_bytes(P, N, H, W, D)
-    ws = _Workspace.get(dev, nbytes)
+    if os.environ.get("GF_FUSED"):   # development switch: see _Workspace.get_zeroed
+        ws = _Workspace.get_zeroed(dev, nbytes, (P, N, H, W, D))
+        flags |= _lib.GF_WORKSPACE_ZEROED
+    else:
+        ws = _Workspace.get(dev, nbytes)
     with torch.cuda.device(dev):
         rc = lib.gf_splat_forward(
-            variant, per_axis, flags | _lib.GF_WORKSPACE_ZEROED, P, N, C, H, W, D,
+            variant, per_axis, flags, P, N, C, H, W, D,
             _lib.ptr(pts), _lib.ptr(points_int), _lib.ptr(means3D), _lib.ptr(means3D_int), _lib.ptr(opacities),
             _lib.ptr(semantics), _lib.ptr(radii), _lib.ptr(cov3D),
             _lib.ptr(logits), _lib.ptr(bin_logits), _lib.ptr(density), _lib.ptr(probability), _lib.ptr(state),
