@@ -40,6 +40,9 @@ struct DafArgs {
 
 template <int VEC>
 struct VecT;
+struct alignas(16) Float8 { float4 lo, hi; };
+template <>
+struct VecT<8> { using type = Float8; };
 template <>
 struct VecT<4> { using type = float4; };
 template <>
@@ -285,6 +288,17 @@ __device__ __forceinline__ float sum8_last(float v)  // valid in lanes with (lan
     return dpp_add<0x114>(v);  // row_shr:4
 }
 
+__device__ __forceinline__ float sum4_last(float v)  // valid in lanes with (lane & 3) == 3
+{
+    v = dpp_add<0x111>(v);  // row_shr:1
+    return dpp_add<0x112>(v);  // row_shr:2
+}
+
+__device__ __forceinline__ float sum16_last(float v)  // valid in lanes with (lane & 15) == 15 (a DPP row)
+{
+    return dpp_add<0x118>(sum8_last(v));  // row_shr:8
+}
+
 __device__ __forceinline__ float sum32_last(float v)  // valid in lanes 31 and 63
 {
     v = dpp_add<0x118>(sum8_last(v));  // row_shr:8 -> lane 15 of each row holds the row
@@ -318,6 +332,7 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
     }
     const int lane = lane_id();
     const bool dpp = REDUCE && lpg == 8 && lpp == 32;  // kernel-uniform
+    const bool dpp16 = REDUCE && lpg == 4 && lpp == 16;  // eight channels per lane at the nuScenes layout: a point is one DPP row
     // the three streams never alias; say so, or every gradient store fences the feature gathers
     const float *__restrict__ feat = a.feat;
     float *__restrict__ grad_weights = a.grad_weights;
@@ -404,16 +419,16 @@ __global__ __launch_bounds__(256) void gf_daf_bwd_kernel(DafArgs a, int lpg, int
 #pragma unroll
             for (int q = 0; q < kDeferLevels; ++q) {
                 if (q >= a.L) break;
-                const float gw = dpp ? sum8_last(gw_level[q]) : group_sum(gw_level[q], lpg);
-                const bool writer = dpp ? (lane & 7) == 7 : (lane & (lpg - 1)) == 0;
+                const float gw = dpp ? sum8_last(gw_level[q]) : dpp16 ? sum4_last(gw_level[q]) : group_sum(gw_level[q], lpg);
+                const bool writer = dpp ? (lane & 7) == 7 : dpp16 ? (lane & 3) == 3 : (lane & (lpg - 1)) == 0;
                 if (writer && active) grad_weights[wbase + (long long)(cam * a.L + q) * a.G] = gw;
             }
         }
         float *gl = grad_loc + (bp * a.cams + cam) * 2;
         if (REDUCE) {
-            gl_w = dpp ? sum32_last(gl_w) : group_sum(gl_w, lpp);
-            gl_h = dpp ? sum32_last(gl_h) : group_sum(gl_h, lpp);
-            const bool writer = dpp ? (lane & 31) == 31 : (lane & (lpp - 1)) == 0;
+            gl_w = dpp ? sum32_last(gl_w) : dpp16 ? sum16_last(gl_w) : group_sum(gl_w, lpp);
+            gl_h = dpp ? sum32_last(gl_h) : dpp16 ? sum16_last(gl_h) : group_sum(gl_h, lpp);
+            const bool writer = dpp ? (lane & 31) == 31 : dpp16 ? (lane & 15) == 15 : (lane & (lpp - 1)) == 0;
             if (writer && active) { gl[0] = gl_w; gl[1] = gl_h; }
         } else {
             unsafeAtomicAdd(gl, gl_w);
@@ -1282,6 +1297,12 @@ static int daf_forward_impl(bool pin_groups, int B, int num_cams, int num_feat, 
         const long long npts = (long long)B * num_pts, chunks = (npts + 31) / 32;
         const int chunks_per_sub = (int)((chunks + nsub - 1) / nsub);
         hipLaunchKernelGGL(gf_daf_fwd_grouped_kernel<8>, dim3((unsigned)(8 * chunks_per_sub)), dim3(256), 0, stream, a, chunks_per_sub);
+    } else if (vec == 4 && num_cams <= 8 && C % 8 == 0 && (C / G) % 8 == 0 && getenv("GF_DAF_VEC4") == nullptr) {
+        // eight channels per lane (bit-identical: the arithmetic per channel is unchanged): the tap geometry of a (point, camera,
+        // level) is computed by every lane of the point, so half the lanes per point is half of that work -- 139 -> 117 us with
+        // projected geometry at 230 400 points, where the kernel is bound by vector-ALU issue (uniform locations: unchanged)
+        a.total = (long long)B * num_pts * (C / 8);
+        hipLaunchKernelGGL(gf_daf_fwd4_kernel<8>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a);
     } else if (vec == 4 && num_cams <= 8 && getenv("GF_DAF_PLAIN") == nullptr)
         hipLaunchKernelGGL(gf_daf_fwd4_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else if (vec == 4) hipLaunchKernelGGL(gf_daf_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
@@ -1382,7 +1403,13 @@ extern "C" int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, 
     const long long blocks = (a.total + 255) / 256;
     GF_CHECK_ARG(blocks < (1ll << 31), "problem too large");
     const int lpp = C / 4, lpg = (C / G) / 4;
-    if (is_pow2(lpg)) hipLaunchKernelGGL((gf_daf_bwd_kernel<4, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, lpg, lpp);
+    // eight channels per lane where the layout allows (both kernels are bound by vector-ALU issue with projected geometry, and
+    // the tap geometry is computed by every lane of a point: half the lanes, half of that work per point)
+    const bool vec8 = C % 8 == 0 && (C / G) % 8 == 0 && is_pow2(C / 8) && is_pow2((C / G) / 8) && C / 8 <= 64 && getenv("GF_DAF_VEC4") == nullptr;
+    if (vec8) {
+        a.total = (long long)B * num_pts * (C / 8);
+        hipLaunchKernelGGL((gf_daf_bwd_kernel<8, true, false>), dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a, (C / G) / 8, C / 8);
+    } else if (is_pow2(lpg)) hipLaunchKernelGGL((gf_daf_bwd_kernel<4, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, lpg, lpp);
     else hipLaunchKernelGGL((gf_daf_bwd_kernel<4, false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, 1, 1);
     GF_CHECK_LAUNCH();
 
