@@ -358,6 +358,7 @@ class _LocalAggregate(torch.autograd.Function):
             ctx.state_event = torch.cuda.Event()
             ctx.state_event.record(torch.cuda.current_stream(pts.device))
         ctx.save_for_backward(state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii)
+        _LocalAggregate.last_state = state   # (read back, never waited for, by LocalAggregator._watch_path)
         return logits
 
     @staticmethod
@@ -561,7 +562,36 @@ class LocalAggregator(_AggregatorBase):
             flags = pts_flag | (0 if self._grid_exact else _lib.GF_EXACT_FP32)
         else:
             flags = pts_flag | (_lib.GF_MFMA_SPLAT if self.matrix_cores else _lib.GF_EXACT_FP32)
-        return _LocalAggregate.apply(pts, *args, H, self.W, self.D, flags)
+        out = _LocalAggregate.apply(pts, *args, H, self.W, self.D, flags)
+        if self.matrix_cores is None and self._grid_exact and pts.shape[0] == H * self.W * self.D:
+            self._watch_path(pts.device)
+        return out
+
+    def _watch_path(self, device):
+        """The module judged its grid an exact lattice from (pc_min, grid_size); the ``pts`` actually passed may be built
+        differently (e.g. in fp64 and cast), fail the device's lattice verdict and be rendered by the arbitrary-points body in
+        every frame, ~7x slower, with word 1 of the state block as the only sign.  So the word is copied to pinned host memory
+        now and then (first calls, then every 64th; behind an event, never waited for); when a copy says GF_PATH_ARBITRARY the
+        module warns once and uses the exact-fp32 tile kernel from then on."""
+        import warnings
+        w = getattr(self, "_path_watch", None)
+        if w is None:
+            w = self._path_watch = {"calls": 0, "host": None, "event": None}
+        if w["event"] is not None and w["event"].query():
+            if int(w["host"][1]) == _lib.GF_PATH_ARBITRARY:
+                warnings.warn("LocalAggregator: pts is a dense grid but not the exact fp32 lattice of (pc_min, grid_size): the "
+                              "matrix-core kernel's device verdict sends every frame to the arbitrary-points body; using the "
+                              "exact-fp32 kernel from now on (matrix_cores=False selects it up front)")
+                self._grid_exact = False
+            w["host"] = w["event"] = None
+        w["calls"] += 1
+        state = getattr(_LocalAggregate, "last_state", None)
+        if (w["event"] is None and state is not None and state.is_cuda and (w["calls"] <= 3 or w["calls"] % 64 == 0)
+                and not torch.cuda.is_current_stream_capturing()):
+            w["host"] = torch.empty(5, dtype=torch.int32, pin_memory=True)
+            w["host"].copy_(state[:20].view(torch.int32), non_blocking=True)
+            w["event"] = torch.cuda.Event()
+            w["event"].record(torch.cuda.current_stream(device))
 
     def _radii(self, scales):
         return torch.ceil(scales.max(dim=-1)[0] * self.scale_multiplier / self.grid_size).to(torch.int)

@@ -610,3 +610,37 @@ def test_mfma_development_kernels_match_the_oracle_and_repeat_themselves(gpu, na
             assert_logits_close(got["logits"], ref, tol=1e-4)
         again, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
         assert np.array_equal(got["logits"], again["logits"]), (name, kw)
+
+
+def test_module_notices_a_dense_grid_that_is_not_its_lattice(gpu):
+    """the module picks the matrix-core kernel from (pc_min, grid_size); a caller's dense ``pts`` built differently
+    (here: a few centres one ulp off) fails the device verdict in every frame.  The module reads the state word back without
+    waiting, warns once and switches itself to the exact-fp32 kernel."""
+    import time
+    import warnings
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import LocalAggregator, _LocalAggregate
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=13, P=300, H=24, W=24, D=16)
+    m = LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)[None]
+    pts = si.pts.copy()
+    pts[::97, 1] = np.nextafter(pts[::97, 1], np.float32(1e9))
+    args = (t(pts), t(si.means3D), t(si.opacities), t(si.semantics), t(si.scales), t(si.cov3D))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        first = m(*args)
+        assert _LocalAggregate.last_state.view(torch.int32)[1].item() == _lib.GF_PATH_ARBITRARY
+        torch.cuda.synchronize()
+        time.sleep(0.05)
+        for _ in range(3):
+            out = m(*args)
+        torch.cuda.synchronize()
+    assert m._grid_exact is False and any("exact-fp32" in str(w.message) for w in caught)
+    assert _LocalAggregate.last_state.view(torch.int32)[1].item() == _lib.GF_PATH_EXACT_TILE
+    assert float(((out - first).abs() / first.abs().clamp(min=1.0)).max()) <= 1e-4
+    # the module's own lattice is left alone
+    m2 = LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)
+    for _ in range(4):
+        m2(t(si.pts), *args[1:])
+        torch.cuda.synchronize()
+    assert m2._grid_exact is True
