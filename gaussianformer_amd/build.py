@@ -13,6 +13,9 @@ LIB_NAME = "libgf_hip.so"
 SOURCES = ["gf_api.hip", "splat_fwd.hip", "splat_bwd.hip", "splat_bwd_mfma.hip", "daf.hip", "gaussian_prepare.hip", "daf_prepare.hip", "head_labels.hip", "feature_format.hip", "subm_conv.hip", "key_points.hip"]
 HEADERS = ["gf_common.hpp", "splat_fwd_pair.inc", "splat_fwd_solo.inc", os.path.join("..", "..", "include", "gf_hip.h")]
 ARCH = "gfx950"
+# -munsafe-fp-atomics only for the translation units that issue float atomics (hardware fp32 adds without a CAS loop); the
+# others are built without it
+FP_ATOMICS = {"daf.hip", "splat_bwd.hip", "splat_bwd_mfma.hip", "subm_conv.hip"}
 
 
 def lib_path():
@@ -41,13 +44,13 @@ def build(force=False, verbose=False, extra_flags=(), lib_name=None):
     out_lib = lib_path() if lib_name is None else os.path.join(CSRC, lib_name)
     tag = "" if lib_name is None else "." + os.path.splitext(lib_name)[0]
     objs = []
-    common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+    common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
               "-Wall", "-Wno-unused-function", "-Wno-inline-asm", *extra_flags]
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
         objs.append(obj)
-        cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = common + (["-munsafe-fp-atomics"] if src in FP_ATOMICS else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
