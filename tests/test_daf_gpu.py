@@ -179,3 +179,66 @@ def test_daf_random_shapes_sweep(gpu):
             assert_grad_close(w.grad.cpu().numpy(), gw, "grad_weights")
         except AssertionError as e:
             raise AssertionError(f"trial {trial}: {case}: {e}")
+
+
+# ---- round 5: the accumulation of grad_mc_ms_feat by image regions (gf_daf_raccumulate_kernel) against the tile formulation
+# (GF_DAF_TILES=1) and the oracle, on the shapes its geometry has to get right
+
+_REGION_CASES = [
+    # the nuScenes layout: dyadic pyramid, 10 x 10 + 7 x 7 + 5 x 5 + 4 x 4 rows per region
+    ("nuscenes pyramid", dict(num_pts=3000, B=1, cams=6, C=128, G=4, levels=((64, 176), (32, 88), (16, 44), (8, 22))), None),
+    # levels that are NOT halves of each other: rectangles from the ratios, some capped -> taps outside take the per-tap path
+    ("odd ratios", dict(num_pts=2500, B=1, cams=2, C=128, G=4, levels=((37, 53), (30, 41), (9, 17))), None),
+    ("coarse levels larger than level 0's share", dict(num_pts=1500, B=1, cams=1, C=128, G=2, levels=((16, 16), (15, 15), (14, 14), (13, 13))), None),
+    ("sixteen lanes per row, one group, two batch elements", dict(num_pts=1200, B=2, cams=3, C=64, G=1, levels=((20, 33), (10, 17))), None),
+    ("one level", dict(num_pts=900, B=1, cams=2, C=128, G=4, levels=((24, 40),)), None),
+    ("maps smaller than a region", dict(num_pts=700, B=1, cams=2, C=128, G=4, levels=((5, 7), (3, 4), (2, 2), (1, 1))), None),
+    # everything lands in ONE region: many items of one region, their row adds meet in the same rows
+    ("one crowded region", dict(num_pts=6000, B=1, cams=1, C=128, G=4, levels=((64, 176), (32, 88), (16, 44), (8, 22))), "crowd"),
+    ("nothing visible", dict(num_pts=500, B=1, cams=2, C=128, G=4, levels=((16, 24), (8, 12))), "invisible"),
+    ("on the image border", dict(num_pts=800, B=1, cams=2, C=128, G=4, levels=((16, 24), (8, 12), (4, 6))), "border"),
+]
+
+
+@pytest.mark.parametrize("name,case,special", _REGION_CASES, ids=[c[0] for c in _REGION_CASES])
+def test_daf_backward_by_regions(gpu, name, case, special, monkeypatch):
+    import torch
+    from gaussianformer_amd.deformable_aggregation import deformable_aggregation_backward as bwd
+    d = make_daf_inputs(seed=31, **case)
+    rng = np.random.default_rng(32)
+    loc = d["sampling_location"]
+    if special == "crowd":
+        loc[...] = (0.40 + 0.02 * rng.random(loc.shape)).astype(np.float32)
+    elif special == "invisible":
+        loc[...] = (1.0 + rng.random(loc.shape)).astype(np.float32)
+    elif special == "border":
+        edge = rng.integers(0, 4, size=loc.shape[:-1])
+        loc[..., 0] = np.where(edge == 0, 1e-6, np.where(edge == 1, 1 - 1e-6, loc[..., 0])).astype(np.float32)
+        loc[..., 1] = np.where(edge == 2, 1e-6, np.where(edge == 3, 1 - 1e-6, loc[..., 1])).astype(np.float32)
+    feat, ss, st, loc_t, w = to_dev(gpu, d["mc_ms_feat"], d["spatial_shape"], d["scale_start_index"], loc, d["weights"])
+    B, pts, C = loc.shape[0], loc.shape[1], feat.shape[-1]
+    g = rng.standard_normal((B, pts, C)).astype(np.float32)
+    go = torch.from_numpy(g).to(gpu)
+    res = {}
+    for mode in ("regions", "tiles"):
+        monkeypatch.delenv("GF_DAF_TILES", raising=False)
+        if mode == "tiles":
+            monkeypatch.setenv("GF_DAF_TILES", "1")
+        gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(loc_t), torch.zeros_like(w)
+        bwd(feat, ss, st, loc_t, w, go, gf, gl, gw)
+        res[mode] = (gf, gl, gw)
+    monkeypatch.delenv("GF_DAF_TILES", raising=False)
+    (gf1, gl1, gw1), (gf0, gl0, gw0) = res["regions"], res["tiles"]
+    assert torch.equal(gl1, gl0) and torch.equal(gw1, gw0)            # the gather side is the same kernel
+    scale = max(gf0.abs().max().item(), 1e-30)
+    assert torch.isfinite(gf1).all()
+    assert (gf1 - gf0).abs().max().item() <= 2e-5 * scale, name       # fp32 summation order only
+    if special == "invisible":
+        assert gf1.abs().max().item() == 0.0
+    ogf, ogl, ogw = oracle.daf_backward(d["mc_ms_feat"], d["spatial_shape"], d["scale_start_index"], loc, d["weights"], g)
+    assert_grad_close(gf1.cpu().numpy(), ogf, "grad_mc_ms_feat")
+    assert_grad_close(gl1.cpu().numpy(), ogl, "grad_sampling_location")
+    assert_grad_close(gw1.cpu().numpy(), ogw, "grad_weights")
+    # accumulation semantics: a second call adds to what is there
+    bwd(feat, ss, st, loc_t, w, go, gf1, gl1, gw1)
+    assert (gf1 - 2 * gf0).abs().max().item() <= 4e-5 * scale
