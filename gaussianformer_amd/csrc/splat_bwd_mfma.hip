@@ -240,6 +240,7 @@ __device__ __forceinline__ void zero_big_gaussians(const BwdMArgs &a, int lane)
 }
 
 // ---------------------------------------------------------------------------------------
+template <bool INTER>   // supertiles dealt to the XCDs round-robin (default) or in contiguous bands: see gf_splat_render_mfma_wave_kernel
 __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_u[kMLdsDwords];
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     const int xcd = (int)(blockIdx.x & 7u);
     const int per_super = 4 * ((a.D + 7) >> 3);
     const int nunits = a.nsx * a.nsy * per_super;
-    const int per_xcd = (nunits + 7) >> 3;
+    const int per_xcd = INTER ? ((a.nsx * a.nsy + 7) >> 3) * per_super : (nunits + 7) >> 3;
     const uint32_t m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / (unsigned)per_super);
     const uint32_t m_nsy = (uint32_t)(((1ull << 32) + a.nsy - 1) / (unsigned)a.nsy);
     using gptr = const __attribute__((address_space(1))) void *;
@@ -342,10 +343,11 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     const int nchunk = (a.nwords + 63) >> 6;
     int local = (int)(blockIdx.x >> 3);
     while (true) {  // units of this wave
-        const int logical = xcd * per_xcd + local;
-        if (!(local < per_xcd && logical < nunits)) break;
+        const int logical = INTER ? local : xcd * per_xcd + local;
+        const int qs = (int)__umulhi((uint32_t)logical, m_ps);
+        if (!(local < per_xcd && (INTER ? 8 * qs + xcd < a.nsx * a.nsy : logical < nunits))) break;
         uint32_t claimed = 0u;
-        const int s = (int)__umulhi((uint32_t)logical, m_ps), r = logical - s * per_super;
+        const int s = INTER ? 8 * qs + xcd : qs, r = logical - qs * per_super;
         const int srow = a.nsy == 1 ? s : (int)__umulhi((uint32_t)s, m_nsy), scol = s - srow * a.nsy;
         const int Xw = srow * kSuper + 4 * (r & 1), Y0 = scol * kSuper + 4 * ((r >> 1) & 1), Zw = 8 * (r >> 2);
         if (Xw < a.H && Y0 < a.W) {
@@ -1199,7 +1201,8 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
     a.gate = gate ? 1 : 0; a.records_asserted = records_asserted;
     a.timeline = g_bwd_timeline;
     a.cap = ws.bwd_cap;
-    hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel, dim3(grid), dim3(64), 0, stream, a);
+    if (getenv("GF_UNITS_BANDS") != nullptr) hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<false>, dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
     BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, ws.bwd_row_first, gen_word,
                   ws.flags + kBwdCounters, state, (uint32_t)(grid / 8), P, gate, (P + 31) / 32, records_asserted};
     hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + 256), dim3(256), 0, stream, r);

@@ -1867,7 +1867,13 @@ static_assert(2 * 64 * kC <= 1536 + 3 * kWList, "output staging fits over the sl
 // default kernel's code is unchanged.
 // PREP: the GF_PREPARE_BACKWARD variant (row layout + published candidate lists) -- an instantiation of its own, so that the plain
 // forward keeps its code and register allocation (as one kernel the extra paths cost it 0.8 us per step: 31 more spilled SGPRs).
-template <bool LABELS, bool PREP = false>
+// INTER (the default since round 5): supertiles dealt to the XCDs round-robin (supertile s on XCD s % 8) instead of in eight
+// contiguous bands of units (INTER = false, GF_UNITS_BANDS=1 for comparison).  With Gaussians clustered in the middle of the grid
+// -- what a trained model produces -- the bands of the middle XCDs hold several times the work of the outer ones and nothing moves
+// work between XCDs: 61.1 us per step at gs25600 with sigmoid(N(0,1)) centres; dealt round-robin every XCD sees the same density:
+// 48.1 us.  The locality given up (a Gaussian's record is fetched by as many XCDs as it has neighbouring supertiles) does not
+// show: 43.6 us either way with uniform centres.  Same arithmetic per unit: bit-identical results.
+template <bool LABELS, bool PREP = false, bool INTER = true>
 __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(RenderArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_u[kWLdsDwords];
@@ -1882,7 +1888,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     const int xcd = (int)(blockIdx.x & 7u);
     const int per_super = 4 * ((a.D + 7) >> 3);          // units of a supertile: 2 x 2 column quarters x z bricks
     const int nunits = a.nsx * a.nsy * per_super;
-    const int per_xcd = (nunits + 7) >> 3;
+    const int per_xcd = INTER ? ((a.nsx * a.nsy + 7) >> 3) * per_super : (nunits + 7) >> 3;
 
     // unit index -> (supertile, quarter, z brick) -> supertile row and column: divisions by launch constants, as multiplications
     // by rounded-up reciprocals (exact for the < 2^20 indices of a grid)
@@ -1895,9 +1901,10 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     // The first unit's bitmask row is requested before anything else: its round trip then runs under the verdict loads and the
     // set-up below instead of behind them (a failed verdict wastes one LDS-DMA).
     {
-        const int logical = xcd * per_xcd + local;
-        if (local < per_xcd && logical < nunits) {
-            const int s0 = (int)__umulhi((uint32_t)logical, m_ps), r0 = logical - s0 * per_super;
+        const int logical = INTER ? local : xcd * per_xcd + local;
+        const int q0 = (int)__umulhi((uint32_t)logical, m_ps);
+        if (local < per_xcd && (INTER ? 8 * q0 + xcd < a.nsx * a.nsy : logical < nunits)) {
+            const int s0 = INTER ? 8 * q0 + xcd : q0, r0 = logical - q0 * per_super;
             const int srow0 = a.nsy == 1 ? s0 : (int)__umulhi((uint32_t)s0, m_nsy), scol0 = s0 - srow0 * a.nsy;
             if (srow0 * kSuper + 4 * (r0 & 1) < a.H && scol0 * kSuper + 4 * ((r0 >> 1) & 1) < a.W) {
                 const unsigned long long *bm0 = a.bitmask + (size_t)s0 * a.nrow;
@@ -2016,8 +2023,9 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     const int nchunk = (a.nwords + 63) >> 6;
     int nst_prev = 0;        // ... and this many store instructions were issued after that request
     while (true) {  // units of this wave
-        const int logical = xcd * per_xcd + local;
-        if (!(local < per_xcd && logical < nunits)) break;
+        const int logical = INTER ? local : xcd * per_xcd + local;
+        const int qs = (int)__umulhi((uint32_t)logical, m_ps);
+        if (!(local < per_xcd && (INTER ? 8 * qs + xcd < a.nsx * a.nsy : logical < nunits))) break;
         bool next_row = false;
         int nst = -1;
         // The next unit is claimed first thing (workgroup scope: the counter of XCD x is only touched by workgroups running on
@@ -2025,7 +2033,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
         // divergent block that issued it).  The answer is waited for together with the bitmask row.
         uint32_t claimed = 0u;
         bool have_next = false;
-        const int s = (int)__umulhi((uint32_t)logical, m_ps), r = logical - s * per_super;
+        const int s = INTER ? 8 * qs + xcd : qs, r = logical - qs * per_super;
         const int srow = a.nsy == 1 ? s : (int)__umulhi((uint32_t)s, m_nsy), scol = s - srow * a.nsy;   // (2^32 / 1 does not fit)
         const int Xw = srow * kSuper + 4 * (r & 1), Y0 = scol * kSuper + 4 * ((r >> 1) & 1), Zw = 8 * (r >> 2);
         if (Xw < a.H && Y0 < a.W) {
@@ -2402,9 +2410,10 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed)::"memory");
             have_next = true;
             {
-                const int nl = __builtin_amdgcn_readfirstlane((int)claimed), nlog = xcd * per_xcd + nl;
-                if (nl < per_xcd && nlog < nunits) {
-                    const int s2 = (int)__umulhi((uint32_t)nlog, m_ps), r2 = nlog - s2 * per_super;
+                const int nl = __builtin_amdgcn_readfirstlane((int)claimed), nlog = INTER ? nl : xcd * per_xcd + nl;
+                const int q2 = (int)__umulhi((uint32_t)nlog, m_ps);
+                if (nl < per_xcd && (INTER ? 8 * q2 + xcd < a.nsx * a.nsy : nlog < nunits)) {
+                    const int s2 = INTER ? 8 * q2 + xcd : q2, r2 = nlog - q2 * per_super;
                     const int srow2 = a.nsy == 1 ? s2 : (int)__umulhi((uint32_t)s2, m_nsy), scol2 = s2 - srow2 * a.nsy;
                     if (srow2 * kSuper + 4 * (r2 & 1) < a.H && scol2 * kSuper + 4 * ((r2 >> 1) & 1) < a.W) {
                         const unsigned long long *bm2 = a.bitmask + (size_t)s2 * a.nrow;
@@ -2642,9 +2651,12 @@ static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stre
         hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<true>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
     else if (mfma_by_wave(r.nrow) && r.rows_valid)
         hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, true>), dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
-    else if (mfma_by_wave(r.nrow))
-        hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<false>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
-    else
+    else if (mfma_by_wave(r.nrow)) {
+        if (getenv("GF_UNITS_BANDS") != nullptr)   // (comparison only: the unit -> XCD mapping of rounds 3 and 4)
+            hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, false, false>), dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
+        else
+            hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<false>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
+    } else
         hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
     if (prof) (void)hipEventRecord(ev1, stream);
 }
