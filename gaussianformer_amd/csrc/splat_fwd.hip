@@ -562,6 +562,7 @@ struct RenderArgs {
     unsigned long long *timeline;  // debug: 4 timestamps per workgroup (null = off)
     const int *tile_perm;          // debug (GF_TIMELINE builds): workgroup -> logical tile, for scheduling experiments
     int P, N, nwords, nrow, H, W, D, nsx, nsy, ntiles_total, verify_dense;
+    int bands;   // exact tile kernel: 1 = tiles dealt to the XCDs in contiguous bands (rounds 1 - 4; GF_UNITS_BANDS=1), 0 = by supertile, round-robin
     // optional head epilogue (gf_splat_forward_labels): labels straight from the accumulators
     long long *out_labels;  // null = off
     int label_mode, empty_label;
@@ -913,10 +914,12 @@ __global__ __launch_bounds__(kBlock, kRenderWavesPerSimd) void gf_splat_render_k
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // tile of this workgroup.  XCD-aware order: consecutive logical tiles (supertile-major)
-    // stay on one XCD so its L2 keeps that supertile's bitmask, boxes and records.
+    // tile of this workgroup.  XCD-aware order: the tiles of a supertile stay on one XCD (workgroup b runs on XCD b % 8) so its L2
+    // keeps that supertile's bitmask, boxes and records; the supertiles are dealt to the XCDs round-robin (round 5: in contiguous
+    // bands the XCDs of the middle of the grid carried several times the work of the outer ones when the Gaussians cluster there).
     const int per_xcd = (int)(gridDim.x >> 3);
-    int logical = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    int logical = a.bands ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3)
+                          : (8 * ((int)(blockIdx.x >> 3) / kTilesPerSuper) + (int)(blockIdx.x & 7u)) * kTilesPerSuper + (int)(blockIdx.x >> 3) % kTilesPerSuper;
 #if GF_TIMELINE
     if (a.tile_perm) logical = a.tile_perm[blockIdx.x];
 #endif
@@ -1248,7 +1251,7 @@ __device__ __forceinline__ void lds_dma4(const __attribute__((address_space(1)))
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"((uint32_t)(uintptr_t)l) : "memory", "m0");
 }
-template <bool LABELS>
+template <bool LABELS, bool INTER = true>   // INTER: supertiles dealt to the XCDs round-robin (see gf_splat_render_mfma_wave_kernel)
 __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderArgs a)
 {
     // the output staging area is NOT aliased onto the list here (two workgroups per CU leave the LDS for it): a wave that
@@ -1270,7 +1273,9 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     // the following ones come from a per-XCD counter (initialised by the prep kernel), claimed late in the current tile.
     __shared__ int s_next;
     const int xcd = (int)(blockIdx.x & 7u);
-    const int per_xcd = (a.ntiles_total + 7) >> 3;  // logical tiles per XCD (the last XCD's tail may be short)
+    // logical tiles per XCD: an eighth of the tiles in one contiguous band (the last XCD's tail may be short), or -- INTER -- the
+    // tiles of every eighth supertile
+    const int per_xcd = INTER ? ((a.nsx * a.nsy + 7) >> 3) * kTilesPerSuper : (a.ntiles_total + 7) >> 3;
 
     // The prep launch's verdict words (point scans: 4 x 16 bytes per thread) and the records pass's range verdicts (four clamped
     // 16-byte reads per thread: 4 096 words, P <= 262 144; longer rows add a loop) in ONE round trip: all eight loads are
@@ -1297,11 +1302,11 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
         }
     }
     int local = (int)(blockIdx.x >> 3);
-    int logical = xcd * per_xcd + local;
-    int s = logical / kTilesPerSuper, t = logical % kTilesPerSuper;
+    int logical = INTER ? local : xcd * per_xcd + local;
+    int s = INTER ? 8 * (logical / kTilesPerSuper) + xcd : logical / kTilesPerSuper, t = logical % kTilesPerSuper;
     int X0 = (s / a.nsy) * kSuper;
     int Y0 = (s % a.nsy) * kSuper + t * kTileY;
-    bool tile_ok = local < per_xcd && logical < a.ntiles_total && X0 < a.H && Y0 < a.W;
+    bool tile_ok = local < per_xcd && (INTER ? s < a.nsx * a.nsy : logical < a.ntiles_total) && X0 < a.H && Y0 < a.W;
     const unsigned long long *__restrict__ bm = a.bitmask + (size_t)(tile_ok ? s : 0) * a.nrow;
 
     // verdicts of the prep launch: bit 0 = a point is not in its voxel, bit 1 = pts is not an exact affine lattice,
@@ -1828,11 +1833,11 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     next_local = s_next;
     local = next_local;
-    logical = xcd * per_xcd + local;
-    s = logical / kTilesPerSuper; t = logical % kTilesPerSuper;
+    logical = INTER ? local : xcd * per_xcd + local;
+    s = INTER ? 8 * (logical / kTilesPerSuper) + xcd : logical / kTilesPerSuper; t = logical % kTilesPerSuper;
     X0 = (s / a.nsy) * kSuper;
     Y0 = (s % a.nsy) * kSuper + t * kTileY;
-    if (!(local < per_xcd && logical < a.ntiles_total)) break;  // workgroup-uniform
+    if (!(local < per_xcd && (INTER ? s < a.nsx * a.nsy : logical < a.ntiles_total))) break;  // workgroup-uniform
     bm = a.bitmask + (size_t)s * a.nrow;
     // the slowest wave is done with the list and the scan scratch.  LDS ordering only: a full __syncthreads() also waits
     // (vmcnt) for the output stores just issued to be acknowledged
@@ -2656,7 +2661,9 @@ static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stre
             hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, false, false>), dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
         else
             hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<false>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
-    } else
+    } else if (getenv("GF_UNITS_BANDS") != nullptr)
+        hipLaunchKernelGGL((gf_splat_render_mfma_kernel<false, false>), dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
+    else
         hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
     if (prof) (void)hipEventRecord(ev1, stream);
 }
@@ -2665,7 +2672,7 @@ template <int VARIANT, int EXP, bool LABELS>
 static void launch_render(bool dense_candidate, const RenderArgs &r, hipStream_t stream)
 {
     if (dense_candidate) {
-        const int per_xcd = (r.ntiles_total + 7) / 8;
+        const int per_xcd = r.bands ? (r.ntiles_total + 7) / 8 : ((r.nsx * r.nsy + 7) / 8) * kTilesPerSuper;
         // the embedded arbitrary-points body grid-strides, so the tile grid is enough
         hipEvent_t ev0, ev1;
         const bool prof = profile_slot(&ev0, &ev1);
@@ -2893,6 +2900,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.verify_flags = ws.flags + 64; ra.state = (uint32_t *)state; ra.P = P; ra.N = N; ra.nwords = ws.nwords; ra.nrow = ws.nrow;
     ra.H = H; ra.W = W; ra.D = D; ra.nsx = ws.nsx; ra.nsy = ws.nsy; ra.ntiles_total = ws.nsuper * kTilesPerSuper;
     ra.verify_dense = verify ? 1 : 0;
+    ra.bands = getenv("GF_UNITS_BANDS") != nullptr ? 1 : 0;
     ra.timeline = g_timeline;
     ra.tile_perm = g_tile_perm;
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
