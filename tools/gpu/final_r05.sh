@@ -21,6 +21,7 @@ rm -rf gpurun_out/kt_bwd; timeout 200 rocprofv3 --kernel-trace --stats --output-
 # forward: the development kernels next to the default one; prep / render / gap of the default path
 timeout 300 python tools/pair_probe.py > $OUT/fwd_kernels_$R.txt 2>&1; cat $OUT/fwd_kernels_$R.txt | tail -4
 bash tools/gpu/kernel_pair.sh > $OUT/kernel_pair_$R.txt 2>&1; grep "mean\|per step" $OUT/kernel_pair_$R.txt
+(timeout 300 python tools/interleave_probe.py nuscenes_gs25600_solid nuscenes_gs144000; timeout 200 python tools/interleave_probe_exact.py) 2>&1 | grep -v amdgpu.ids > $OUT/interleave_$R.txt; cat $OUT/interleave_$R.txt | cut -c1-200
 timeout 100 python tools/subm_range_probe.py > $OUT/subm_range_$R.txt 2>&1; cat $OUT/subm_range_$R.txt | grep anchors
 timeout 300 python tools/bench_frame.py --frames 20 --graph > $OUT/bench_frame_$R.jsonl 2> gpurun_out/bench_frame.err; cut -c1-200 $OUT/bench_frame_$R.jsonl
 timeout 300 python tools/bench_step.py > $OUT/bench_step_$R.json 2> gpurun_out/bench_step.err; cat $OUT/bench_step_$R.json | cut -c1-300
