@@ -59,6 +59,13 @@ union H8 {
     _Float16 e[8];
 };
 
+// The Gaussians with more than kBwdBigRows rows (normally one: the whole-grid "empty" Gaussian), as a table the gradient kernel's
+// zeroing wave leaves for the row-sum kernel: [0] = count (0xFFFFFFFF: more than kBwdBigTable, the row-sum kernel finds them itself),
+// then (Gaussian, first row, rows) triples in ascending Gaussian order.  It lives in the unused tail of the layout words
+// (bwd_wave_total holds kBwdBigCap = 1024 words, the matrix-core backward takes P <= 64 kWRow: 618 of them).
+constexpr int kBwdBigTableAt = 640, kBwdBigTable = (kBwdBigCap - kBwdBigTableAt - 1) / 3;
+static_assert(kBwdBigTableAt >= kWRow && kBwdBigTable >= 64, "the table sits past the layout words in use");
+
 struct BwdMArgs {
     const float *pts;            // lattice: pts[0] and the three axis steps
     const float *records;        // [P][32]   (gf_splat_prep_kernel; natural-log covariance)
@@ -78,6 +85,7 @@ struct BwdMArgs {
     int gate;                    // 1: run only if the forward's state says "matrix cores" (2: the set-up kernel wrote NaN gradients otherwise)
     int records_asserted;        // 1: no records pass ran -- stand down unless the workspace still holds the forward's (generation)
     unsigned long long *timeline;  // debug (GF_TIMELINE builds): 8 stamps per unit
+    uint32_t *big_table;         // (zero_big_gaussians -> gf_splat_bwd_rows_kernel: see kBwdBigTableAt)
     uint32_t cap;                // rows in `rows`: a row index beyond it is never written (defence in depth: a first row read from a layout
                                  // that was not completed would otherwise be an out-of-bounds store)
 };
@@ -213,6 +221,7 @@ __device__ __forceinline__ void zero_big_gaussians(const BwdMArgs &a, int lane)
 #pragma unroll
     for (int k = 0; k < kPer; ++k) fl[k] = a.wave_total[min(64 * k + lane, nw - 1)];
     asm volatile("" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]), "+v"(fl[4]), "+v"(fl[5]), "+v"(fl[6]), "+v"(fl[7]), "+v"(fl[8]), "+v"(fl[9]));
+    int nbig = 0;   // entries of the table so far (wave-uniform)
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int w0 = 64 * k;
@@ -222,21 +231,39 @@ __device__ __forceinline__ void zero_big_gaussians(const BwdMArgs &a, int lane)
             const int w = w0 + __builtin_ctzll(m);
             m &= m - 1;
             const int g = 64 * w + lane;
+            bool big_here = false;
+            uint32_t first_here = 0u;
+            int cnt_here = 0;
             if (g < a.P) {
                 const uint2 b = a.boxes[g];
                 const bool ne = ux(b.y) > ux(b.x) && uy(b.y) > uy(b.x) && uz(b.y) > uz(b.x);
                 const int cnt = !ne ? 0 : (((ux(b.y) - 1) >> 2) - (ux(b.x) >> 2) + 1) * (((uy(b.y) - 1) >> 2) - (uy(b.x) >> 2) + 1) *
                                               (((uz(b.y) - 1) >> 3) - (uz(b.x) >> 3) + 1);
                 // (one without rows was zeroed by the set-up kernel and is receiving this kernel's atomics: hands off)
-                if (cnt > kBwdBigRows && a.row_first[g] != 0xFFFFFFFFu) {
+                first_here = a.row_first[g];
+                if (cnt > kBwdBigRows && first_here != 0xFFFFFFFFu) {
                     for (int k = 0; k < kC; ++k) a.sem_grad[(size_t)kC * g + k] = 0.f;
                     for (int k = 0; k < 6; ++k) a.cov_grad[6 * (size_t)g + k] = 0.f;
                     for (int k = 0; k < 3; ++k) a.means_grad[3 * (size_t)g + k] = 0.f;
                     a.opa_grad[g] = 0.f;
+                    big_here = true;
+                    cnt_here = cnt;
                 }
             }
+            // the row-sum kernel's work list (ascending Gaussian index: waves in order, lanes in order)
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(big_here);
+            if (big_here) {
+                const int pos = nbig + __builtin_popcountll(bm & ((1ull << lane) - 1ull));
+                if (pos < kBwdBigTable) {
+                    a.big_table[1 + 3 * pos] = (uint32_t)g;
+                    a.big_table[2 + 3 * pos] = first_here;
+                    a.big_table[3 + 3 * pos] = (uint32_t)cnt_here;
+                }
+            }
+            nbig += __builtin_popcountll(bm);
         }
     }
+    if (lane == 0) a.big_table[0] = nbig <= kBwdBigTable ? (uint32_t)nbig : 0xFFFFFFFFu;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -251,8 +278,16 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     uint32_t *q_id = s_u + 1536 + 3 * kMList + kMDlDwords;
     _Float16 *s_dh = reinterpret_cast<_Float16 *>(s_dl), *s_dq = s_dh + kC * kMPitch16;   // hi and lo terms, [channel][voxel]
 
-    if (a.gate && !state_is_matrix_core(a.state)) return;
-    if (a.records_asserted && !records_still_there(a.state, a.gen_word)) return;
+    // (all the words the start of a wave decides on in ONE round trip -- gate, asserted records, published lists: as three
+    // conditions in a row each was a scalar load of its own, waited for before the next was requested)
+    uint32_t st0 = a.state[0], st1 = a.state[1], st3 = a.state[3], st4 = a.state[4], gen = *a.gen_word;
+    uint32_t lbad = a.lists ? *a.lists_bad : 1u;
+    asm volatile("" : "+s"(st0), "+s"(st1), "+s"(st3), "+s"(st4), "+s"(gen), "+s"(lbad));
+    const bool mc_fwd = st0 == 0u && (st1 == (uint32_t)GF_PATH_MATRIX_CORE || st1 == (uint32_t)GF_PATH_MATRIX_CORE_WAVE ||
+                                      st1 == (uint32_t)GF_PATH_MATRIX_CORE_PAIR || st1 == (uint32_t)GF_PATH_MATRIX_CORE_SOLO);
+    const bool still_there = st3 == gen && (st4 & 1u) != 0u;   // (records_still_there)
+    if (a.gate && !mc_fwd) return;
+    if (a.records_asserted && !still_there) return;
 
     const int lane = threadIdx.x;
     if (blockIdx.x == 0) zero_big_gaussians(a, lane);
@@ -310,7 +345,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     // The forward published every supertile's candidate list (GF_PREPARE_BACKWARD) and the workspace still holds it: the unit
     // takes the list -- ids and packed boxes, 3 KB in three requests -- instead of the bitmask row, and skips the row scan and
     // the box round trip (1.7 + ~1 us of a unit's 21.6).
-    const bool use_lists = a.lists && records_still_there(a.state, a.gen_word) && *a.lists_bad == 0u;
+    const bool use_lists = a.lists && still_there && lbad == 0u;
     auto request_unit = [&](int s_, int Xw_, int Y0_, int Zw_) {
         int wl = lane;
         asm volatile("" : "+v"(wl));
@@ -990,6 +1025,7 @@ struct BwdRowsArgs {
     const uint32_t *wave_total;   // records pass: rows per wave of 64 Gaussians, bit 31 = the wave has a Gaussian of more than kBwdBigRows rows
     const uint32_t *row_first;
     uint32_t *gen_word;
+    const uint32_t *big_table;    // the gradient kernel's list of Gaussians with more than kBwdBigRows rows (kBwdBigTableAt)
     uint32_t *unit_counters;      // the gradient kernel's per-XCD unit counters: re-armed here for the next backward
     const uint32_t *state;
     uint32_t counter_init;
@@ -1016,17 +1052,35 @@ __device__ __forceinline__ void bwd_add_column(const BwdRowsArgs &a, int g, int 
 
 __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
 {
-    const bool mc = state_is_matrix_core(a.state);
-    if (a.gate == 1 && !mc) return;
+    // Everything this workgroup decides on is REQUESTED before anything is decided: the state block's words, the generation word
+    // and -- for the Gaussian-range workgroups -- the Gaussian's first row and its record's box.  Written the natural way (gate,
+    // then the asserted-records check, then the layout words, then the rows) the kernel was four dependent round trips long.
     const int tid = threadIdx.x;
+    const bool gauss_range = (int)blockIdx.x < a.ngauss_blocks;
+    const int g_own = min((int)blockIdx.x * 32 + (tid >> 3), a.P - 1);
+    uint32_t st0 = a.state[0], st1 = a.state[1], st3 = a.state[3], st4 = a.state[4], gen = *a.gen_word;
+    // (the workgroups past the Gaussian range: the gradient kernel's table of big Gaussians, one word per thread)
+    uint32_t tab_n = gauss_range ? 0u : a.big_table[0], tab_w = gauss_range ? 0u : a.big_table[1 + min(tid, 3 * 64 - 1)];
+    uint32_t first_own = a.row_first[gauss_range ? g_own : 0];
+    float4 rec2_own = *reinterpret_cast<const float4 *>(a.records + (size_t)(gauss_range ? g_own : 0) * kRecDwords + 8);
+    asm volatile("" : "+s"(st0), "+s"(st1), "+s"(st3), "+s"(st4), "+s"(gen), "+v"(first_own), "+v"(rec2_own.z), "+v"(rec2_own.w), "+v"(tab_n), "+v"(tab_w));
+    const bool mc = st0 == 0u && (st1 == (uint32_t)GF_PATH_MATRIX_CORE || st1 == (uint32_t)GF_PATH_MATRIX_CORE_WAVE ||
+                                  st1 == (uint32_t)GF_PATH_MATRIX_CORE_PAIR || st1 == (uint32_t)GF_PATH_MATRIX_CORE_SOLO);
+    const bool still_there = st3 == gen && (st4 & 1u) != 0u;   // (records_still_there)
+    if (a.gate == 1 && !mc) return;
     // a caller's assertion that does not hold (not a matrix-core forward, or the workspace has been used since): NaN, not numbers
-    const bool bad = (a.gate == 2 && !mc) || (a.records_asserted && !records_still_there(a.state, a.gen_word));
+    const bool bad = (a.gate == 2 && !mc) || (a.records_asserted && !still_there);
     if (!bad && blockIdx.x == 0) {
         if (tid < 8) a.unit_counters[64 * tid] = a.counter_init;
         // (a backward that ran its own records pass: the workspace no longer holds what any forward's state block describes.
         // Nobody else reads the word in this launch.)
-        if (!a.records_asserted && tid == 0 && !records_still_there(a.state, a.gen_word)) *a.gen_word = *a.gen_word + 1u;
+        if (!a.records_asserted && tid == 0 && !still_there) *a.gen_word = gen + 1u;
     }
+    auto rows_of_box = [&](uint32_t glo, uint32_t ghi) -> int {
+        if (!(ux(ghi) > ux(glo) && uy(ghi) > uy(glo) && uz(ghi) > uz(glo))) return 0;
+        return (((ux(ghi) - 1) >> 2) - (ux(glo) >> 2) + 1) * (((uy(ghi) - 1) >> 2) - (uy(glo) >> 2) + 1) *
+               (((uz(ghi) - 1) >> 3) - (uz(glo) >> 3) + 1);
+    };
     auto box_rows = [&](int g) -> int {
         const float4 r2 = *reinterpret_cast<const float4 *>(a.records + (size_t)g * kRecDwords + 8);
         const uint32_t glo = __float_as_uint(r2.z), ghi = __float_as_uint(r2.w);
@@ -1044,8 +1098,8 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
         if (bad) {
             acc.x = acc.y = acc.z = acc.w = __uint_as_float(0x7fc00000u);
         } else {
-            const uint32_t first = a.row_first[g];
-            const int cnt = box_rows(g);
+            const uint32_t first = first_own;
+            const int cnt = rows_of_box(__float_as_uint(rec2_own.z), __float_as_uint(rec2_own.w));
             if (cnt > 0 && (first == 0xFFFFFFFFu || cnt > kBwdBigRows)) return;
             const float *base = a.rows + (size_t)first * kBwdRowDwords + c4;
             for (int r = 0; r < cnt; r += kRowsInFlight) {
@@ -1066,12 +1120,59 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
         return;
     }
     if (bad) return;
-    // ---- big Gaussians.  Every workgroup of this range walks the flagged waves and their Gaussians in the same (ascending)
-    // order and takes the items that fall to it.
+    // ---- big Gaussians: 64-row work items, dealt to the workgroups of this range in the same order everywhere.
     __shared__ __attribute__((aligned(16))) float s_part[32][32];
     __shared__ int s_wave[kBwdBigCap], s_cnt[64];
     __shared__ uint32_t s_first[64];
     __shared__ int s_nwave;
+    __shared__ uint32_t s_tab[3 * 64];
+    int item = (int)blockIdx.x - a.ngauss_blocks;
+    const int stride = (int)gridDim.x - a.ngauss_blocks;
+    const int lg = tid >> 3, c4 = 4 * (tid & 7);
+    // sum of `n` rows, `pitch` rows apart, from `src` (this thread's four columns): lane group lg takes rows lg, lg + 32, ...;
+    // the 32 lane groups' sums are then added in lane-group order; threads 0..31 return column `tid`
+    auto sum_rows = [&](const float *src, int n, size_t pitch) -> float {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = lg; r < n; r += 64) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)r * pitch);
+            const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)min(r + 32, n - 1) * pitch);
+            const bool in1 = r + 32 < n;
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += in1 ? v1.x : 0.f; acc.y += in1 ? v1.y : 0.f; acc.z += in1 ? v1.z : 0.f; acc.w += in1 ? v1.w : 0.f;
+        }
+        __syncthreads();
+        *reinterpret_cast<float4 *>(&s_part[lg][c4]) = acc;
+        __syncthreads();
+        float t = 0.f;
+        if (tid < 32) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) t += s_part[k][tid];
+        }
+        return t;
+    };
+    // The gradient kernel left the list (kBwdBigTableAt): this kernel's second round trip is already the rows.  (Finding the
+    // Gaussians here -- layout words, then the flagged waves' first rows and boxes, then the rows -- made these workgroups the
+    // kernel's tail: 13.4 us where the Gaussian range takes 8.8.)
+    tab_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab_n);
+    if (tab_n <= 64u) {
+        if (tid < 3 * 64) s_tab[tid] = tab_w;
+        __syncthreads();
+        for (uint32_t j = 0; j < tab_n; ++j) {
+            const int g = (int)s_tab[3 * j], cnt = (int)s_tab[3 * j + 2];
+            const float *grows = a.rows + (size_t)s_tab[3 * j + 1] * kBwdRowDwords;
+            const int parts = (cnt + 63) / 64;
+            while (item < parts) {
+                const int r0 = item * 64;
+                const float t = sum_rows(grows + (size_t)r0 * kBwdRowDwords + c4, min(cnt - r0, 64), kBwdRowDwords);
+                // (the gradient kernel zeroed this Gaussian's gradients: zero_big_gaussians)
+                if (tid < 28) bwd_add_column(a, g, tid, t);
+                item += stride;
+            }
+            item -= parts;
+        }
+        return;
+    }
+    // (more big Gaussians than the table holds: every workgroup walks the flagged waves and their Gaussians itself)
     const int nw = (a.P + 63) >> 6;
     {   // (one round trip for all the layout words, then wave 0 compacts the flagged ones in order)
         uint32_t wt[kBwdBigCap / 256];
@@ -1100,30 +1201,6 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
     }
     __syncthreads();
     const int nflag = s_nwave;
-    int item = (int)blockIdx.x - a.ngauss_blocks;
-    const int stride = (int)gridDim.x - a.ngauss_blocks;
-    const int lg = tid >> 3, c4 = 4 * (tid & 7);
-    // sum of `n` rows, `pitch` rows apart, from `src` (this thread's four columns): lane group lg takes rows lg, lg + 32, ...;
-    // the 32 lane groups' sums are then added in lane-group order; threads 0..31 return column `tid`
-    auto sum_rows = [&](const float *src, int n, size_t pitch) -> float {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = lg; r < n; r += 64) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)r * pitch);
-            const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)min(r + 32, n - 1) * pitch);
-            const bool in1 = r + 32 < n;
-            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-            acc.x += in1 ? v1.x : 0.f; acc.y += in1 ? v1.y : 0.f; acc.z += in1 ? v1.z : 0.f; acc.w += in1 ? v1.w : 0.f;
-        }
-        __syncthreads();
-        *reinterpret_cast<float4 *>(&s_part[lg][c4]) = acc;
-        __syncthreads();
-        float t = 0.f;
-        if (tid < 32) {
-#pragma unroll
-            for (int k = 0; k < 32; ++k) t += s_part[k][tid];
-        }
-        return t;
-    };
     for (int e = 0; e < nflag; ++e) {
         __syncthreads();
         if (tid < 64) {
@@ -1196,6 +1273,7 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
     a.pts = pts; a.records = ws.records; a.boxes = ws.boxes; a.bitmask = ws.bitmask; a.out_grad = out_grad; a.rows = ws.bwd_rows;
     a.means_grad = means_grad; a.opa_grad = opa_grad; a.sem_grad = sem_grad; a.cov_grad = cov_grad; a.state = state;
     a.tile_counters = ws.flags + kBwdCounters; a.gen_word = gen_word; a.row_first = ws.bwd_row_first; a.wave_total = ws.bwd_wave_total;
+    a.big_table = ws.bwd_wave_total + kBwdBigTableAt;
     a.lists = getenv("GF_BWD_NO_LISTS") ? nullptr : ws.bwd_lists; a.list_len = ws.bwd_list_len; a.lists_bad = ws.flags + kListsBad;
     a.P = P; a.N = N; a.nwords = ws.nwords; a.nrow = ws.nrow; a.H = H; a.W = W; a.D = D; a.nsx = ws.nsx; a.nsy = ws.nsy;
     a.gate = gate ? 1 : 0; a.records_asserted = records_asserted;
@@ -1204,8 +1282,8 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
     if (getenv("GF_UNITS_BANDS") != nullptr) hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<false>, dim3(grid), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
     BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, ws.bwd_row_first, gen_word,
-                  ws.flags + kBwdCounters, state, (uint32_t)(grid / 8), P, gate, (P + 31) / 32, records_asserted};
-    hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + 256), dim3(256), 0, stream, r);
+                  ws.bwd_wave_total + kBwdBigTableAt, ws.flags + kBwdCounters, state, (uint32_t)(grid / 8), P, gate, (P + 31) / 32, records_asserted};
+    hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + (getenv("GF_X_NO_BIG") ? 0 : 256)), dim3(256), 0, stream, r);
 }
 
 }  // namespace gf
