@@ -39,6 +39,10 @@
 #ifndef GF_X
 #define GF_X 0   // development: timing experiments in the solo kernel (tools/xbuild.sh); 0 in the product
 #endif
+#ifndef GF_XP
+#define GF_XP 0   // development: parts of the records pass compiled out (timing experiments only: 1 bitmask stores, 2 record
+                  // stores, 4 LDS atomics, 8 verification waves, 16 records waves)
+#endif
 
 namespace gf {
 
@@ -127,13 +131,15 @@ __device__ __forceinline__ uint32_t range_bits_of(const float *c, const float *s
     return ((!(bound < 3.0e4f) || !(Q < 1331.4f)) ? 4u : 0u) | ((snan || !(smax < kSemRangeMax)) ? 8u : 0u);
 }
 
-template <int WAVES>
+// STAGED: the records of a wave's 64 Gaussians pass through an LDS image (coalesced loads and stores: large P); !STAGED: each lane
+// loads and stores its own Gaussian (one memory round trip: small P, where the pass is a chain of latencies).
+template <int WAVES, bool STAGED = (WAVES > 1)>
 __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
 {
     // Gaussian role: every wave turns 64 Gaussians into one bitmask word per supertile; a
     // workgroup of WAVES waves owns WAVES consecutive words, so the bitmask rows are written
-    // in 8*WAVES-byte runs (WAVES = 1 for small P, where many small workgroups hide latency
-    // best; WAVES = 4 for large P, where the 8-byte scattered stores dominated: 39 us at P = 144 000).
+    // in 8*WAVES-byte runs (WAVES = 2 for small P -- small workgroups hide latency best, but single-wave ones spent 2.7 of
+    // 9.5 us in their 8-byte scattered stores --; WAVES = 4 for large P, where those stores dominated: 39 us at P = 144 000).
     // LDS is sized at launch: [min(#supertiles, chunk)][WAVES] words.
     extern __shared__ unsigned long long s_bits[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,6 +158,8 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         if (WAVES > 1) __syncthreads();
         else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // single wave: LDS ops stay ordered
     };
+    if (GF_XP & 8) { if ((int)blockIdx.x >= a.nprep_blocks) return; }
+    if (GF_XP & 16) { if ((int)blockIdx.x < a.nprep_blocks) return; }
     if ((int)blockIdx.x >= a.nprep_blocks) {
         // ---- verification role: is point n in voxel n for all n?  Each wave reports its own
         // slice unconditionally (no zero-initialised flag needed).
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     // waited for first -- from a clamped index instead of under `if (valid)`: a load inside a branch is
     // waited for inside it, which put the box, the parameters and the stores one round trip after the other.
     float c_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sm_in[kC], mean_in[3] = {0.f, 0.f, 0.f}, opa_in = 0.f;
-    if (WAVES == 1) {
+    if (!STAGED) {
         const int gc = min(g, a.P - 1);
         const int m0 = a.means_int[3 * gc], m1 = a.means_int[3 * gc + 1], m2 = a.means_int[3 * gc + 2];
         const int r0 = a.radii[a.per_axis ? 3 * gc : gc], r1 = a.radii[a.per_axis ? 3 * gc + 1 : gc],
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     int rq0 = 0, rq1 = 0, rq2 = 0;
     float4 sv4[5], cv4[2];
     bool staged_fast = false;
-    if (WAVES > 1) {
+    if (STAGED) {
         const int gc = min(g, a.P - 1);
         const int m0 = a.means_int[3 * gc], m1 = a.means_int[3 * gc + 1], m2 = a.means_int[3 * gc + 2];
         rq0 = a.radii[a.per_axis ? 3 * gc : gc]; rq1 = a.radii[a.per_axis ? 3 * gc + 1 : gc]; rq2 = a.radii[a.per_axis ? 3 * gc + 2 : gc];
@@ -368,11 +376,11 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
     const int nsuper = a.nsx * a.nsy;
     // zero the first LDS chunk while the parameter loads are in flight
     for (int i = threadIdx.x; i < min(chunk, nsuper) * WAVES; i += 64 * WAVES) s_bits[i] = 0ull;
-    if (WAVES == 1) {
+    if (!STAGED) {
         // ---- records, small P: each lane loads and stores its own Gaussian (strided, but one
         // memory round trip; the staged variant below costs two more and measured 2 us slower
         // at P = 25 601, where the kernel is latency-bound)
-        if (valid) {
+        if (valid && !(GF_XP & 2)) {
             const uint32_t plo = pack3(lo[0], lo[1], lo[2]);
             const uint32_t phi = nonempty ? pack3(hi[0], hi[1], hi[2]) : plo;
             a.boxes[g] = make_uint2(plo, phi);
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         }
         wg_sync();
         // small footprints: each lane ORs its own bit (order-independent => deterministic)
-        if (npairs > 0 && npairs <= 16) {
+        if (npairs > 0 && npairs <= 16 && !(GF_XP & 4)) {
             for (int sx = sx_lo; sx <= sx_hi; ++sx)
                 for (int sy = sy_lo; sy <= sy_hi; ++sy) {
                     const int s = sx * a.nsy + sy - s0;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         wg_sync();
         for (int i = threadIdx.x; i < ns * WAVES; i += 64 * WAVES) {
             const int si = i / WAVES, w = i - si * WAVES;
-            if ((int)blockIdx.x * WAVES + w < a.nwords) {
+            if ((int)blockIdx.x * WAVES + w < a.nwords && !(GF_XP & 1)) {
                 const unsigned long long bits = s_bits[i];
                 a.bitmask[(size_t)(s0 + si) * a.nrow + blockIdx.x * WAVES + w] = bits;
             }
@@ -2721,7 +2729,7 @@ void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, in
     pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.pts = pts; pa.records = ws.records; pa.boxes = ws.boxes;
     pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
     pa.nwords = ws.nwords; pa.nrow = ws.nrow; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
-    const int prep_waves = P >= 65536 ? 4 : 1;
+    const int prep_waves = P >= 65536 ? 4 : 2;   // (as in the forward)
     pa.variant = GF_SPLAT_BASE; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = 0;
     pa.prescale = 0; pa.exact_det = 0; pa.lattice = 0;
     pa.tile_counters = nullptr; pa.tile_counter_init = 0u;   // (the backward's set-up kernel arms the unit counters)
@@ -2730,9 +2738,9 @@ void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, in
     pa.bwd_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);
     pa.gen_word = ws.flags + kGenWord; pa.gate_state = state;
     const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
-                            (prep_waves > 1 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
-    if (prep_waves == 1) hipLaunchKernelGGL(gf_splat_prep_kernel<1>, dim3(pa.nprep_blocks), dim3(64), prep_lds, stream, pa);
-    else hipLaunchKernelGGL(gf_splat_prep_kernel<4>, dim3(pa.nprep_blocks), dim3(256), prep_lds, stream, pa);
+                            (P >= 65536 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
+    if (P >= 65536) hipLaunchKernelGGL(gf_splat_prep_kernel<4>, dim3(pa.nprep_blocks), dim3(256), prep_lds, stream, pa);
+    else hipLaunchKernelGGL((gf_splat_prep_kernel<2, false>), dim3(pa.nprep_blocks), dim3(128), prep_lds, stream, pa);
 }
 
 }  // namespace gf
@@ -2836,7 +2844,13 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.radii = radii; pa.cov3D = cov3D; pa.points_int = points_int; pa.pts = pts; pa.records = ws.records; pa.boxes = ws.boxes;
     pa.bitmask = ws.bitmask; pa.verify_flags = ws.flags + 64; pa.P = P; pa.N = N; pa.H = H; pa.W = W; pa.D = D;
     pa.nwords = ws.nwords; pa.nrow = ws.nrow; pa.nsx = ws.nsx; pa.nsy = ws.nsy; pa.per_axis = radii_per_axis ? 1 : 0;
-    const int prep_waves = P >= 65536 ? 4 : 1;
+    // Waves per workgroup of the records pass = the length of the runs the bitmask rows are written in (a workgroup of W waves owns
+    // W consecutive words of every row).  Small P: TWO, with the records still loaded and stored per lane (round 5: compiling parts
+    // out of the pass showed 2.7 of its 9.5 us in the 625 scattered 8-byte stores of a single-wave workgroup; 16-byte runs:
+    // 43.8 -> 41.9 us per step at P = 25 601; runs of 32 bytes 42.9, of 64 bytes 44.8 -- the workgroup barriers take over).
+    // GF_PREP_WAVES=1|2|4|8 overrides it (development).
+    const int env_waves = (P < 65536 && getenv("GF_PREP_WAVES")) ? atoi(getenv("GF_PREP_WAVES")) : 0;
+    const int prep_waves = P >= 65536 ? 4 : (env_waves == 1 || env_waves == 2 || env_waves == 4 || env_waves == 8) ? env_waves : 2;
     pa.variant = variant; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = verify ? 1 : 0;
     // matrix-core kernel: the default wherever it applies (include/gf_hip.h, GF_MFMA_SPLAT / GF_EXACT_FP32)
     // (the label epilogue -- argmax mode -- is built into the wave-autonomous kernel only: rows of <= kWRow words)
@@ -2886,10 +2900,13 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
                 (int)(pa.unit_totals != nullptr), ws.nrow, D, P, (int)stream_is_capturing(stream), (int)xcc_census_ok());
     const int prep_grid = fused ? 0 : pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
-        const size_t prep_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk) +
-                                (prep_waves > 1 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
+        const size_t bits_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk);
+        const size_t prep_lds = bits_lds + (P >= 65536 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
         if (prep_waves == 1) hipLaunchKernelGGL(gf_splat_prep_kernel<1>, dim3(prep_grid), dim3(64), prep_lds, stream, pa);
-        else hipLaunchKernelGGL(gf_splat_prep_kernel<4>, dim3(prep_grid), dim3(256), prep_lds, stream, pa);
+        else if (P >= 65536) hipLaunchKernelGGL(gf_splat_prep_kernel<4>, dim3(prep_grid), dim3(256), prep_lds, stream, pa);
+        else if (prep_waves == 2) hipLaunchKernelGGL((gf_splat_prep_kernel<2, false>), dim3(prep_grid), dim3(128), prep_lds, stream, pa);
+        else if (prep_waves == 4) hipLaunchKernelGGL((gf_splat_prep_kernel<4, false>), dim3(prep_grid), dim3(256), prep_lds, stream, pa);
+        else hipLaunchKernelGGL((gf_splat_prep_kernel<8, false>), dim3(prep_grid), dim3(512), prep_lds, stream, pa);
         GF_CHECK_LAUNCH();
     }
     if (N == 0) return GF_OK;
