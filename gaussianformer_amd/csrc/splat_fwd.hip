@@ -133,6 +133,8 @@ __device__ __forceinline__ uint32_t range_bits_of(const float *c, const float *s
 
 // STAGED: the records of a wave's 64 Gaussians pass through an LDS image (coalesced loads and stores: large P); !STAGED: each lane
 // loads and stores its own Gaussian (one memory round trip: small P, where the pass is a chain of latencies).
+// (Measured and not kept, round 5: with !STAGED, the lanes' records leaving through a wave-private LDS image as eight contiguous
+// 1 KB stores per wave instead of eight 16-byte pieces per lane at a 128-byte stride -- 41.85 against 41.55 us per step.)
 template <int WAVES, bool STAGED = (WAVES > 1)>
 __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
 {
@@ -391,24 +393,27 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
                 kdet = prob_kdet(c0, c1, c2, c3, c4, c5, a.exact_det);
             }
             const float *sm = sm_in;
-            float4 *rec = reinterpret_cast<float4 *>(a.records + (size_t)g * kRecDwords);
-            rec[0] = make_float4(mean_in[0], mean_in[1], mean_in[2], opa_in);
+            float4 piece[8];
+            piece[0] = make_float4(mean_in[0], mean_in[1], mean_in[2], opa_in);
             if (a.prescale) {
                 // quadratic form pre-multiplied by log2(e) (and its -1/2) in fp64, rounded once:
                 // the render kernels then need a bare v_exp_f32.  Slots: (a, d, f, b, e, c) for
                 //   p2 = dx(a dx + b dy + c dz) + dy(d dy + e dz) + f dz^2 = log2(e) * (-1/2 d^T S^-1 d)
                 const double L = 1.4426950408889634074;
-                rec[1] = make_float4((float)(-0.5 * L * c0), (float)(-0.5 * L * c1), (float)(-0.5 * L * c2), (float)(-L * c3));
-                rec[2] = make_float4((float)(-L * c4), (float)(-L * c5), __uint_as_float(plo), __uint_as_float(phi));
+                piece[1] = make_float4((float)(-0.5 * L * c0), (float)(-0.5 * L * c1), (float)(-0.5 * L * c2), (float)(-L * c3));
+                piece[2] = make_float4((float)(-L * c4), (float)(-L * c5), __uint_as_float(plo), __uint_as_float(phi));
             } else {
-                rec[1] = make_float4(c0, c1, c2, c3);
-                rec[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
+                piece[1] = make_float4(c0, c1, c2, c3);
+                piece[2] = make_float4(c4, c5, __uint_as_float(plo), __uint_as_float(phi));
             }
-            rec[3] = make_float4(sm[0], sm[1], sm[2], sm[3]);
-            rec[4] = make_float4(sm[4], sm[5], sm[6], sm[7]);
-            rec[5] = make_float4(sm[8], sm[9], sm[10], sm[11]);
-            rec[6] = make_float4(sm[12], sm[13], sm[14], sm[15]);
-            rec[7] = make_float4(sm[16], sm[17], kdet, 0.f);
+            piece[3] = make_float4(sm[0], sm[1], sm[2], sm[3]);
+            piece[4] = make_float4(sm[4], sm[5], sm[6], sm[7]);
+            piece[5] = make_float4(sm[8], sm[9], sm[10], sm[11]);
+            piece[6] = make_float4(sm[12], sm[13], sm[14], sm[15]);
+            piece[7] = make_float4(sm[16], sm[17], kdet, 0.f);
+            float4 *rec = reinterpret_cast<float4 *>(a.records + (size_t)g * kRecDwords);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rec[k] = piece[k];
         }
     } else {
         // ---- records, large P.  The 64 Gaussians of a wave are contiguous in every input array, so the
