@@ -44,6 +44,10 @@
 
 #include "gf_common.hpp"
 
+#ifndef GF_XB
+#define GF_XB 0   // development, timing experiments only (wrong results): 1 = every row store goes to row 0 (same instructions, no scatter),
+                  // 4 = the four blocks of a group compiled out
+#endif
 #ifndef GF_TIMELINE
 #define GF_TIMELINE 0  // -DGF_TIMELINE=1: per-unit timestamps of the gradient kernel (tools/timeline_bwd.py)
 #endif
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #pragma unroll
                         for (int q = 0; q < 16; ++q) { mom[q] = 0.f; dsm[q] = 0.f; }
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
+                        for (int b = 0; b < ((GF_XB & 4) ? 0 : 4); ++b) {
                             // one-hot operand of this block: half 0 takes set b & 1, half 1 set b >> 1 (selected register by register:
                             // indexing the two sets with a per-lane index sends them through scratch memory)
                             typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -946,7 +950,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
                             if (has_row) {
                                 // SIX store instructions per group, whatever the lanes hold (the counted wait above relies on it):
                                 // two that both halves take part in, four of half 0
-                                float4 *row = reinterpret_cast<float4 *>(a.rows + ((size_t)first + (size_t)idx) * kBwdRowDwords);
+                                float4 *row = reinterpret_cast<float4 *>(a.rows + ((GF_XB & 1) ? (size_t)0 : (size_t)first + (size_t)idx) * kBwdRowDwords);
                                 row[h] = make_float4(o[0], o[1], o[2], o[3]);
                                 row[2 + h] = make_float4(o[4], o[5], o[6], o[7]);
                                 if (h == 0) {
