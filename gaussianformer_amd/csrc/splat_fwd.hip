@@ -2854,8 +2854,10 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     // out of the pass showed 2.7 of its 9.5 us in the 625 scattered 8-byte stores of a single-wave workgroup; 16-byte runs:
     // 43.8 -> 41.9 us per step at P = 25 601; runs of 32 bytes 42.9, of 64 bytes 44.8 -- the workgroup barriers take over).
     // GF_PREP_WAVES=1|2|4|8 overrides it (development).
-    const int env_waves = (P < 65536 && getenv("GF_PREP_WAVES")) ? atoi(getenv("GF_PREP_WAVES")) : 0;
-    const int prep_waves = P >= 65536 ? 4 : (env_waves == 1 || env_waves == 2 || env_waves == 4 || env_waves == 8) ? env_waves : 2;
+    const int env_waves = getenv("GF_PREP_WAVES") ? atoi(getenv("GF_PREP_WAVES")) : 0;
+    const bool env_ok = env_waves == 1 || env_waves == 2 || env_waves == 4 || env_waves == 8;
+    const bool staged = P >= 65536 && !env_ok;   // (large P: the records through an LDS image, four waves per workgroup)
+    const int prep_waves = env_ok ? env_waves : P >= 65536 ? 4 : 2;
     pa.variant = variant; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = verify ? 1 : 0;
     // matrix-core kernel: the default wherever it applies (include/gf_hip.h, GF_MFMA_SPLAT / GF_EXACT_FP32)
     // (the label epilogue -- argmax mode -- is built into the wave-autonomous kernel only: rows of <= kWRow words)
@@ -2906,9 +2908,9 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     const int prep_grid = fused ? 0 : pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t bits_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk);
-        const size_t prep_lds = bits_lds + (P >= 65536 ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
+        const size_t prep_lds = bits_lds + (staged ? (size_t)prep_waves * 64 * kRecDwords * sizeof(float) : 0);
         if (prep_waves == 1) hipLaunchKernelGGL(gf_splat_prep_kernel<1>, dim3(prep_grid), dim3(64), prep_lds, stream, pa);
-        else if (P >= 65536) hipLaunchKernelGGL(gf_splat_prep_kernel<4>, dim3(prep_grid), dim3(256), prep_lds, stream, pa);
+        else if (staged) hipLaunchKernelGGL(gf_splat_prep_kernel<4>, dim3(prep_grid), dim3(256), prep_lds, stream, pa);
         else if (prep_waves == 2) hipLaunchKernelGGL((gf_splat_prep_kernel<2, false>), dim3(prep_grid), dim3(128), prep_lds, stream, pa);
         else if (prep_waves == 4) hipLaunchKernelGGL((gf_splat_prep_kernel<4, false>), dim3(prep_grid), dim3(256), prep_lds, stream, pa);
         else hipLaunchKernelGGL((gf_splat_prep_kernel<8, false>), dim3(prep_grid), dim3(512), prep_lds, stream, pa);
