@@ -45,6 +45,7 @@ SIGNATURES = {
     "gf_daf_backward": (_i, [_i] * 7 + [_vp] * 10),
     "gf_daf_backward_workspace_bytes": (_sz, [_i] * 7),
     "gf_daf_backward_sorted": (_i, [_i] * 7 + [_vp] * 9 + [_vp, _sz, _vp]),
+    "gf_subm_voxelize": (_i, [ctypes.c_longlong, _i, _i, _i] + [_vp] * 6 + [_vp]),
     "gf_subm_tables_bytes": (_sz, [_i] * 6),
     "gf_subm_rulebook_count": (_i, [_i] * 6 + [_vp, _vp, _sz, _vp]),
     "gf_subm_rulebook_fill": (_i, [_i] * 6 + [_vp] * 4 + [_vp]),

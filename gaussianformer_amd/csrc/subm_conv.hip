@@ -665,6 +665,72 @@ static SubmArgs subm_args(int N, int batch, int X, int Y, int Z, int K, const in
 
 }  // namespace gf
 
+namespace gf {
+
+// Voxel indices of the anchor centres: SparseConv3D's own preamble (spconv3d_module.py:56-66 with `cartesian`,
+// model/encoder/gaussian_encoder/utils.py:26-36, and `safe_sigmoid`, model/utils/safe_ops.py:7-9), which the reference writes as a
+// dozen elementwise torch ops (clamp, sigmoid, three multiply-adds, stack, subtract, divide, cast, arange, repeat, cat): here one
+// launch, with the same fp32 operations in the same order, every one of them rounded on its own (no fused multiply-add: the
+// reference's ops are separate kernels), so that the truncated indices are the reference's.
+struct VoxelizeArgs {
+    const float *anchor;   // [rows, stride] fp32, the first three columns are the centre
+    int *out;              // [rows, 4] (batch, x, y, z)
+    long long rows;
+    int stride, per_batch, use_sigmoid;
+    float span[3], lo[3], pc_lo[3], grid[3];
+};
+
+__global__ __launch_bounds__(256) void gf_subm_voxelize_kernel(VoxelizeArgs a)
+{
+#pragma clang fp contract(off)   // every product and sum below is its own rounded fp32 operation, as in the reference's separate ops
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.rows) return;
+    const float *p = a.anchor + i * a.stride;
+    // the reference's Python scalars reach its kernels as fp32 casts of these doubles
+    constexpr float kSigLo = (float)-9.21, kSigHi = (float)9.21, kIdLo = (float)1e-6, kIdHi = (float)(1 - 1e-6);
+    int idx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float x = p[k];
+        if (a.use_sigmoid) {
+            // safe_sigmoid: clamp(-9.21, 9.21) (NaN stays NaN, as torch.clamp leaves it), then 1 / (1 + exp(-x))
+            x = x < kSigLo ? kSigLo : x;
+            x = x > kSigHi ? kSigHi : x;
+            const float e = expf(-x);
+            const float d = 1.f + e;
+            x = 1.f / d;
+        } else {
+            x = x < kIdLo ? kIdLo : x;
+            x = x > kIdHi ? kIdHi : x;
+        }
+        const float m = x * a.span[k];
+        const float w = m + a.lo[k];          // xyz * (hi - lo) + lo
+        const float s = w - a.pc_lo[k];
+        const float q = s / a.grid[k];        // (xyz - pc_range[:3]) / grid_size
+        idx[k] = (int)q;                      // .to(torch.int32)
+    }
+    *reinterpret_cast<int4 *>(a.out + 4 * i) = make_int4((int)(i / a.per_batch), idx[0], idx[1], idx[2]);
+}
+
+}  // namespace gf
+
+extern "C" int gf_subm_voxelize(long long rows, int per_batch, int anchor_stride, int use_sigmoid, const float *anchor,
+                                const float *span, const float *lo, const float *pc_lo, const float *grid, int *out, void *stream_)
+{
+    using namespace gf;
+    GF_CHECK_ARG(rows >= 0 && per_batch > 0 && anchor_stride >= 3, "bad size");
+    if (rows == 0) return GF_OK;
+    GF_CHECK_ARG(anchor && span && lo && pc_lo && grid && out, "null pointer");
+    GF_CHECK_ARG(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
+    GF_CHECK_ARG((rows + 255) / 256 < (1ll << 31), "too many rows");
+    VoxelizeArgs a{};
+    a.anchor = anchor; a.out = out; a.rows = rows; a.stride = anchor_stride; a.per_batch = per_batch; a.use_sigmoid = use_sigmoid;
+    for (int k = 0; k < 3; ++k) { a.span[k] = span[k]; a.lo[k] = lo[k]; a.pc_lo[k] = pc_lo[k]; a.grid[k] = grid[k]; }   // (host arrays)
+    hipLaunchKernelGGL(gf_subm_voxelize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
 extern "C" size_t gf_subm_tables_bytes(int N, int batch, int X, int Y, int Z, int K)
 {
     using namespace gf;

@@ -6,6 +6,9 @@ Host mirror of ``SparseConv3D`` (model/encoder/gaussian_encoder/spconv3d_module.
 """
 import math
 
+import ctypes
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd.function import Function, once_differentiable
@@ -253,6 +256,36 @@ class SparseConv3D(nn.Module):
     def voxel_indices(self, anchor):
         """int32 ``[b*g, 4]`` (batch, x, y, z) of the anchor centres (spconv3d_module.py:56-66,
         ``cartesian`` model/encoder/gaussian_encoder/utils.py:26-36, ``safe_sigmoid`` model/utils/safe_ops.py:7-9)."""
+        bs, g = anchor.shape[:2]
+        # (integer indices: nothing to differentiate either way)
+        if anchor.is_cuda and anchor.dtype == torch.float32 and anchor.shape[-1] >= 3 and os.environ.get("GF_SUBM_TORCH_VOXELIZE") is None:
+            return self._voxel_indices_native(anchor)
+        return self._voxel_indices_torch(anchor)
+
+    def _voxel_indices_native(self, anchor):
+        """One launch (``gf_subm_voxelize``) instead of the dozen elementwise ops of ``_voxel_indices_torch``: the same fp32
+        operations in the same order, so the same indices (``tests/test_subm_conv.py``)."""
+        import numpy as np
+        bs, g = anchor.shape[:2]
+        a2 = anchor.detach().reshape(bs * g, anchor.shape[-1])
+        if not a2.is_contiguous():
+            a2 = a2.contiguous()
+        key = (self.pc_range.data_ptr(), self.pc_range._version, self.grid_size.data_ptr(), self.grid_size._version)
+        host = getattr(self, "_voxel_host", None)
+        if host is None or host[0] != key:   # (buffers can be reloaded: one host read per change)
+            r = self._range
+            pc, gs = self.pc_range.detach().cpu().numpy().astype(np.float32), self.grid_size.detach().cpu().numpy().astype(np.float32)
+            arr = lambda v: (ctypes.c_float * 3)(*[float(np.float32(x)) for x in v])
+            host = self._voxel_host = (key, arr([r[3 + a] - r[a] for a in range(3)]), arr([r[a] for a in range(3)]), arr(pc[:3]), arr(gs[:3]))
+        out = torch.empty((bs * g, 4), dtype=torch.int32, device=anchor.device)
+        lib = _lib.load()
+        with torch.cuda.device(anchor.device):
+            rc = lib.gf_subm_voxelize(bs * g, g, a2.shape[1], int(self.use_sigmoid), _lib.ptr(a2), host[1], host[2], host[3], host[4],
+                                      _lib.ptr(out), _lib.current_stream(anchor.device))
+        _lib.check(rc, "gf_subm_voxelize")
+        return out
+
+    def _voxel_indices_torch(self, anchor):
         bs, g = anchor.shape[:2]
         xyz = anchor[..., :3]
         xyz = xyz.clamp(-9.21, 9.21).sigmoid() if self.use_sigmoid else xyz.clamp(min=1e-6, max=1 - 1e-6)

@@ -351,6 +351,13 @@ int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const
  * chain, ~13 % slower).  The weight gradient runs on f32 MFMAs.  Results are deterministic except the weight gradient
  * of segments longer than 512 pairs (float atomics between their chunks).
  */
+/* (round 5) The block's own preamble -- voxel indices (batch, x, y, z) of the anchor centres, spconv3d_module.py:56-66 -- in one
+ * launch instead of a dozen elementwise ops; the same fp32 operations in the same order, each rounded on its own.  `anchor` is
+ * [rows, anchor_stride] fp32 on the device (centre in the first three columns), batch index = row / per_batch; span = hi - lo and
+ * lo of pc_range (what `cartesian` multiplies and adds), pc_lo / grid = the module's pc_range[:3] and grid_size buffers: four host
+ * arrays of three floats.  out: int32 [rows, 4] on the device, 16-byte aligned. */
+int gf_subm_voxelize(long long rows, int per_batch, int anchor_stride, int use_sigmoid, const float *anchor, const float *span,
+                     const float *lo, const float *pc_lo, const float *grid, int *out, void *stream);
 size_t gf_subm_tables_bytes(int N, int batch, int X, int Y, int Z, int K);
 int gf_subm_rulebook_count(int N, int batch, int X, int Y, int Z, int K, const int *indices, void *tables,
                            size_t tables_bytes, void *stream);

@@ -435,3 +435,35 @@ def test_sparse_conv3d_output_range(pairs_per_point):
         subm_conv3d(feat[0].clone().requires_grad_(True), idx, m.layer.weight, 1, m._spatial, 5, rulebook=rb)
     with pytest.raises(RuntimeError):
         Rulebook(idx, 1, m._spatial, 5, out_range=(5, g + 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("activation", ["sigmoid", "identity"])
+def test_voxel_indices_in_one_launch_equal_the_torch_op_sequence(gpu, activation):
+    """``gf_subm_voxelize`` (round 5) against the reference's dozen elementwise ops (spconv3d_module.py:56-66): the same int32
+    indices, element for element, for a million anchors -- random, far out on both sides of the clamp, and exactly on cell
+    boundaries of the grid."""
+    import torch
+    from gaussianformer_amd.sparse_conv import SparseConv3D
+    pc_range, grid = [-50.0, -50.0, -5.0, 50.0, 50.0, 3.0], [0.5, 0.5, 0.5]
+    blk = SparseConv3D(16, 16, pc_range, grid, xyz_activation=activation).to(gpu)
+    g = torch.Generator().manual_seed(5)
+    n = 1 << 19
+    if activation == "sigmoid":
+        a = torch.randn(2, n, 11, generator=g) * 3.0
+        a[0, :1000, :3] = torch.linspace(-30, 30, 1000)[:, None]          # both sides of the clamp
+        # centres that land exactly on cell boundaries: logit of (k * 0.5 + 50) / 100
+        t = (torch.arange(1, 200, dtype=torch.float64) * 0.5) / 100.0
+        a[1, :199, 0] = torch.log(t / (1 - t)).float()
+    else:
+        a = torch.rand(2, n, 11, generator=g)
+        a[0, :100, :3] = torch.linspace(-0.5, 1.5, 100)[:, None]
+        a[1, :199, 1] = ((torch.arange(1, 200, dtype=torch.float64) * 0.5) / 100.0).float()
+    a = a.to(gpu)
+    native = blk._voxel_indices_native(a)
+    ref = blk._voxel_indices_torch(a)
+    assert native.dtype == ref.dtype == torch.int32 and native.shape == ref.shape == (2 * n, 4)
+    assert torch.equal(native, ref), int((native != ref).any(dim=1).sum())
+    # a view with a row stride (anchors sliced out of a wider tensor) goes through the same entry
+    wide = torch.cat([a, a], dim=-1)[..., :11]
+    assert torch.equal(blk.voxel_indices(wide), ref)
