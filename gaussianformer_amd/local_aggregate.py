@@ -414,6 +414,21 @@ class _LocalAggregateProb(torch.autograd.Function):
 class _AggregatorBase(nn.Module):
     """Shared pre-processing of the three ``LocalAggregator`` classes."""
 
+    def _points_int(self, pts):
+        """Voxel indices of the query points: fp32 subtract, fp32 true division, truncation (``.to(torch.int)``) --
+        model/head/localagg/local_aggregate/__init__.py:137-141.  The voxel grid of a model does not change between frames: the
+        result is kept for the LAST ``pts`` tensor seen (same storage, shape and version counter, same ``pc_min`` / cell; a strong
+        reference, so the address cannot be recycled) -- three passes over 640 000 points and their launches per frame otherwise.
+        A caller that builds a new tensor per frame simply recomputes."""
+        key = (pts.data_ptr(), pts._version, tuple(pts.shape), pts.device, self.pc_min.data_ptr(), self.pc_min._version, float(self.grid_size))
+        hit = getattr(self, "_points_int_cache", None)
+        if hit is not None and hit[0] == key and hit[1]._version == key[1]:
+            return hit[2]
+        points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
+        if not torch.cuda.is_current_stream_capturing():
+            self._points_int_cache = (key, pts, points_int)
+        return points_int
+
     def _prepare(self, pts, means3D, opacities, semantics, scales, cov3D):
         assert pts.shape[0] == 1
         pts = pts.squeeze(0)
@@ -425,7 +440,7 @@ class _AggregatorBase(nn.Module):
         cov3D = cov3D.squeeze(0)
         # integer path: fp32 subtract, fp32 true division, truncation (.to(torch.int)) --
         # model/head/localagg/local_aggregate/__init__.py:137-141
-        points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
+        points_int = self._points_int(pts)
         means3D_int = ((means3D.detach() - self.pc_min) / self.grid_size).to(torch.int)
         violations = None
         if self.check_inputs:
@@ -491,7 +506,7 @@ class _AggregatorBase(nn.Module):
         means3D_int, radii, cov6 = _GaussianPrepare.apply(
             means3D, scales.squeeze(0), rotations.squeeze(0), self._pc_min_host, self.grid_size,
             self.scale_multiplier, self.H, self.W, self.D, self._radii_mode, getattr(self, "radii_min", 1), status)
-        points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
+        points_int = self._points_int(pts)
         if self.check_inputs:
             assert int(status.item()) == 0, f"gaussian_prepare status {int(status.item())} (GF_PREPARE_* bits)"
         return self._splat(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov6)

@@ -644,3 +644,27 @@ def test_module_notices_a_dense_grid_that_is_not_its_lattice(gpu):
         m2(t(si.pts), *args[1:])
         torch.cuda.synchronize()
     assert m2._grid_exact is True
+
+
+def test_module_keeps_the_voxel_indices_of_the_last_grid_tensor(gpu):
+    """``points_int`` is recomputed only when the ``pts`` tensor changes (storage, shape or version counter): the second frame
+    on the same grid tensor reuses it, an in-place edit or a new tensor does not."""
+    from gaussianformer_amd.local_aggregate import LocalAggregator
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=14, P=300, H=24, W=24, D=16)
+    m = LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)[None]
+    pts = t(si.pts)
+    rest = (t(si.means3D), t(si.opacities), t(si.semantics), t(si.scales), t(si.cov3D))
+    first = m(pts, *rest)
+    kept = m._points_int_cache[2]
+    again = m(pts, *rest)
+    assert m._points_int_cache[2] is kept and torch.equal(first, again)
+    pts2 = pts.clone()
+    other = m(pts2, *rest)
+    assert m._points_int_cache[2] is not kept and torch.equal(other, first)
+    kept2 = m._points_int_cache[2]
+    pts2[0, 0, 0] += 0.0   # an in-place write bumps the version counter: the indices are recomputed
+    m(pts2, *rest)
+    assert m._points_int_cache[2] is not kept2
+    ref = ((pts2.squeeze(0) - m.pc_min) / m.grid_size).to(torch.int)
+    assert torch.equal(m._points_int_cache[2], ref)
