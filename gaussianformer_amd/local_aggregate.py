@@ -425,7 +425,7 @@ class _AggregatorBase(nn.Module):
         if hit is not None and hit[0] == key and hit[1]._version == key[1]:
             return hit[2]
         points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
-        if not torch.cuda.is_current_stream_capturing():
+        if pts.is_cuda and not torch.cuda.is_current_stream_capturing():
             self._points_int_cache = (key, pts, points_int)
         return points_int
 
