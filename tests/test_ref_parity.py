@@ -18,7 +18,8 @@ import oracle
 from oracle import ref
 from gaussianformer_amd.synthetic import make_daf_inputs, make_splat_inputs
 
-from util import (assert_grad_close, assert_logits_close, hip_splat_backward, hip_splat_forward, prep, to_dev)
+from util import (assert_grad_close, assert_grad_rows_close, assert_logits_abs, assert_logits_close, grad_row_errors,
+                  hip_splat_backward, hip_splat_forward, prep, to_dev, whole_grid_rows)
 
 pytestmark = pytest.mark.gpu
 
@@ -217,9 +218,18 @@ def test_hip_full_size_vs_reference(gpu, reflib, config):
     si = make_splat_inputs(config, seed=0)
     rf, rgrads, grads, stats = _hip_vs_ref(gpu, reflib, si, False, 1)
     print(f"\n[{config}] HIP vs reference: max scaled logits err {stats['logits']:.3e}")
-    for name, a, b in zip(GRAD_NAMES, grads, rgrads):
-        assert_grad_close(a, b, what=f"HIP {name} vs reference")
     pi, mi, radii, cov6 = prep(si)
+    # north_star's bounds, literally: ABSOLUTE 1e-4 on the logits; gradients row by row -- every Gaussian against its
+    # own magnitude (floor: the median ordinary row), the whole-grid "empty" Gaussian judged by itself
+    got, t, state, fwd_t = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    a = assert_logits_abs(got["logits"], rf["logits"], what=f"HIP logits vs reference [{config}]")
+    print(f"[{config}] max ABSOLUTE logits err {a:.3e} (max|logit| {np.abs(rf['logits']).max():.3e})")
+    whole = whole_grid_rows(mi, radii, si.H, si.W, si.D)
+    assert int(whole.sum()) == (1 if config == "nuscenes_gs25600_solid" else 0)
+    for name, a, b in zip(GRAD_NAMES, grads, rgrads):
+        e = assert_grad_rows_close(a, b, whole, what=f"HIP {name} vs reference [{config}]")
+        print(f"[{config}] {name}: worst ordinary row {e['ordinary']:.3e} (floor {e['floor']:.3e}, absolute {e['abs']:.3e}), "
+              f"whole-grid row {e['whole_grid']:.3e}, tensor-wide {e['tensor']:.3e}")
     vols, R = splat_box_volumes(torch.from_numpy(mi).to(gpu), torch.from_numpy(radii).to(gpu), si.H, si.W, si.D)
     assert R == rf["num_rendered"]
     # the restatement at full size, so the full-size oracle comparisons elsewhere are pinned too
@@ -258,6 +268,8 @@ def test_hip_prob_full_size_vs_reference(gpu, reflib, per_axis):
         scale = max(np.abs(b[ok]).max(), 1e-6)
         err = np.abs(a[ok].astype(np.float64) - b[ok]).max() / scale
         print(f"   {name}: max err / max|ref| {err:.3e} ({(~ok).sum()} non-finite reference rows)")
+        er = grad_row_errors(a[ok], b[ok])    # reported, not asserted: the reference's own fp32 quadratic form cancels
+        print(f"   {name}: row by row: worst {er['ordinary']:.3e} (floor {er['floor']:.3e}, absolute {er['abs']:.3e})")
         assert np.isfinite(a[ok]).all() and err <= 1e-3, (name, err)
     if not per_axis:
         # the fp64 determinant (GF_PROB_EXACT_DET) leaves no non-finite voxel and agrees with the reference wherever

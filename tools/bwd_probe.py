@@ -13,7 +13,7 @@ import torch
 from gaussianformer_amd import _lib
 from gaussianformer_amd.local_aggregate import splat_backward, splat_forward
 from gaussianformer_amd.synthetic import make_splat_inputs
-from util import prep, to_dev
+from util import grad_row_errors, prep, to_dev, whole_grid_rows
 
 dev = torch.device("cuda:0")
 mode = sys.argv[1] if len(sys.argv) > 1 else "small"
@@ -54,6 +54,10 @@ def run(si, tag, grad_scale=1.0):
                 errs = [float(np.abs(o.cpu().numpy().reshape(w.shape).astype(np.float64) - w).max() / max(np.abs(w).max(), 1e-30)) for o, w in zip(outs[name], rg)]
                 aerr = [float(np.abs(o.cpu().numpy().reshape(w.shape).astype(np.float64) - w).max()) for o, w in zip(outs[name], rg)]
                 print(f"{tag}: {name:5s} vs oracle/_ref (scaled by max|ref| / absolute): " + ", ".join(f"{n} {e:.2e} / {ae:.2e}" for n, e, ae in zip(names, errs, aerr)), flush=True)
+                whole = whole_grid_rows(mi, radii, si.H, si.W, si.D)
+                rows = [grad_row_errors(o.cpu().numpy().reshape(w.shape), w, whole) for o, w in zip(outs[name], rg)]
+                print(f"{tag}: {name:5s} vs oracle/_ref ROW BY ROW (worst ordinary row / whole-grid row; tests/util.py): "
+                      + ", ".join(f"{n} {e['ordinary']:.2e} / {e['whole_grid']:.2e}" for n, e in zip(names, rows)), flush=True)
     except Exception as exc:
         print("no oracle/_ref:", type(exc).__name__, exc)
     return t, state, g
