@@ -23,6 +23,8 @@ constexpr int kBwdList = 256;       // candidate-list entries of the matrix-core
 constexpr int kListsBad = 8101;      // flag-section word: a supertile's list did not fit kBwdList (the backward then scans the bitmask rows itself)
 constexpr int kFusedCounters = 6144; // flag-section index of the fused forward's per-XCD counter blocks ([+ 128 x] dwords = 64 64-bit words each)
 constexpr int kFusedRowMax = 1024;   // bitmask row words up to which a workspace carries the fused forward's per-XCD copies
+constexpr int kVerdictWords = 8104;  // flag-section index (16-byte aligned) of the single-word verdict block [A, B, V0, V1] of a workspace that was
+                                     // handed over zeroed (GF_WORKSPACE_ZEROED; splat_fwd.hip, "one verdict word")
 constexpr int kGenWord = 8100;       // generation word of a workspace: index into its flag section -- the same word whatever the call's
                                      // shape; every launch that rewrites the records (or the sections they share with other shapes) bumps it
 

@@ -39,6 +39,12 @@
 #ifndef GF_X
 #define GF_X 0   // development: timing experiments in the solo kernel (tools/xbuild.sh); 0 in the product
 #endif
+#ifndef GF_VD1
+#define GF_VD1 1   // one verdict word on GF_WORKSPACE_ZEROED workspaces (gf_splat_prep_kernel); 0: every render wave reads every verdict word
+#endif
+#ifndef GF_PHITAB
+#define GF_PHITAB 1   // wave kernel: the exponent MFMAs' B operands from a compile-time table (kPhiHot) instead of 235 VALU per wave
+#endif
 #ifndef GF_XP
 #define GF_XP 0   // development: parts of the records pass compiled out (timing experiments only: 1 bitmask stores, 2 record
                   // stores, 4 LDS atomics, 8 verification waves, 16 records waves)
@@ -70,6 +76,8 @@ struct PrepArgs {
     uint32_t *gen_word;      // null, or the workspace's generation word: bumped by every launch that rewrites the records
     const uint32_t *gate_state;  // null, or (backward) the forward's state block: stand down if the workspace still holds its records
     int range_theta_here;    // 1: the records pass checks theta as well as opacity * semantics (no verification waves: GF_PTS_ASSUME_DENSE)
+    uint32_t *verdict_words; // null, or the workspace's verdict block [A, B, V0, V1] (kVerdictWords; GF_WORKSPACE_ZEROED callers):
+                             // a wave that finds a violation ORs its bits into V[(A + 1) & 1] -- see "one verdict word" below
     uint32_t *range_flags;   // null, or [nwords + 4]: per wave of 64 Gaussians, bit 2 = a Gaussian's theta may leave the f16
                              // range, bit 3 = |opacity * semantics| may (matrix-core render kernel: both change per frame, so
                              // they are checked in the records pass on EVERY call, GF_PTS_ASSUME_DENSE included)
@@ -251,10 +259,21 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         }
         const unsigned long long any = __builtin_amdgcn_ballot_w64(bad), any2 = __builtin_amdgcn_ballot_w64(bad_lattice),
                                  any3 = __builtin_amdgcn_ballot_w64((rbits & 4u) != 0u);
-        if (lane == 0) a.verify_flags[vb] = (any ? 1u : 0u) | (any2 ? 2u : 0u) | (any3 ? 4u : 0u);
+        const uint32_t vbits = (any ? 1u : 0u) | (any2 ? 2u : 0u) | (any3 ? 4u : 0u);
+        if (lane == 0) a.verify_flags[vb] = vbits;
+        if (a.verdict_words && vbits && lane == 0) atomicOr(a.verdict_words + 2 + ((a.verdict_words[0] + 1u) & 1u), vbits);   // (rare)
         return;
     }
     if (a.tile_counters && blockIdx.x == 0 && threadIdx.x < 8) a.tile_counters[64 * threadIdx.x] = a.tile_counter_init;
+    // One verdict word (round 6).  Every wave of this launch stores its verdict word unconditionally (nothing to zero) and every
+    // render wave used to read ALL of them: 16 + 3 sixteen-byte loads per lane, 19 KB per wave, 39 MB of L2 reads per launch for a
+    // value that is almost always 0.  On a workspace that was handed over zeroed once (GF_WORKSPACE_ZEROED) the verdict is ONE
+    // word instead: a block [A, B, V0, V1] of the flag section with A == B between calls; a wave of this launch that finds a
+    // violation (rare) ORs its bits into V[(A + 1) & 1] (A is not written during this launch), workgroup 0 publishes B = A + 1;
+    // every render wave reads the block with one load and takes V[B & 1] (B is not written during the render launch), render
+    // workgroup 0 stores A = B and clears the OTHER word, V[(B + 1) & 1] -- the one the next call's violators will use.  All the
+    // state lives on the device, so a replayed HIP graph behaves like an eager call.
+    if (a.verdict_words && blockIdx.x == 0 && threadIdx.x == 0) a.verdict_words[1] = a.verdict_words[0] + 1u;
     const int word = blockIdx.x * WAVES + wave;  // bitmask word of this wave
     const int g = word * 64 + lane;
     const bool valid = g < a.P;
@@ -517,6 +536,8 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         const unsigned long long b2 = __builtin_amdgcn_ballot_w64((range_bits & 4u) != 0u),
                                  b3 = __builtin_amdgcn_ballot_w64((range_bits & 8u) != 0u);
         if (lane == 0 && word < a.nwords) a.range_flags[word] = (b2 ? 4u : 0u) | (b3 ? 8u : 0u);
+        if (a.verdict_words && (b2 | b3) && lane == 0)   // (rare)
+            atomicOr(a.verdict_words + 2 + ((a.verdict_words[0] + 1u) & 1u), (b2 ? 4u : 0u) | (b3 ? 8u : 0u));
         if (word == a.nwords - 1 && lane >= 1 && lane <= 3) a.range_flags[a.nwords - 1 + lane] = 0u;
     }
     const unsigned long long mybit = 1ull << lane;
@@ -589,6 +610,8 @@ struct RenderArgs {
     uint32_t *unit_first;                       // ... [P] first row of every Gaussian, written by the wave kernel
     uint32_t unit_cap;                          // ... rows available
     uint32_t *pub_lists, *pub_len;              // ... [nsuper][3][kBwdList] / [nsuper]: the candidate lists, published for the backward
+    uint32_t *verdict_words;   // null, or the workspace's verdict block [A, B, V0, V1] (gf_splat_prep_kernel, "one verdict word"): the wave
+                               // kernel reads it with ONE load instead of every prep wave's verdict word
 };
 
 // Words 3 and 4 of the state block: the workspace's generation (gf_splat_prep_kernel bumped it) and whether the records carry
@@ -1857,6 +1880,46 @@ __global__ __launch_bounds__(kBlock, 2) void gf_splat_render_mfma_kernel(RenderA
     }
 }
 
+// B operands of the exponent MFMAs (monomials phi and one-hot coordinates) of every lane's voxel in each of a double brick's four
+// blocks, as a compile-time table: [piece 0..3 = phi of block b, 4..7 = one-hot of block b][lane] sixteen bytes each, 8 KB, read
+// with eight coalesced loads at the start of a wave (they join the loads already in flight there).  Built in registers they were
+// 235 VALU instructions at the start of EVERY wave -- with two waves per SIMD starting together, ~0.8 us before the first unit of
+// the launch (round-6 census, profiles/census_wave_r06.txt).  Every value is a multiple of 1/4 of magnitude <= 12.25: exact in f16.
+struct PhiHotTable { uint32_t w[8][64][4]; };
+constexpr uint32_t f16_of_quarters(int k)   // f16 bits of k / 4, |k| <= 2047
+{
+    if (k == 0) return 0u;
+    const uint32_t sign = k < 0 ? 0x8000u : 0u;
+    uint32_t m = (uint32_t)(k < 0 ? -k : k);
+    int msb = 0;
+    for (int i = 0; i < 11; ++i) if (m >> i) msb = i;
+    return sign | ((uint32_t)(msb - 2 + 15) << 10) | ((m << (10 - msb)) & 0x3FFu);
+}
+constexpr PhiHotTable make_phi_hot_table()
+{
+    PhiHotTable t{};
+    for (int lane = 0; lane < 64; ++lane) {
+        const int n = lane & 31, h = lane >> 5;
+        for (int b = 0; b < 4; ++b) {
+            // half-integer offsets of the voxel from the double brick's centre, in halves: ux = lx - 1.5, uy = ly - 1.5, uz = z - 3.5
+            const int lx = 2 * (b & 1) + (n >> 4), ly = (n >> 2) & 3, zz = 4 * (b >> 1) + (n & 3);
+            const int x2 = 2 * lx - 3, y2 = 2 * ly - 3, z2 = 2 * zz - 7;   // 2 u
+            // quarters: 1 -> 4, u -> 2 (2u), u v -> (2u)(2v)
+            const int m0[8] = {4, 2 * x2, 2 * y2, 2 * z2, x2 * x2, 0, 0, 0};
+            const int m1[8] = {y2 * y2, z2 * z2, x2 * y2, y2 * z2, x2 * z2, 0, 0, 0};
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t ph = f16_of_quarters(h ? m1[j] : m0[j]);
+                const bool one = h ? zz == j : (j < 4 ? lx == j : ly == j - 4);
+                const uint32_t ho = one ? 0x3C00u : 0u;
+                t.w[b][lane][j >> 1] |= ph << (16 * (j & 1));
+                t.w[4 + b][lane][j >> 1] |= ho << (16 * (j & 1));
+            }
+        }
+    }
+    return t;
+}
+__device__ const PhiHotTable kPhiHot = make_phi_hot_table();
+
 // ---------------------------------------------------------------------------------------
 // Wave-autonomous matrix-core render kernel (bitmask rows of <= kWRow words, i.e. P <= 39 552; longer rows keep the tile
 // kernel above).  The arithmetic is gf_splat_render_mfma_kernel's, group for group; what changes is who owns what:
@@ -1949,12 +2012,29 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                      : "v"(pp), "v"(pp + ix), "v"(pp + iy), "v"(pp + iz)
                      : "memory");
     }
+#if GF_PHITAB
+    uint4 phihot_raw[8];
+    {
+        const uint4 *tp = reinterpret_cast<const uint4 *>(&kPhiHot.w[0][0][0]) + lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) phihot_raw[k] = tp[64 * k];
+    }
+#endif
     // verdicts of the prep launch (see gf_splat_render_mfma_kernel): the point scans' (GF_PTS_AUTO) and the records pass's range
     // verdicts (every call, GF_PTS_ASSUME_DENSE included).  All loads first, then the ballots: ONE memory round trip.  (The range
     // words: three clamped 16-byte reads per lane cover the <= 618 + 4 words of the rows this kernel takes -- no loop: as a loop
     // every iteration was a round trip of its own at the start of every wave, +4.6 us per launch.)
     int verdict = 0;
-    {
+    if (a.verdict_words) {
+        // one verdict word (gf_splat_prep_kernel): [A, B, V0, V1], one 16-byte load, the same address in every lane
+        const uint4 vw = *reinterpret_cast<const uint4 *>(a.verdict_words);
+        const uint32_t vv = (vw.y & 1u) ? vw.w : vw.z;
+        verdict = __builtin_amdgcn_readfirstlane((int)(vv & (a.verify_dense ? 15u : 12u)));
+        if (blockIdx.x == 0 && lane == 0) {   // A = B; the word the NEXT call's violators will use starts from zero
+            a.verdict_words[0] = vw.y;
+            a.verdict_words[2 + ((vw.y + 1u) & 1u)] = 0u;
+        }
+    } else {
         uint32_t v = 0u, rv = 0u;
         uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
         if (a.range_flags) {
@@ -2005,8 +2085,15 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     const double sy = a.W > 1 ? (double)q1y - p0y : 1.0;
     const double sz = a.D > 1 ? (double)q1z - p0z : 1.0;
 
-    // B operands of the exponent MFMAs: monomials and one-hot coordinates of this lane's voxel in each of the four blocks
+    // B operands of the exponent MFMAs: monomials and one-hot coordinates of this lane's voxel in each of the four blocks (kPhiHot)
     h8 phi[4], hot[4];
+#if GF_PHITAB
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        phi[b] = __builtin_bit_cast(h8, phihot_raw[b]);
+        hot[b] = __builtin_bit_cast(h8, phihot_raw[4 + b]);
+    }
+#else
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const float ux_ = (float)(2 * (b & 1) + (n >> 4)) - 1.5f, uy_ = (float)((n >> 2) & 3) - 1.5f,
@@ -2020,6 +2107,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             hot[b][j] = (_Float16)((h ? zz == j : (j < 4 ? lx == j : ly == j - 4)) ? 1.f : 0.f);
         }
     }
+#endif
 
     auto request_records_at = [&](int qh, int start, int count) {
         const uint32_t id = q_id[(qh + start + (n < count ? n : 0)) & (kQCap - 1)];
@@ -2738,7 +2826,7 @@ void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, in
     pa.variant = GF_SPLAT_BASE; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = 0;
     pa.prescale = 0; pa.exact_det = 0; pa.lattice = 0;
     pa.tile_counters = nullptr; pa.tile_counter_init = 0u;   // (the backward's set-up kernel arms the unit counters)
-    pa.range_flags = nullptr; pa.range_theta_here = 0;
+    pa.range_flags = nullptr; pa.range_theta_here = 0; pa.verdict_words = nullptr;
     pa.unit_totals = ws.bwd_wave_total; pa.unit_local = ws.bwd_row_local; pa.bwd_counters = ws.flags + kBwdCounters;
     pa.bwd_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);
     pa.gen_word = ws.flags + kGenWord; pa.gate_state = state;
@@ -2883,6 +2971,11 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.tile_counters = mfma ? tile_counters : nullptr;
     pa.range_flags = mfma ? ws.range_flags : nullptr;
     pa.range_theta_here = (mfma && !verify) ? 1 : 0;   // (with the point scans running, their waves take the theta verdict)
+    // one verdict word instead of one per prep wave: the wave kernel on a workspace that was handed over zeroed (see gf_splat_prep_kernel)
+    uint32_t *const verdict_words = (GF_VD1 && mfma && (flags & GF_WORKSPACE_ZEROED) &&
+                                     mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr) == 1)
+                                        ? ws.flags + kVerdictWords : nullptr;
+    pa.verdict_words = verdict_words;
     pa.tile_counter_init = !mfma ? 0u
                            : mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr) == 3
                                ? (uint32_t)((solo_waves() == 3 ? mfma_solo_grid<3>(mfma_wave_units(ws.nsuper, D), ws.nrow)
@@ -2935,6 +3028,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.rows_valid = pa.unit_totals ? 1u : 0u;
     ra.unit_totals = ws.bwd_wave_total; ra.unit_local = ws.bwd_row_local; ra.unit_first = ws.bwd_row_first; ra.unit_cap = ws.bwd_cap;
     ra.pub_lists = ws.bwd_lists; ra.pub_len = ws.bwd_list_len;
+    ra.verdict_words = verdict_words;
     if (fused) {
         // (unique per launch; the low 32 bits count from 1 -- the unit counters' tags must grow --, the bits above are a per-process
         // salt, so that item flags a previous process left in recycled device memory cannot pass for this launch's)

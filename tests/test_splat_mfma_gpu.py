@@ -668,3 +668,69 @@ def test_module_keeps_the_voxel_indices_of_the_last_grid_tensor(gpu):
     assert m._points_int_cache[2] is not kept2
     ref = ((pts2.squeeze(0) - m.pc_min) / m.grid_size).to(torch.int)
     assert torch.equal(m._points_int_cache[2], ref)
+
+
+@pytest.mark.parametrize("assume_dense", [False, True])
+def test_one_verdict_word_follows_the_inputs_call_after_call(gpu, assume_dense):
+    """Round 6: on a workspace that was handed over zeroed (GF_WORKSPACE_ZEROED; SplatForwardPlan) the wave kernel reads ONE verdict
+    word -- a double-buffered block [A, B, V0, V1] kept on the device -- instead of every prep wave's word.  The verdict has to follow
+    the inputs call after call on the SAME workspace: violation (range bit 3) -> benign -> violation (theta, bit 2) -> benign ->
+    a pts tensor that is not the lattice (bit 1, with the scans on) -> benign; twice in a row each, so that both parities of the
+    block see both outcomes; every result against the exact-fp32 kernel on a workspace of its own."""
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.local_aggregate import SplatForwardPlan
+    from util import to_dev
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=77, P=600, H=32, W=24, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    t = to_dev(gpu, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
+    base = _lib.GF_PTS_ASSUME_DENSE if assume_dense else 0
+    plan = SplatForwardPlan(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=base)
+    exact = SplatForwardPlan(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=base | _lib.GF_EXACT_FP32)
+    pts, sem, cov, rad = t[0], t[5], t[7], t[6]
+    sem0, cov0, rad0, pts0 = sem.clone(), cov.clone(), rad.clone(), pts.clone()
+
+    def step(path, bits):
+        got = plan.run().clone()
+        torch.cuda.synchronize()
+        assert plan.state_words()[1:3] == [path, bits], (plan.state_words()[:3], path, bits)
+        want = exact.run()
+        assert_logits_close(got.cpu().numpy(), want.cpu().numpy(), tol=1e-4)
+
+    wave, arb = _lib.GF_PATH_MATRIX_CORE_WAVE, _lib.GF_PATH_ARBITRARY
+    for _ in range(2):
+        step(wave, 0)
+    sem[17, 3] = 7e4                                        # |opacity * semantics| >= 64
+    for _ in range(2):
+        step(arb, 8)
+    sem.copy_(sem0)
+    for _ in range(3):
+        step(wave, 0)
+    cov[5] = torch.tensor([1.0 / 0.004 ** 2, 1.0, 1.0, 0, 0, 0], device=gpu)   # theta out of range
+    rad[5] = 12
+    step(arb, 4)
+    sem[40, 0] = 9e4                                        # both at once
+    step(arb, 12)
+    cov.copy_(cov0); rad.copy_(rad0); sem.copy_(sem0)
+    step(wave, 0)
+    if not assume_dense:
+        pts[1000, 2] += 1e-3                                # not the exact lattice any more (the point is still in its voxel)
+        for _ in range(2):
+            step(arb, 2)
+        pts.copy_(pts0)
+        for _ in range(2):
+            step(wave, 0)
+    # the same under HIP-graph replay: the block's state lives on the device
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.run(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            plan.run(stream=s.cuda_stream)
+    for poison in (False, True, True, False, False):
+        sem.copy_(sem0)
+        if poison:
+            sem[17, 3] = 7e4
+        g.replay()
+        torch.cuda.synchronize()
+        assert plan.state_words()[1:3] == ([arb, 8] if poison else [wave, 0]), (poison, plan.state_words()[:3])
+        assert_logits_close(plan.logits.cpu().numpy(), exact.run().cpu().numpy(), tol=1e-4)
