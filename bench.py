@@ -473,35 +473,24 @@ def main():
 
         def clustered_centres():
             # "distribution sensitivity nobody reports".  The same frame with the Gaussians' centres drawn from
-            # sigmoid(N(0, 1)) -- clustered in the middle of the grid, as a trained model's are -- under the unit -> XCD mapping of
-            # this round (supertiles dealt round-robin) and under rounds 3-4's (contiguous bands, GF_UNITS_BANDS=1, read per launch).
-            import os as _os
+            # sigmoid(N(0, 1)) -- clustered in the middle of the grid, as a trained model's are.  (The comparison with rounds 3-4's
+            # contiguous bands of units lives in the development build: tools/interleave_probe.py, profiles/interleave_r05.txt.)
             sc = make_splat_inputs(args.config, seed=0, clustered=True)
             pi, mi, radii, cov6 = oracle.prepare_splat_inputs(sc.pts, sc.means3D, sc.scales, sc.cov3D, sc.pc_min, sc.grid_size,
                                                                 sc.scale_multiplier, radii_min=1 if sc.variant == "prob" else None)
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
             tc = [up(sc.pts), up(pi), up(sc.means3D), up(mi), up(sc.opacities), up(sc.semantics), up(radii), up(cov6)]
             plan = SplatForwardPlan(wl.variant, *tc, sc.H, sc.W, sc.D, flags=_lib.GF_PTS_AUTO)
-            res, outs = {}, {}
-            for name in ("round_robin", "contiguous_bands"):
-                _os.environ.pop("GF_UNITS_BANDS", None)
-                if name == "contiguous_bands":
-                    _os.environ["GF_UNITS_BANDS"] = "1"
-                outs[name] = plan.run(wl.stream).clone()
-                for _ in range(max(2, args.warmup // 2)):
-                    plan.run(wl.stream)
-                torch.cuda.synchronize()
-                t8 = time.perf_counter()
-                for _ in range(args.steps):
-                    plan.run(wl.stream)
-                torch.cuda.synchronize()
-                res[name] = (time.perf_counter() - t8) / args.steps
-            _os.environ.pop("GF_UNITS_BANDS", None)
-            return {"ms_per_step": res["round_robin"] * 1e3, "value": sc.means3D.shape[0] / res["round_robin"], "unit": "Gaussians/s",
-                    "ms_per_step_with_contiguous_bands": res["contiguous_bands"] * 1e3,
-                    "bit_identical_between_the_mappings": bool(torch.equal(outs["round_robin"], outs["contiguous_bands"])),
-                    "note": "same workload with centres ~ sigmoid(N(0,1)); supertiles dealt to the XCDs round-robin (default since round 5) "
-                            "against eight contiguous bands of units (GF_UNITS_BANDS=1)"}
+            for _ in range(max(2, args.warmup // 2)):
+                plan.run(wl.stream)
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            for _ in range(args.steps):
+                plan.run(wl.stream)
+            torch.cuda.synchronize()
+            dt8 = (time.perf_counter() - t8) / args.steps
+            return {"ms_per_step": dt8 * 1e3, "value": sc.means3D.shape[0] / dt8, "unit": "Gaussians/s",
+                    "note": "same workload with centres ~ sigmoid(N(0,1)); supertiles dealt to the XCDs round-robin"}
 
         extra("splat_backward", splat_backward_extra)
         extra("clustered_centres", clustered_centres)

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GF_LIB selects a development variant built by build.build(lib_name=...) (tools/ only)
 LIB_PATH = os.environ.get("GF_LIB") or os.path.join(_HERE, "csrc", "libgf_hip.so")
 
-GF_ABI_VERSION = 2
+GF_ABI_VERSION = 3
 GF_SPLAT_BASE, GF_SPLAT_PROB = 0, 1
 GF_NUM_CHANNELS = 18
 GF_LABELS_ARGMAX, GF_LABELS_PROB_THRESHOLD, GF_LABELS_PROB_GEOSEM = 0, 1, 2
@@ -34,6 +34,9 @@ _vp, _i, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_floa
 SIGNATURES = {
     "gf_abi_version": (_i, []),
     "gf_last_error": (ctypes.c_char_p, []),
+    "gf_set_option": (_i, [ctypes.c_char_p, _i]),
+    "gf_get_option": (_i, [ctypes.c_char_p, _vp]),
+    "gf_is_development_build": (_i, []),
     "gf_splat_workspace_bytes": (_sz, [_i] * 5),
     "gf_splat_state_bytes": (_sz, []),
     "gf_splat_forward": (_i, [_i] * 9 + [_vp] * 13 + [_vp, _sz, _vp]),
@@ -97,6 +100,42 @@ def check(rc, what):
     if rc != 0:
         msg = load().gf_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def set_option(name, value):
+    """``gf_set_option``: a process-wide library option (include/gf_hip.h); explicit calls -- the library never reads the
+    environment.  Returns the previous value.  ``dev.*`` names exist in the development build only (tools/)."""
+    lib = load()
+    old = ctypes.c_int(0)
+    check(lib.gf_get_option(name.encode(), ctypes.addressof(old)), f"gf_get_option({name})")
+    check(lib.gf_set_option(name.encode(), int(value)), f"gf_set_option({name})")
+    return old.value
+
+
+def get_option(name):
+    lib = load()
+    v = ctypes.c_int(0)
+    check(lib.gf_get_option(name.encode(), ctypes.addressof(v)), f"gf_get_option({name})")
+    return v.value
+
+
+class option:
+    """``with _lib.option("splat.mfma_tile_kernel", 1): ...`` -- sets a library option for the block and restores it."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
+
+
+def is_development_build():
+    return bool(load().gf_is_development_build())
 
 
 def ptr(t):

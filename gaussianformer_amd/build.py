@@ -67,5 +67,17 @@ def build(force=False, verbose=False, extra_flags=(), lib_name=None):
     return out_lib
 
 
+DEV_LIB_NAME = "libgf_hip_dev.so"
+
+
+def build_dev(verbose=False):
+    """The development build tools/ use (``-DGF_DEV=1``: the measured-and-not-kept kernels of earlier rounds and the ``dev.*``
+    options of ``gf_set_option``), next to the product library and never in its place.  Select it with ``GF_LIB=<path>``."""
+    return build(force=True, verbose=verbose, extra_flags=("-DGF_DEV=1",), lib_name=DEV_LIB_NAME)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--dev" in sys.argv:
+        print(build_dev(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -17,7 +17,6 @@
 // one workgroup per tile adds its taps row by row in registers -- no float atomics; the order
 // of a row's taps follows integer LDS atomics, so the last bits may differ between runs);
 // shapes the sort does not cover fall back to the reference's atomicAdd scatter.
-#include <stdlib.h>
 
 #include "gf_common.hpp"
 
@@ -1297,13 +1296,13 @@ static int daf_forward_impl(bool pin_groups, int B, int num_cams, int num_feat, 
         const long long npts = (long long)B * num_pts, chunks = (npts + 31) / 32;
         const int chunks_per_sub = (int)((chunks + nsub - 1) / nsub);
         hipLaunchKernelGGL(gf_daf_fwd_grouped_kernel<8>, dim3((unsigned)(8 * chunks_per_sub)), dim3(256), 0, stream, a, chunks_per_sub);
-    } else if (vec == 4 && num_cams <= 8 && C % 8 == 0 && (C / G) % 8 == 0 && getenv("GF_DAF_VEC4") == nullptr) {
+    } else if (vec == 4 && num_cams <= 8 && C % 8 == 0 && (C / G) % 8 == 0 && !dev_option(kOptDafVec4)) {
         // eight channels per lane (bit-identical: the arithmetic per channel is unchanged): the tap geometry of a (point, camera,
         // level) is computed by every lane of the point, so half the lanes per point is half of that work -- 139 -> 117 us with
         // projected geometry at 230 400 points, where the kernel is bound by vector-ALU issue (uniform locations: unchanged)
         a.total = (long long)B * num_pts * (C / 8);
         hipLaunchKernelGGL(gf_daf_fwd4_kernel<8>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a);
-    } else if (vec == 4 && num_cams <= 8 && getenv("GF_DAF_PLAIN") == nullptr)
+    } else if (vec == 4 && num_cams <= 8 && !dev_option(kOptDafPlain))
         hipLaunchKernelGGL(gf_daf_fwd4_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else if (vec == 4) hipLaunchKernelGGL(gf_daf_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else if (vec == 2) hipLaunchKernelGGL(gf_daf_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
@@ -1405,7 +1404,7 @@ extern "C" int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, 
     const int lpp = C / 4, lpg = (C / G) / 4;
     // eight channels per lane where the layout allows (both kernels are bound by vector-ALU issue with projected geometry, and
     // the tap geometry is computed by every lane of a point: half the lanes, half of that work per point)
-    const bool vec8 = C % 8 == 0 && (C / G) % 8 == 0 && is_pow2(C / 8) && is_pow2((C / G) / 8) && C / 8 <= 64 && getenv("GF_DAF_VEC4") == nullptr;
+    const bool vec8 = C % 8 == 0 && (C / G) % 8 == 0 && is_pow2(C / 8) && is_pow2((C / G) / 8) && C / 8 <= 64 && !dev_option(kOptDafVec4);
     if (vec8) {
         a.total = (long long)B * num_pts * (C / 8);
         hipLaunchKernelGGL((gf_daf_bwd_kernel<8, true, false>), dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a, (C / G) / 8, C / 8);
@@ -1424,7 +1423,7 @@ extern "C" int gf_daf_backward_sorted(int B, int num_cams, int num_feat, int C, 
     sa.cam_bits = p.cam_bits; sa.lvl_bits = p.lvl_bits; sa.tile_rows = p.tile_rows; sa.ntiles = p.ntiles;
     sa.samples = (long long)num_pts * num_cams;
     static_assert(sizeof(DafRegionGeom) <= 192, "the regions' geometry fits the workspace header");
-    const bool by_region = p.region_ok && getenv("GF_DAF_TILES") == nullptr;   // (GF_DAF_TILES=1: the tile formulation of round 1, for comparison)
+    const bool by_region = p.region_ok && option(kOptDafBackwardTiles) == 0;   // (gf_set_option("daf.backward_tiles", 1): the tile formulation of round 1 -- also the path of shapes the regions do not take)
     for (int b = 0; b < B; ++b) {
         sa.loc = sampling_location + (size_t)b * num_pts * num_cams * 2;
         sa.weights = weights + (size_t)b * num_pts * num_cams * L * G;

@@ -1,6 +1,8 @@
 // gf_api.hip -- error reporting and ABI version of libgf_hip.so.
 #include <stdarg.h>
+#include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include "gf_common.hpp"
@@ -72,6 +74,51 @@ extern "C" int gf_profile_read(float *ms_out, int capacity)
     gf::g_used = 0;
     return n;
 }
+
+namespace gf {
+static std::atomic<int> g_options[kOptCount];
+int option(int which) { return which >= 0 && which < kOptCount ? g_options[which].load(std::memory_order_relaxed) : 0; }
+static const struct { const char *name; int which; } kOptionNames[] = {
+    {"splat.mfma_tile_kernel", kOptSplatTileKernel}, {"daf.backward_tiles", kOptDafBackwardTiles}, {"subm.f32_mfma", kOptSubmF32Mfma},
+#if GF_DEV
+    {"dev.splat_pair", kOptSplatPair}, {"dev.splat_solo", kOptSplatSolo}, {"dev.splat_solo_waves", kOptSplatSoloWaves},
+    {"dev.splat_fused", kOptSplatFused}, {"dev.splat_fused_why", kOptSplatFusedWhy}, {"dev.units_bands", kOptUnitsBands},
+    {"dev.prep_waves", kOptPrepWaves}, {"dev.bwd_no_lists", kOptBwdNoLists}, {"dev.bwd_no_big", kOptBwdNoBig},
+    {"dev.daf_vec4", kOptDafVec4}, {"dev.daf_plain", kOptDafPlain},
+#endif
+};
+static int option_index(const char *name)
+{
+    if (name)
+        for (const auto &o : kOptionNames)
+            if (strcmp(o.name, name) == 0) return o.which;
+    return -1;
+}
+}  // namespace gf
+
+extern "C" int gf_set_option(const char *name, int value)
+{
+    const int i = gf::option_index(name);
+    if (i < 0) {
+        gf::set_error("gf_set_option: unknown option '%s'", name ? name : "(null)");
+        return GF_EINVAL;
+    }
+    gf::g_options[i].store(value, std::memory_order_relaxed);
+    return GF_OK;
+}
+
+extern "C" int gf_get_option(const char *name, int *value)
+{
+    const int i = gf::option_index(name);
+    if (i < 0 || !value) {
+        gf::set_error("gf_get_option: unknown option '%s'", name ? name : "(null)");
+        return GF_EINVAL;
+    }
+    *value = gf::option(i);
+    return GF_OK;
+}
+
+extern "C" int gf_is_development_build(void) { return GF_DEV ? 1 : 0; }
 
 extern "C" int gf_abi_version(void) { return GF_ABI_VERSION; }
 extern "C" const char *gf_last_error(void) { return gf::g_err; }

@@ -6,7 +6,30 @@
 
 #include "../../include/gf_hip.h"
 
+#ifndef GF_DEV
+#define GF_DEV 0   // -DGF_DEV=1: the development build tools/ use (libgf_hip_dev.so): measured-and-not-kept kernels (pair, solo, fused
+                   // forward), comparison mappings and the development options of gf_set_option.  The product build holds none of them.
+#endif
+
 namespace gf {
+
+// ---- library options (gf_set_option, include/gf_hip.h): explicit calls, never the environment -- the library does not call getenv
+enum Option {
+    kOptSplatTileKernel = 0,   // "splat.mfma_tile_kernel": matrix-core forward on the tile kernel where the wave kernel would apply
+    kOptDafBackwardTiles,      // "daf.backward_tiles": gf_daf_backward_sorted by pixel tiles (round 1) instead of by image regions
+    kOptSubmF32Mfma,           // "subm.f32_mfma": gf_subm_conv_apply on the exact-f32 MFMA kernel instead of the 3 x bf16 split
+    kOptProductCount,
+    // development build only (GF_DEV)
+    kOptSplatPair = kOptProductCount, kOptSplatSolo, kOptSplatSoloWaves, kOptSplatFused, kOptSplatFusedWhy, kOptUnitsBands, kOptPrepWaves,
+    kOptBwdNoLists, kOptBwdNoBig, kOptDafVec4, kOptDafPlain,
+    kOptCount
+};
+int option(int which);           // gf_api.hip; 0 unless set
+#if GF_DEV
+inline int dev_option(int which) { return option(which); }
+#else
+constexpr int dev_option(int) { return 0; }   // (constant: the code behind a development option is not even compiled in)
+#endif
 
 // ---- geometry constants -------------------------------------------------------------
 constexpr int kC = GF_NUM_CHANNELS;  // 18 semantic channels
@@ -114,7 +137,9 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.bwd_list_len = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? ws.nsuper : 0) * 4);
     ws.bwd_rows = (float *)(p + off); off += align256((size_t)ws.bwd_cap * kBwdRowDwords * 4);
     {
-        const bool fused_ok = P > 0 && P < 65536 && ws.nrow <= kFusedRowMax;
+        // (the fused single-launch forward -- measured, not kept: DESIGN.md section 3.2c -- exists in the development build only;
+        // the product's workspace carries none of its per-XCD copies)
+        const bool fused_ok = GF_DEV && P > 0 && P < 65536 && ws.nrow <= kFusedRowMax;
         ws.x_records = fused_ok ? (float *)(p + off) : nullptr; off += align256(fused_ok ? (size_t)8 * P * kRecDwords * 4 : 0);
         ws.x_boxes = fused_ok ? (uint2 *)(p + off) : nullptr; off += align256(fused_ok ? (size_t)8 * P * 8 : 0);
         ws.x_bitmask = fused_ok ? (unsigned long long *)(p + off) : nullptr; off += align256(fused_ok ? (size_t)8 * ws.nsuper * ws.nrow * 8 : 0);

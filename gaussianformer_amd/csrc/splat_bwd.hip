@@ -20,7 +20,6 @@
 //                        waves -- e.g. the whole-grid Gaussian -- are order-dependent).
 //
 // Launches: [voxel->point map (arbitrary pts only)] -> volumes -> gradient kernel.
-#include <stdlib.h>
 
 #include "gf_common.hpp"
 
@@ -730,7 +729,7 @@ extern "C" int gf_splat_backward(int variant, int radii_per_axis, int flags, int
     // every other case).  GF_MFMA_SPLAT: the caller has seen the state block (e.g. an asynchronous copy of it) and asserts the
     // matrix-core path; a state block that says otherwise yields NaN gradients, not wrong ones.
     const bool mfma_eligible = variant == GF_SPLAT_BASE && !a.force_general && state != nullptr && ws.bwd_cap > 0 &&
-                               !(flags & GF_EXACT_FP32) && getenv("GF_BWD_EXACT") == nullptr;
+                               !(flags & GF_EXACT_FP32);
     if (mfma_eligible) {
         const int gate = (flags & GF_MFMA_SPLAT) ? 2 : 1;
         // GF_RECORDS_VALID: the caller vouches that `workspace` has not been used since the forward that wrote `state` -- its

@@ -40,7 +40,6 @@
 // forward's state block says a matrix-core body rendered the call) and to rows of <= kWRow bitmask words (P <= 39 552).
 #include <algorithm>
 
-#include <stdlib.h>
 
 #include "gf_common.hpp"
 
@@ -1278,16 +1277,19 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
     a.means_grad = means_grad; a.opa_grad = opa_grad; a.sem_grad = sem_grad; a.cov_grad = cov_grad; a.state = state;
     a.tile_counters = ws.flags + kBwdCounters; a.gen_word = gen_word; a.row_first = ws.bwd_row_first; a.wave_total = ws.bwd_wave_total;
     a.big_table = ws.bwd_wave_total + kBwdBigTableAt;
-    a.lists = getenv("GF_BWD_NO_LISTS") ? nullptr : ws.bwd_lists; a.list_len = ws.bwd_list_len; a.lists_bad = ws.flags + kListsBad;
+    a.lists = dev_option(kOptBwdNoLists) ? nullptr : ws.bwd_lists; a.list_len = ws.bwd_list_len; a.lists_bad = ws.flags + kListsBad;
     a.P = P; a.N = N; a.nwords = ws.nwords; a.nrow = ws.nrow; a.H = H; a.W = W; a.D = D; a.nsx = ws.nsx; a.nsy = ws.nsy;
     a.gate = gate ? 1 : 0; a.records_asserted = records_asserted;
     a.timeline = g_bwd_timeline;
     a.cap = ws.bwd_cap;
-    if (getenv("GF_UNITS_BANDS") != nullptr) hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<false>, dim3(grid), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
+#if GF_DEV
+    if (dev_option(kOptUnitsBands)) hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<false>, dim3(grid), dim3(64), 0, stream, a);   // (comparison: rounds 3, 4)
+    else
+#endif
+    hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
     BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, ws.bwd_row_first, gen_word,
                   ws.bwd_wave_total + kBwdBigTableAt, ws.flags + kBwdCounters, state, (uint32_t)(grid / 8), P, gate, (P + 31) / 32, records_asserted};
-    hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + (getenv("GF_X_NO_BIG") ? 0 : 256)), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + (dev_option(kOptBwdNoBig) ? 0 : 256)), dim3(256), 0, stream, r);
 }
 
 }  // namespace gf

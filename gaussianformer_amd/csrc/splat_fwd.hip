@@ -25,8 +25,6 @@
 //      If the prep kernel found pts is NOT the dense grid, the same launch runs the
 //      arbitrary-points body instead (one lane per point).
 //   3. gf_splat_render_general_kernel   arbitrary query points when N != H*W*D.
-#include <stdlib.h>
-
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -130,12 +128,19 @@ __device__ __forceinline__ uint32_t range_bits_of(const float *c, const float *s
     bool snan = false;
 #pragma unroll
     for (int j = 0; j < kC; ++j) {
-        // (the pair kernel carries the opacity in the exponent and the RAW semantics as S': both magnitudes are bounded)
+#if GF_DEV
+        // (the pair / solo kernels of the development build carry the opacity in the exponent and the RAW semantics as S': both
+        // magnitudes are bounded there)
         const float v = fmaxf(fabsf(opa * sm[j]), fabsf(sm[j]));
+#else
+        const float v = fabsf(opa * sm[j]);
+#endif
         snan |= !(v == v);
         smax = fmaxf(smax, v);
     }
-    snan |= !(opa >= 0.f);   // log2(opacity) in the exponent: a negative (or NaN) opacity takes the fall-back
+#if GF_DEV
+    snan |= !(opa >= 0.f);   // (pair / solo kernels: log2(opacity) in the exponent: a negative (or NaN) opacity takes the fall-back)
+#endif
     return ((!(bound < 3.0e4f) || !(Q < 1331.4f)) ? 4u : 0u) | ((snan || !(smax < kSemRangeMax)) ? 8u : 0u);
 }
 
@@ -2671,8 +2676,12 @@ static int mfma_wave_grid(int nunits)
     return 8 * std::min(per_xcd, std::max(1, 8 * cus / 8));
 }
 
+#if GF_DEV
+// (round 5: the pair, solo and fused kernels -- measured, correct, not faster than the wave kernel: DESIGN.md section 3.2c.  Development
+// build only, selected there with gf_set_option("dev.splat_pair" / "dev.splat_solo" / "dev.splat_fused", 1); the product holds none of them.)
 #include "splat_fwd_pair.inc"
 #include "splat_fwd_solo.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------
 struct BoxVolArgs {
@@ -2719,27 +2728,42 @@ static int mfma_grid(int ntiles_total)
 static int mfma_wave_units(int nsuper, int D) { return nsuper * 4 * ((D + 7) / 8); }
 
 // which of the two matrix-core kernels renders a call: the wave-autonomous one wherever a bitmask row fits its LDS block
-// (GF_MFMA_TILE in the environment keeps the tile kernel, for comparison)
+// (gf_set_option("splat.mfma_tile_kernel", 1) keeps the tile kernel, for comparison: the two are bit-identical, tested)
 static bool mfma_by_wave(int nrow)
 {
-    return nrow <= kWRow && getenv("GF_MFMA_TILE") == nullptr;   // (read per call: a test runs both kernels in one process)
+    return nrow <= kWRow && option(kOptSplatTileKernel) == 0;
 }
 
-// ... and the pair kernel (round 5) wherever it applies: plain forward (no label epilogue, no backward preparation -- those stay
-// with the wave kernel), rows of <= kPRowMax words, depth a multiple of 4 (16-byte output pieces), ids that leave 12 mask bits.
-// GF_MFMA_WAVE / GF_MFMA_TILE in the environment keep the older kernels, for comparison.
-// kind of the forward's matrix-core kernel for a call: 0 tile, 1 wave (round 3), 2 pair, 3 solo (round 5).  The round-5 kernels take
-// plain forwards only (no label epilogue, no backward preparation), rows of <= kPRowMax words, a depth that is a multiple of 4
-// (16-byte output pieces) and ids that leave room for the box mask beside them.  GF_MFMA_SOLO / GF_MFMA_PAIR in the environment
-// select them (read per call: tests run several kernels in one process); GF_MFMA_TILE keeps the tile kernel.
+// kind of the forward's matrix-core kernel for a call: 0 tile, 1 wave (round 3); development build only: 2 pair, 3 solo (round 5).
+// The round-5 kernels take plain forwards only (no label epilogue, no backward preparation), rows of <= kPRowMax words, a depth that
+// is a multiple of 4 (16-byte output pieces) and ids that leave room for the box mask beside them.
 static int mfma_kind(int nrow, int D, int P, bool labels, bool prepare_backward)
 {
-    const bool plain = !labels && !prepare_backward && nrow <= kPRowMax && (D & 3) == 0 && getenv("GF_MFMA_TILE") == nullptr;
-    if (plain && getenv("GF_MFMA_PAIR") != nullptr && P < (1 << 20)) return 2;
-    if (plain && getenv("GF_MFMA_SOLO") != nullptr && P < (1 << 16)) return 3;
+#if GF_DEV
+    const bool plain = !labels && !prepare_backward && nrow <= kPRowMax && (D & 3) == 0 && option(kOptSplatTileKernel) == 0;
+    if (plain && dev_option(kOptSplatPair) && P < (1 << 20)) return 2;
+    if (plain && dev_option(kOptSplatSolo) && P < (1 << 16)) return 3;
+#else
+    (void)D; (void)P; (void)labels; (void)prepare_backward;
+#endif
     return mfma_by_wave(nrow) ? 1 : 0;
 }
-static int solo_waves() { const char *e = getenv("GF_SOLO_WAVES"); return e && e[0] == '3' ? 3 : 2; }
+#if GF_DEV
+static int solo_waves() { return dev_option(kOptSplatSoloWaves) == 3 ? 3 : 2; }
+#endif
+
+// workgroups per XCD of the matrix-core kernel that renders a call (what the per-XCD unit counters start from)
+static uint32_t mfma_counter_init(int kind, int nsuper, int nrow, int D)
+{
+#if GF_DEV
+    if (kind == 3)
+        return (uint32_t)((solo_waves() == 3 ? mfma_solo_grid<3>(mfma_wave_units(nsuper, D), nrow) : mfma_solo_grid<2>(mfma_wave_units(nsuper, D), nrow)) / 8);
+    if (kind == 2) return (uint32_t)(mfma_pair_grid(mfma_wave_units(nsuper, D), nrow) / 8);
+#else
+    (void)nrow;
+#endif
+    return kind == 1 ? (uint32_t)(mfma_wave_grid(mfma_wave_units(nsuper, D)) / 8) : (uint32_t)(mfma_grid(nsuper * kTilesPerSuper) / 8);
+}
 
 static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stream)
 {
@@ -2747,23 +2771,26 @@ static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stre
     const bool prof = profile_slot(&ev0, &ev1);
     if (prof) (void)hipEventRecord(ev0, stream);
     const int kind = mfma_kind(r.nrow, r.D, r.P, r.out_labels != nullptr, r.rows_valid != 0u);
+    const int wave_grid = mfma_wave_grid(mfma_wave_units(nsuper, r.D));
+#if GF_DEV
     if (kind == 3 && solo_waves() == 3)
         hipLaunchKernelGGL((gf_splat_render_mfma_solo_kernel<3, false>), dim3(mfma_solo_grid<3>(mfma_wave_units(nsuper, r.D), r.nrow)), dim3(64), solo_lds_bytes(r.nrow), stream, r, FusedArgs{});
     else if (kind == 3)
         hipLaunchKernelGGL((gf_splat_render_mfma_solo_kernel<2, false>), dim3(mfma_solo_grid<2>(mfma_wave_units(nsuper, r.D), r.nrow)), dim3(64), solo_lds_bytes(r.nrow), stream, r, FusedArgs{});
     else if (kind == 2)
         hipLaunchKernelGGL(gf_splat_render_mfma_pair_kernel, dim3(mfma_pair_grid(mfma_wave_units(nsuper, r.D), r.nrow)), dim3(128), pair_lds_bytes(r.nrow), stream, r);
-    else if (mfma_by_wave(r.nrow) && r.out_labels)
-        hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<true>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
-    else if (mfma_by_wave(r.nrow) && r.rows_valid)
-        hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, true>), dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
-    else if (mfma_by_wave(r.nrow)) {
-        if (getenv("GF_UNITS_BANDS") != nullptr)   // (comparison only: the unit -> XCD mapping of rounds 3 and 4)
-            hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, false, false>), dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
-        else
-            hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<false>, dim3(mfma_wave_grid(mfma_wave_units(nsuper, r.D))), dim3(64), 0, stream, r);
-    } else if (getenv("GF_UNITS_BANDS") != nullptr)
+    else if (kind == 1 && !r.out_labels && !r.rows_valid && dev_option(kOptUnitsBands))   // (comparison only: the unit -> XCD mapping of rounds 3 and 4)
+        hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, false, false>), dim3(wave_grid), dim3(64), 0, stream, r);
+    else if (kind == 0 && dev_option(kOptUnitsBands))
         hipLaunchKernelGGL((gf_splat_render_mfma_kernel<false, false>), dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
+    else
+#endif
+    if (kind == 1 && r.out_labels)
+        hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<true>, dim3(wave_grid), dim3(64), 0, stream, r);
+    else if (kind == 1 && r.rows_valid)
+        hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, true>), dim3(wave_grid), dim3(64), 0, stream, r);
+    else if (kind == 1)
+        hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<false>, dim3(wave_grid), dim3(64), 0, stream, r);
     else
         hipLaunchKernelGGL(gf_splat_render_mfma_kernel<false>, dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
     if (prof) (void)hipEventRecord(ev1, stream);
@@ -2852,6 +2879,7 @@ extern "C" size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D)
 extern "C" size_t gf_splat_state_bytes(void) { return 256; }
 
 namespace gf {
+#if GF_DEV
 __global__ void gf_xcc_census_kernel(uint32_t *out)
 {
     if (threadIdx.x == 0) out[blockIdx.x] = (uint32_t)physical_xcc();
@@ -2888,6 +2916,7 @@ static bool stream_is_capturing(hipStream_t stream)
     if (hipStreamIsCapturing(stream, &st) != hipSuccess) return true;   // (be conservative)
     return st != hipStreamCaptureStatusNone;
 }
+#endif   // GF_DEV
 struct LabelOpts {
     long long *labels;  // null: plain forward
     int mode, empty_label;
@@ -2941,8 +2970,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     // W consecutive words of every row).  Small P: TWO, with the records still loaded and stored per lane (round 5: compiling parts
     // out of the pass showed 2.7 of its 9.5 us in the 625 scattered 8-byte stores of a single-wave workgroup; 16-byte runs:
     // 43.8 -> 41.9 us per step at P = 25 601; runs of 32 bytes 42.9, of 64 bytes 44.8 -- the workgroup barriers take over).
-    // GF_PREP_WAVES=1|2|4|8 overrides it (development).
-    const int env_waves = getenv("GF_PREP_WAVES") ? atoi(getenv("GF_PREP_WAVES")) : 0;
+    const int env_waves = dev_option(kOptPrepWaves);   // (development build: gf_set_option("dev.prep_waves", 1|2|4|8))
     const bool env_ok = env_waves == 1 || env_waves == 2 || env_waves == 4 || env_waves == 8;
     const bool staged = P >= 65536 && !env_ok;   // (large P: the records through an LDS image, four waves per workgroup)
     const int prep_waves = env_ok ? env_waves : P >= 65536 ? 4 : 2;
@@ -2976,28 +3004,25 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
                                      mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr) == 1)
                                         ? ws.flags + kVerdictWords : nullptr;
     pa.verdict_words = verdict_words;
-    pa.tile_counter_init = !mfma ? 0u
-                           : mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr) == 3
-                               ? (uint32_t)((solo_waves() == 3 ? mfma_solo_grid<3>(mfma_wave_units(ws.nsuper, D), ws.nrow)
-                                                               : mfma_solo_grid<2>(mfma_wave_units(ws.nsuper, D), ws.nrow)) / 8)
-                           : mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr) == 2
-                               ? (uint32_t)(mfma_pair_grid(mfma_wave_units(ws.nsuper, D), ws.nrow) / 8)
-                           : mfma_by_wave(ws.nrow) ? (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8)
-                                                   : (uint32_t)(mfma_grid(ws.nsuper * kTilesPerSuper) / 8);
-    // The fused single-launch forward (splat_fwd_solo.inc, FusedArgs): plain base forward on a grid the caller vouches for, a
-    // workspace whose flag section was zeroed once, a shape the solo kernel takes, not under stream capture (a replayed launch would
-    // repeat its launch id), and a device whose workgroup -> XCD placement passed the one-time census.
-    // MEASURED AND NOT THE DEFAULT (GF_FUSED=1 in the environment selects it): correct, bit-identical to the
-    // two-launch solo kernel, but 57 against 43.5 us per step -- eight XCDs each reading and writing the whole record set land their
-    // first inputs at 8 us and hand off at 15 us, later than the separate records pass finishes.
-    const bool fused = mfma && !verify && (flags & GF_WORKSPACE_ZEROED) && ws.x_records != nullptr && getenv("GF_FUSED") != nullptr &&
-                       getenv("GF_MFMA_PAIR") == nullptr && getenv("GF_MFMA_TILE") == nullptr && getenv("GF_MFMA_WAVE") == nullptr &&
+    pa.tile_counter_init = !mfma ? 0u : mfma_counter_init(mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr), ws.nsuper, ws.nrow, D);
+#if GF_DEV
+    // The fused single-launch forward (splat_fwd_solo.inc, FusedArgs; development build only): plain base forward on a grid the caller
+    // vouches for, a workspace whose flag section was zeroed once, a shape the solo kernel takes, not under stream capture (a replayed
+    // launch would repeat its launch id), and a device whose workgroup -> XCD placement passed the one-time census.
+    // MEASURED AND NOT KEPT: correct, bit-identical to the two-launch solo kernel, but 57 against 43.5 us per
+    // step -- eight XCDs each reading and writing the whole record set land their first inputs at 8 us and hand off at 15 us, later
+    // than the separate records pass finishes.
+    const bool fused = mfma && !verify && (flags & GF_WORKSPACE_ZEROED) && ws.x_records != nullptr && dev_option(kOptSplatFused) &&
+                       !dev_option(kOptSplatPair) && option(kOptSplatTileKernel) == 0 &&
                        !lab.labels && pa.unit_totals == nullptr && ws.nrow <= kPRowMax && (D & 3) == 0 && P < (1 << 16) &&
                        !stream_is_capturing(stream) && xcc_census_ok();
-    if (!fused && getenv("GF_FUSED") != nullptr && getenv("GF_FUSED_WHY") != nullptr)   // development: which precondition said no
-        fprintf(stderr, "GF_FUSED not taken: mfma %d verify %d zeroed %d x_records %d labels %d unit_totals %d nrow %d D %d P %d capturing %d census %d\n",
+    if (!fused && dev_option(kOptSplatFused) && dev_option(kOptSplatFusedWhy))   // which precondition said no
+        fprintf(stderr, "dev.splat_fused not taken: mfma %d verify %d zeroed %d x_records %d labels %d unit_totals %d nrow %d D %d P %d capturing %d census %d\n",
                 (int)mfma, (int)verify, (int)((flags & GF_WORKSPACE_ZEROED) != 0), (int)(ws.x_records != nullptr), (int)(lab.labels != nullptr),
                 (int)(pa.unit_totals != nullptr), ws.nrow, D, P, (int)stream_is_capturing(stream), (int)xcc_census_ok());
+#else
+    constexpr bool fused = false;
+#endif
     const int prep_grid = fused ? 0 : pa.nprep_blocks + (verify ? kVerifyBlocks / prep_waves : 0);
     if (prep_grid > 0) {
         const size_t bits_lds = sizeof(unsigned long long) * (size_t)std::min(ws.nsx * ws.nsy * prep_waves, kPrepSuperChunk);
@@ -3017,7 +3042,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.verify_flags = ws.flags + 64; ra.state = (uint32_t *)state; ra.P = P; ra.N = N; ra.nwords = ws.nwords; ra.nrow = ws.nrow;
     ra.H = H; ra.W = W; ra.D = D; ra.nsx = ws.nsx; ra.nsy = ws.nsy; ra.ntiles_total = ws.nsuper * kTilesPerSuper;
     ra.verify_dense = verify ? 1 : 0;
-    ra.bands = getenv("GF_UNITS_BANDS") != nullptr ? 1 : 0;
+    ra.bands = dev_option(kOptUnitsBands) ? 1 : 0;
     ra.timeline = g_timeline;
     ra.tile_perm = g_tile_perm;
     ra.out_labels = lab.labels; ra.label_mode = lab.mode; ra.empty_label = lab.empty_label; ra.threshold = lab.threshold;
@@ -3029,6 +3054,7 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.unit_totals = ws.bwd_wave_total; ra.unit_local = ws.bwd_row_local; ra.unit_first = ws.bwd_row_first; ra.unit_cap = ws.bwd_cap;
     ra.pub_lists = ws.bwd_lists; ra.pub_len = ws.bwd_list_len;
     ra.verdict_words = verdict_words;
+#if GF_DEV
     if (fused) {
         // (unique per launch; the low 32 bits count from 1 -- the unit counters' tags must grow --, the bits above are a per-process
         // salt, so that item flags a previous process left in recycled device memory cannot pass for this launch's)
@@ -3048,7 +3074,9 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
         // (two waves per SIMD: the records pass stages through 20 KB of LDS per wave, eight waves per CU)
         hipLaunchKernelGGL((gf_splat_render_mfma_solo_kernel<2, true>), dim3(mfma_solo_grid<2>(nunits, ws.nrow, true)), dim3(64), solo_lds_bytes(ws.nrow, true), stream, ra, fa);
         if (prof) (void)hipEventRecord(ev1, stream);
-    } else if (mfma)
+    } else
+#endif
+    if (mfma)
         launch_render_mfma(ra, ws.nsuper, stream);
     else if (variant == GF_SPLAT_BASE)
         launch_render_exp<GF_SPLAT_BASE>(flags, dense_candidate, ra, stream);

@@ -780,6 +780,7 @@ static int subm_rulebook_count_impl(int N, int batch, int X, int Y, int Z, int K
         hipLaunchKernelGGL(gf_subm_clear_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<char *>(a.t.head), head16,
                            reinterpret_cast<char *>(a.t.cnt), cnt16, reinterpret_cast<char *>(a.t.total), reinterpret_cast<char *>(a.t.kcount), kc16,
                            (size_t)a.cells * 4, (size_t)N * a.K3 * 2, (size_t)a.K3 * 8);
+        GF_CHECK_LAUNCH();
     }
     if (N > 0) {
         hipLaunchKernelGGL(gf_subm_grid_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
@@ -890,7 +891,7 @@ extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, 
     const size_t lds = (size_t)Cin * SW * sizeof(float);
     const dim3 gemm_grid((unsigned)(total_pairs / kPairTile + K3), Cout / SW);  // x >= the number of tiles, whatever the split over the segments
     const int rows = 256 / (Cout / 4);
-    const bool exact_f32 = getenv("GF_SUBM_F32_MFMA") != nullptr;  // the f32-MFMA kernel, for comparison (read per call: tests flip it)
+    const bool exact_f32 = option(kOptSubmF32Mfma) != 0;  // gf_set_option("subm.f32_mfma", 1): the exact-f32 MFMA kernel
     if (exact_f32) {
 #define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds, stream, a)
         GF_SUBM_DISPATCH(GF_GEMM);

@@ -10,6 +10,7 @@ so ``GaussianHead`` (model/head/gaussian_head.py:30-39) can import these unchang
 The compute goes through the C ABI of ``libgf_hip.so``; there is no CPU path.
 """
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -31,23 +32,28 @@ class _Workspace:
 
     @classmethod
     def get(cls, device, nbytes):
+        """The stream's buffer.  Its first 32 KB -- the library's flag section, the same words whatever the call's shape -- are zeroed
+        when the buffer is allocated and afterwards only written by the library: what ``GF_WORKSPACE_ZEROED`` promises (the
+        matrix-core forward then keeps its fall-back verdict in one word instead of one per wave of the records pass)."""
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = cls._cache.pop(key, None)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            buf[:cls.FLAG_BYTES].zero_()
         cls._cache[key] = buf              # most recently used last
         while len(cls._cache) > cls.MAX_STREAMS:
             cls._cache.pop(next(iter(cls._cache)))
         cls._uses += 1
         return buf
 
+    FLAG_BYTES = 32768
     _zeroed = {}
 
     @classmethod
     def get_zeroed(cls, device, nbytes, shape):
         """A buffer of its own per (stream, problem shape), zeroed when created and never handed to another shape: what
-        ``GF_WORKSPACE_ZEROED`` promises (the development switch GF_FUSED=1 needs it: its flags and counters are tagged per
-        launch instead of being reset, which only holds in memory no other layout has written)."""
+        the development build's fused forward needs (``dev.splat_fused``: its flags and counters are tagged per launch instead of
+        being reset, which only holds in memory no other layout has written)."""
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, nbytes, shape)
         buf = cls._zeroed.get(key)
         if buf is None:
@@ -145,11 +151,11 @@ def splat_forward(variant, pts, points_int, means3D, means3D_int, opacities, sem
         probability = torch.empty(N, dtype=f32, device=dev)
     state = torch.empty(lib.gf_splat_state_bytes(), dtype=torch.uint8, device=dev)
     nbytes = lib.gf_splat_workspace_bytes(P, N, H, W, D)
-    if os.environ.get("GF_FUSED"):   # development switch: see _Workspace.get_zeroed
+    if _lib.is_development_build() and _lib.get_option("dev.splat_fused"):   # (tools/ only: see _Workspace.get_zeroed)
         ws = _Workspace.get_zeroed(dev, nbytes, (P, N, H, W, D))
-        flags |= _lib.GF_WORKSPACE_ZEROED
     else:
         ws = _Workspace.get(dev, nbytes)
+    flags |= _lib.GF_WORKSPACE_ZEROED
     with torch.cuda.device(dev):
         rc = lib.gf_splat_forward(
             variant, per_axis, flags, P, N, C, H, W, D,
@@ -183,6 +189,7 @@ def splat_forward_labels(variant, pts, points_int, means3D, means3D_int, opaciti
     state = torch.empty(lib.gf_splat_state_bytes(), dtype=torch.uint8, device=dev)
     nbytes = lib.gf_splat_workspace_bytes(P, N, H, W, D)
     ws = _Workspace.get(dev, nbytes)
+    flags |= _lib.GF_WORKSPACE_ZEROED
     with torch.cuda.device(dev):
         rc = lib.gf_splat_forward_labels(variant, int(radii.dim() == 2), flags, P, N, C, H, W, D,
                                          _lib.ptr(pts), _lib.ptr(points_int), _lib.ptr(means3D), _lib.ptr(means3D_int),
@@ -334,6 +341,9 @@ def splat_box_volumes(means3D_int, radii, H, W, D):
     return touched.to(torch.int64) & 0xFFFFFFFF, int(total.item())
 
 
+_tls = threading.local()
+
+
 class _LocalAggregate(torch.autograd.Function):
     """model/head/localagg/local_aggregate/__init__.py:18-106."""
 
@@ -358,7 +368,7 @@ class _LocalAggregate(torch.autograd.Function):
             ctx.state_event = torch.cuda.Event()
             ctx.state_event.record(torch.cuda.current_stream(pts.device))
         ctx.save_for_backward(state, means3D, means3D_int, pts, points_int, cov3D, opacities, semantics, radii)
-        _LocalAggregate.last_state = state   # (read back, never waited for, by LocalAggregator._watch_path)
+        _tls.last_state = state   # (this thread's last call: picked up by LocalAggregator._splat right after apply() returns)
         return logits
 
     @staticmethod
@@ -419,13 +429,17 @@ class _AggregatorBase(nn.Module):
         model/head/localagg/local_aggregate/__init__.py:137-141.  The voxel grid of a model does not change between frames: the
         result is kept for the LAST ``pts`` tensor seen (same storage, shape and version counter, same ``pc_min`` / cell; a strong
         reference, so the address cannot be recycled) -- three passes over 640 000 points and their launches per frame otherwise.
-        A caller that builds a new tensor per frame simply recomputes."""
+        A caller that builds a new tensor per frame simply recomputes.  Two caveats: a buffer rewritten behind autograd's back
+        (raw pointer, ``.data``) does not move the version counter -- pass a new tensor then; and while a HIP graph is being
+        captured the cache is neither read nor written (the indices are computed inside the capture, in the graph's own pool, so
+        a replay never reads memory that a later eager call released)."""
+        capturing = pts.is_cuda and torch.cuda.is_current_stream_capturing()
         key = (pts.data_ptr(), pts._version, tuple(pts.shape), pts.device, self.pc_min.data_ptr(), self.pc_min._version, float(self.grid_size))
         hit = getattr(self, "_points_int_cache", None)
-        if hit is not None and hit[0] == key and hit[1]._version == key[1]:
+        if not capturing and hit is not None and hit[0] == key and hit[1]._version == key[1]:
             return hit[2]
         points_int = ((pts - self.pc_min) / self.grid_size).to(torch.int)
-        if pts.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if pts.is_cuda and not capturing:
             self._points_int_cache = (key, pts, points_int)
         return points_int
 
@@ -578,11 +592,13 @@ class LocalAggregator(_AggregatorBase):
         else:
             flags = pts_flag | (_lib.GF_MFMA_SPLAT if self.matrix_cores else _lib.GF_EXACT_FP32)
         out = _LocalAggregate.apply(pts, *args, H, self.W, self.D, flags)
+        state, _tls.last_state = getattr(_tls, "last_state", None), None   # (the state block of THIS call, not of another module's or thread's)
+        self.last_state = state
         if self.matrix_cores is None and self._grid_exact and pts.shape[0] == H * self.W * self.D:
-            self._watch_path(pts.device)
+            self._watch_path(pts.device, state)
         return out
 
-    def _watch_path(self, device):
+    def _watch_path(self, device, state):
         """The module judged its grid an exact lattice from (pc_min, grid_size); the ``pts`` actually passed may be built
         differently (e.g. in fp64 and cast), fail the device's lattice verdict and be rendered by the arbitrary-points body in
         every frame, ~7x slower, with word 1 of the state block as the only sign.  So the word is copied to pinned host memory
@@ -600,7 +616,6 @@ class LocalAggregator(_AggregatorBase):
                 self._grid_exact = False
             w["host"] = w["event"] = None
         w["calls"] += 1
-        state = getattr(_LocalAggregate, "last_state", None)
         if (w["event"] is None and state is not None and state.is_cuda and (w["calls"] <= 3 or w["calls"] % 64 == 0)
                 and not torch.cuda.is_current_stream_capturing()):
             w["host"] = torch.empty(5, dtype=torch.int32, pin_memory=True)

@@ -303,6 +303,15 @@ class SparseConv3D(nn.Module):
         bs, g, _ = instance_feature.shape
         indices = self.voxel_indices(anchor)
         feats = instance_feature.flatten(0, 1)
+        # refusals of earlier calls surface here, without blocking: a refused rulebook already produced NaN features,
+        # this names the cause as soon as its status has reached the host.  (Both paths below: the list keeps at most the
+        # eight youngest rulebooks whose status is still in flight, so a long inference loop holds a bounded set of tables.)
+        if self._unchecked and not torch.cuda.is_current_stream_capturing():
+            still = []
+            for old in self._unchecked:
+                if old.poll() is None:
+                    still.append(old)
+            self._unchecked = still[-8:]
         if out_range is not None:
             if bs != 1 or not isinstance(self.layer, SubMConv3d):
                 raise RuntimeError("out_range needs batch size 1 and a single-layer block")
@@ -314,14 +323,6 @@ class SparseConv3D(nn.Module):
             out = self.layer(feats, indices, bs, self._spatial, rulebook=rb)
             return self.output_proj(out[lo:hi])[None]
         cap = None if self.pairs_per_point is None else int(self.pairs_per_point) * indices.shape[0]
-        # refusals of earlier calls surface here, without blocking: a refused rulebook already produced NaN features,
-        # this names the cause as soon as its status has reached the host
-        if self._unchecked and not torch.cuda.is_current_stream_capturing():
-            still = []
-            for old in self._unchecked:
-                if old.poll() is None:
-                    still.append(old)
-            self._unchecked = still[-8:]
         rb = self.last_rulebook = Rulebook(indices, bs, self._spatial, self.kernel_size, pair_capacity=cap)
         if cap is not None and not rb.checked and rb._status_event is not None:
             self._unchecked.append(rb)

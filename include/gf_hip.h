@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 2
+#define GF_ABI_VERSION 3   /* 3 (round 6): gf_set_option / gf_get_option / gf_is_development_build, gf_daf_fused_forward; GF_WORKSPACE_ZEROED = one verdict word; workspace without the fused forward's per-XCD copies */
 
 /* error codes */
 #define GF_OK 0
@@ -90,21 +90,35 @@ extern "C" {
  * buffer.  Ignored where the matrix-core backward does not apply. */
 #define GF_PREPARE_BACKWARD 1024
 /* The caller promises that the workspace's first 32 KB (its flag section) were zero when the workspace was first handed to the
- * library (e.g. allocated with hipMemset / torch.zeros) and have since only been written by the library.  With this flag and
- * GF_PTS_ASSUME_DENSE a plain base forward on the matrix cores runs as ONE launch (records pass and render fused, round 5): its
- * device-side counters are tagged by launch and need that one-time zero.  Without the flag nothing changes. */
+ * library (e.g. allocated with hipMemset / torch.zeros) and have since only been written by the library.  The matrix-core forward
+ * on the wave kernel then keeps its fall-back verdict in ONE word of that section (a double-buffered block maintained on the
+ * device, so a replayed HIP graph behaves like an eager call) instead of one word per wave of the records pass that every render
+ * wave has to read (19 KB per wave).  Same results; without the flag nothing changes. */
 #define GF_WORKSPACE_ZEROED 2048
 
 /* values of word 1 of the state block after gf_splat_forward: which body rendered the call */
 #define GF_PATH_EXACT_TILE 0     /* exact-fp32 tile kernel (dense grid) */
 #define GF_PATH_MATRIX_CORE 1    /* split-f16 MFMA kernel (dense exact lattice), one workgroup per tile: P > 39 552 */
 #define GF_PATH_MATRIX_CORE_WAVE 3 /* the same arithmetic (equal bits), one wave per double brick: P <= 39 552 */
-#define GF_PATH_MATRIX_CORE_PAIR 4 /* round 5: two waves per double brick, one brick each (opacity in the exponent); the default for rows of <= 1024 words */
-#define GF_PATH_MATRIX_CORE_SOLO 5 /* round 5: one wave per double brick again, with the instruction diet (mask table, transposed semantics gather, opacity in the exponent): the default */
+#define GF_PATH_MATRIX_CORE_PAIR 4 /* development build only (gf_is_development_build): round 5's two-waves-per-double-brick kernel -- measured, NOT the default, not in the product library */
+#define GF_PATH_MATRIX_CORE_SOLO 5 /* development build only: round 5's single-wave kernel with the opacity in the exponent -- measured, NOT the default, not in the product library */
 #define GF_PATH_ARBITRARY 2      /* arbitrary-points body (pts not the dense grid, or a failed lattice / range verdict) */
 
 int gf_abi_version(void);
 const char *gf_last_error(void);
+
+/* Library options: process-wide integers set by explicit calls -- the library never reads the environment.  Unknown names
+ * return GF_EINVAL.  The product library knows three, all 0 by default, each selecting an alternative kernel kept for comparison
+ * (same results within the documented bounds):
+ *   "splat.mfma_tile_kernel"  1: the matrix-core forward runs on the tile kernel (one workgroup per tile) even where the wave
+ *                                kernel applies (P <= 39 552); the two are bit-identical
+ *   "daf.backward_tiles"      1: gf_daf_backward_sorted accumulates by pixel tiles instead of by image regions
+ *   "subm.f32_mfma"           1: gf_subm_conv_apply on the exact-f32 MFMA kernel instead of the 3 x bf16 split
+ * A development build (gf_is_development_build() == 1; built by tools/ with -DGF_DEV=1, never shipped as libgf_hip.so) also accepts
+ * "dev.*" names for the measured-and-not-kept kernels of earlier rounds. */
+int gf_set_option(const char *name, int value);
+int gf_get_option(const char *name, int *value);
+int gf_is_development_build(void);
 
 /* Bytes of device scratch gf_splat_forward / gf_splat_backward need for these sizes. */
 size_t gf_splat_workspace_bytes(int P, int N, int H, int W, int D);

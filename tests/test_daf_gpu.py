@@ -182,7 +182,7 @@ def test_daf_random_shapes_sweep(gpu):
 
 
 # ---- round 5: the accumulation of grad_mc_ms_feat by image regions (gf_daf_raccumulate_kernel) against the tile formulation
-# (GF_DAF_TILES=1) and the oracle, on the shapes its geometry has to get right
+# (library option "daf.backward_tiles") and the oracle, on the shapes its geometry has to get right
 
 _REGION_CASES = [
     # the nuScenes layout: dyadic pyramid, 10 x 10 + 7 x 7 + 5 x 5 + 4 x 4 rows per region
@@ -201,7 +201,7 @@ _REGION_CASES = [
 
 
 @pytest.mark.parametrize("name,case,special", _REGION_CASES, ids=[c[0] for c in _REGION_CASES])
-def test_daf_backward_by_regions(gpu, name, case, special, monkeypatch):
+def test_daf_backward_by_regions(gpu, name, case, special):
     import torch
     from gaussianformer_amd.deformable_aggregation import deformable_aggregation_backward as bwd
     d = make_daf_inputs(seed=31, **case)
@@ -220,14 +220,12 @@ def test_daf_backward_by_regions(gpu, name, case, special, monkeypatch):
     g = rng.standard_normal((B, pts, C)).astype(np.float32)
     go = torch.from_numpy(g).to(gpu)
     res = {}
+    from gaussianformer_amd import _lib
     for mode in ("regions", "tiles"):
-        monkeypatch.delenv("GF_DAF_TILES", raising=False)
-        if mode == "tiles":
-            monkeypatch.setenv("GF_DAF_TILES", "1")
-        gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(loc_t), torch.zeros_like(w)
-        bwd(feat, ss, st, loc_t, w, go, gf, gl, gw)
+        with _lib.option("daf.backward_tiles", 1 if mode == "tiles" else 0):
+            gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(loc_t), torch.zeros_like(w)
+            bwd(feat, ss, st, loc_t, w, go, gf, gl, gw)
         res[mode] = (gf, gl, gw)
-    monkeypatch.delenv("GF_DAF_TILES", raising=False)
     (gf1, gl1, gw1), (gf0, gl0, gw0) = res["regions"], res["tiles"]
     assert torch.equal(gl1, gl0) and torch.equal(gw1, gw0)            # the gather side is the same kernel
     scale = max(gf0.abs().max().item(), 1e-30)

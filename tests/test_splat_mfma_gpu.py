@@ -69,18 +69,18 @@ def test_mfma_crowded_tile(gpu):
     ("nuscenes_gs25600_solid", dict(P=39000, H=44, W=36, D=24)),     # 610 words (nearly the longest row it takes), three z bricks
     ("nuscenes_gs25600_solid", dict(P=700, H=9, W=7, D=4)),          # one supertile column, one partial brick
 ])
-def test_mfma_wave_and_tile_kernels_agree_bit_for_bit(gpu, config, kw, monkeypatch):
+def test_mfma_wave_and_tile_kernels_agree_bit_for_bit(gpu, config, kw):
     """The two matrix-core kernels -- one wave per double brick (rows of <= 618 words) and one workgroup per tile
-    (GF_MFMA_TILE=1 forces it) -- take a double brick's hits in the same groups of 32 in ascending index and run the same
+    (the library option "splat.mfma_tile_kernel" forces it) -- take a double brick's hits in the same groups of 32 in ascending index and run the same
     arithmetic on them: equal bits, whatever path (fast fill, chunked refill) built the lists."""
     from gaussianformer_amd import _lib
     si = make_splat_inputs(config, seed=4, **kw)
     pi, mi, radii, cov6 = prep(si)
-    monkeypatch.delenv("GF_MFMA_TILE", raising=False)
-    wave, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
-    monkeypatch.setenv("GF_MFMA_TILE", "1")
-    tile, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
-    monkeypatch.delenv("GF_MFMA_TILE", raising=False)
+    wave, _, wstate, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    with _lib.option("splat.mfma_tile_kernel", 1):
+        tile, _, tstate, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_MFMA_SPLAT)
+    assert wstate[:12].view(torch.int32).cpu().tolist()[1] == _lib.GF_PATH_MATRIX_CORE_WAVE
+    assert tstate[:12].view(torch.int32).cpu().tolist()[1] == _lib.GF_PATH_MATRIX_CORE
     assert np.isfinite(wave["logits"]).all()
     assert np.array_equal(wave["logits"], tile["logits"])
     ref = _oracle_logits(si, pi, mi, radii, cov6)
@@ -570,46 +570,39 @@ def test_forward_and_backward_are_reproducible_bit_for_bit_at_the_full_shape(gpu
             assert all(torch.equal(a, b) for a, b in zip(cur, ref))
 
 
-# Round 5: three more organisations of the matrix-core forward, kept behind development switches (the wave kernel stayed the
-# fastest: DESIGN round 5).  They take a double brick's hits in blocks of 32 like the wave kernel but fold the opacity into the
-# exponent, so they agree with it to rounding, not bit for bit.
-_EXPERIMENTAL = [
-    ("pair", {"GF_MFMA_PAIR": "1"}, 0, "GF_PATH_MATRIX_CORE_PAIR"),
-    ("solo", {"GF_MFMA_SOLO": "1"}, 0, "GF_PATH_MATRIX_CORE_SOLO"),
-    ("solo, three waves per SIMD", {"GF_MFMA_SOLO": "1", "GF_SOLO_WAVES": "3"}, 0, "GF_PATH_MATRIX_CORE_SOLO"),
-    ("fused records pass", {"GF_FUSED": "1"}, 1, "GF_PATH_MATRIX_CORE_SOLO"),
-]
-
-
-@pytest.mark.parametrize("name,env,assume_dense,path", _EXPERIMENTAL)
-def test_mfma_development_kernels_match_the_oracle_and_repeat_themselves(gpu, name, env, assume_dense, path, monkeypatch):
+def test_product_library_is_not_a_development_build_and_reads_no_environment(gpu, monkeypatch):
+    """Round 6: the pair / solo / fused kernels and every environment switch live in the development build only
+    (-DGF_DEV=1, tools/); the product library selects its kernels by arguments, flags and gf_set_option -- an environment variable
+    of an earlier round changes nothing, a development option is refused."""
     from gaussianformer_amd import _lib
-    for k in ("GF_MFMA_PAIR", "GF_MFMA_SOLO", "GF_SOLO_WAVES", "GF_FUSED", "GF_MFMA_TILE"):
-        monkeypatch.delenv(k, raising=False)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    flags = _lib.GF_MFMA_SPLAT | (_lib.GF_PTS_ASSUME_DENSE if assume_dense else 0)
-    shapes = [dict(), dict(P=300, H=16, W=16, D=8), dict(P=2000, H=40, W=40, D=16), dict(P=777, H=20, W=36, D=12),
-              dict(P=64, H=8, W=8, D=4), dict(P=1, H=8, W=8, D=8), dict(P=3000, H=30, W=50, D=16)]
-    for seed, kw in enumerate(shapes):
-        si = make_splat_inputs("nuscenes_gs25600_solid", seed=seed + 1, **kw)
-        pi, mi, radii, cov6 = prep(si)
-        got, _, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
-        words = state[:12].view(torch.int32).cpu().tolist()
-        assert words[1] == getattr(_lib, path), (name, kw, words[:3])
-        assert np.isfinite(got["logits"]).all()
-        ref = _oracle_logits(si, pi, mi, radii, cov6) if kw else None
-        if ref is None:   # the full shape: the wave kernel (itself held to the oracle above) stands in for the CPU oracle
-            for k in env:
-                monkeypatch.delenv(k, raising=False)
-            ref = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)[0]["logits"]
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            assert_logits_close(got["logits"], ref, tol=5e-5)
-        else:
-            assert_logits_close(got["logits"], ref, tol=1e-4)
-        again, *_ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=flags)
-        assert np.array_equal(got["logits"], again["logits"]), (name, kw)
+    if _lib.is_development_build():
+        pytest.skip("GF_LIB points at a development build")
+    si = make_splat_inputs("nuscenes_gs25600_solid", seed=3, P=800, H=24, W=24, D=16)
+    pi, mi, radii, cov6 = prep(si)
+    want, _, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    for k in ("GF_MFMA_TILE", "GF_MFMA_PAIR", "GF_MFMA_SOLO", "GF_FUSED", "GF_UNITS_BANDS", "GF_PREP_WAVES"):
+        monkeypatch.setenv(k, "1")
+    got, _, state2, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    assert state2[:12].view(torch.int32).cpu().tolist()[1] == _lib.GF_PATH_MATRIX_CORE_WAVE
+    assert np.array_equal(got["logits"], want["logits"])
+    with pytest.raises(RuntimeError):
+        _lib.set_option("dev.splat_solo", 1)
+    with pytest.raises(RuntimeError):
+        _lib.set_option("no.such.option", 1)
+
+
+def test_development_kernels_in_the_development_build(gpu):
+    """The round-5 kernels stay honest in the development build, when one has been built (python -m gaussianformer_amd.build --dev):
+    tools/dev_kernels_check.py runs in a process of its own with GF_LIB pointing at it."""
+    import os, subprocess, sys
+    from gaussianformer_amd import build
+    dev = os.path.join(build.CSRC, build.DEV_LIB_NAME)
+    if not os.path.exists(dev):
+        pytest.skip("no development build (python -m gaussianformer_amd.build --dev)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dev_kernels_check.py")], env={**os.environ, "GF_LIB": dev},
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
 
 
 def test_module_notices_a_dense_grid_that_is_not_its_lattice(gpu):
@@ -619,7 +612,7 @@ def test_module_notices_a_dense_grid_that_is_not_its_lattice(gpu):
     import time
     import warnings
     from gaussianformer_amd import _lib
-    from gaussianformer_amd.local_aggregate import LocalAggregator, _LocalAggregate
+    from gaussianformer_amd.local_aggregate import LocalAggregator
     si = make_splat_inputs("nuscenes_gs25600_solid", seed=13, P=300, H=24, W=24, D=16)
     m = LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)[None]
@@ -629,14 +622,14 @@ def test_module_notices_a_dense_grid_that_is_not_its_lattice(gpu):
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         first = m(*args)
-        assert _LocalAggregate.last_state.view(torch.int32)[1].item() == _lib.GF_PATH_ARBITRARY
+        assert m.last_state.view(torch.int32)[1].item() == _lib.GF_PATH_ARBITRARY
         torch.cuda.synchronize()
         time.sleep(0.05)
         for _ in range(3):
             out = m(*args)
         torch.cuda.synchronize()
     assert m._grid_exact is False and any("exact-fp32" in str(w.message) for w in caught)
-    assert _LocalAggregate.last_state.view(torch.int32)[1].item() == _lib.GF_PATH_EXACT_TILE
+    assert m.last_state.view(torch.int32)[1].item() == _lib.GF_PATH_EXACT_TILE
     assert float(((out - first).abs() / first.abs().clamp(min=1.0)).max()) <= 1e-4
     # the module's own lattice is left alone
     m2 = LocalAggregator(si.scale_multiplier, si.H, si.W, si.D, list(si.pc_min), si.grid_size).to(gpu)

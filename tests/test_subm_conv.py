@@ -299,9 +299,9 @@ def test_subm_conv_without_host_read():
 
 
 @pytest.mark.parametrize("cin,cout", [(128, 128), (32, 64)])
-def test_subm_conv_bf16_split_against_f32_mfma(cin, cout, monkeypatch):
+def test_subm_conv_bf16_split_against_f32_mfma(cin, cout):
     """The default gather-GEMM (fp32 operands split into three bf16 terms, six bf16 MFMAs per product) against the
-    f32-MFMA kernel (GF_SUBM_F32_MFMA=1: bitwise an fmaf chain) on the same rulebook, and both against the fp64
+    f32-MFMA kernel (library option "subm.f32_mfma": bitwise an fmaf chain) on the same rulebook, and both against the fp64
     definition: the split must stay in fp32's error class, also for operands spanning many binades (a plain bf16 GEMM
     would be at 4e-3)."""
     from gaussianformer_amd.sparse_conv import Rulebook
@@ -316,11 +316,10 @@ def test_subm_conv_bf16_split_against_f32_mfma(cin, cout, monkeypatch):
     # the error scale of an fp32 dot product: eps * sum |a||b|, per output element
     mag = _dense_reference(feat.double().abs(), idx.long(), weight.double().abs(), batch, shape, K)
     rb = Rulebook(idx.to(dev), batch, shape, K)
-    monkeypatch.delenv("GF_SUBM_F32_MFMA", raising=False)
+    from gaussianformer_amd import _lib
     split = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()
-    monkeypatch.setenv("GF_SUBM_F32_MFMA", "1")
-    exact = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()
-    monkeypatch.delenv("GF_SUBM_F32_MFMA", raising=False)
+    with _lib.option("subm.f32_mfma", 1):
+        exact = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()
     assert not torch.equal(split, exact)                          # two different kernels did run
     bound = 2.0 ** -20 * mag + 1e-30        # 16 units of fp32 roundoff of sum |a||b| (a plain bf16 product: 2^-8)
     assert bool(((exact - ref).abs() <= bound).all())

@@ -1,9 +1,10 @@
-"""Development probe (GPU box): deformable aggregation forward, eight channels per lane (default) against four (GF_DAF_VEC4=1) -- equal bits? times?"""
+"""Development probe (GPU box): deformable aggregation forward, eight channels per lane (default) against four (dev.daf_vec4) -- equal bits? times?"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
+from gaussianformer_amd import _lib
 from gaussianformer_amd.deformable_aggregation import deformable_aggregation_forward
 from gaussianformer_amd.synthetic import make_daf_inputs
 
@@ -27,9 +28,7 @@ for dist in (sys.argv[1:] or ["projected", "uniform"]):
         loc, w = loc.contiguous(), w.contiguous()
     out = {}
     for mode in ("vec4", "vec8"):
-        os.environ.pop("GF_DAF_VEC4", None)
-        if mode == "vec4":
-            os.environ["GF_DAF_VEC4"] = "1"
+        _lib.set_option("dev.daf_vec4", 1 if mode == "vec4" else 0)   # (development build: GF_LIB=.../libgf_hip_dev.so)
         y = deformable_aggregation_forward(feat, ss, st, loc, w)
         torch.cuda.synchronize()
         for _ in range(5):
@@ -41,5 +40,5 @@ for dist in (sys.argv[1:] or ["projected", "uniform"]):
         e1.record()
         torch.cuda.synchronize()
         out[mode] = (y, e0.elapsed_time(e1) / 20 * 1e3)
-    os.environ.pop("GF_DAF_VEC4", None)
-    print(f"{dist}: four channels per lane (GF_DAF_VEC4=1) {out['vec4'][1]:.1f} us, eight (default) {out['vec8'][1]:.1f} us; equal bits {bool(torch.equal(out['vec4'][0], out['vec8'][0]))}", flush=True)
+    _lib.set_option("dev.daf_vec4", 0)
+    print(f"{dist}: four channels per lane (dev.daf_vec4) {out['vec4'][1]:.1f} us, eight (default) {out['vec8'][1]:.1f} us; equal bits {bool(torch.equal(out['vec4'][0], out['vec8'][0]))}", flush=True)

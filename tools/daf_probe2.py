@@ -1,8 +1,9 @@
-"""Development probe (GPU box): DAF forward, plain walk (GF_DAF_PLAIN=1) against the batched-loads kernel, both location distributions."""
+"""Development probe (GPU box): DAF forward, plain walk (development build, option "dev.daf_plain") against the batched-loads kernel, both location distributions."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
+from gaussianformer_amd import _lib
 from gaussianformer_amd.deformable_aggregation import deformable_aggregation_forward
 from gaussianformer_amd.synthetic import make_daf_inputs
 dev = torch.device("cuda:0")
@@ -32,8 +33,7 @@ ploc, pw = ploc.contiguous(), pw.contiguous()
 for name, (l_, w_) in (("uniform", (loc, w)), ("projected", (ploc, pw))):
     outs = {}
     for mode in ("plain", "batched"):
-        if mode == "plain": os.environ["GF_DAF_PLAIN"] = "1"
-        else: os.environ.pop("GF_DAF_PLAIN", None)
+        _lib.set_option("dev.daf_plain", 1 if mode == "plain" else 0)   # (development build: GF_LIB=.../libgf_hip_dev.so)
         outs[mode] = deformable_aggregation_forward(feat, ss, st, l_, w_).clone()
         print(f"{name:10s} {mode:8s}: {timed(lambda: deformable_aggregation_forward(feat, ss, st, l_, w_)):7.1f} us", flush=True)
     print(f"{name:10s} bit-identical: {bool(torch.equal(outs['plain'], outs['batched']))}")

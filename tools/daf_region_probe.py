@@ -1,10 +1,11 @@
 """Development probe (GPU box): the region-major accumulation of the deformable aggregation backward (default) against the tile
-formulation (GF_DAF_TILES=1) -- gradients equal? times?   python tools/daf_region_probe.py [uniform|projected ...]"""
+formulation (library option "daf.backward_tiles") -- gradients equal? times?   python tools/daf_region_probe.py [uniform|projected ...]"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
+from gaussianformer_amd import _lib
 from gaussianformer_amd.deformable_aggregation import deformable_aggregation_backward
 from gaussianformer_amd.synthetic import make_daf_inputs
 
@@ -29,9 +30,7 @@ for dist in (sys.argv[1:] or ["projected", "uniform"]):
     go = torch.randn(1, loc.shape[1], 128, device=dev)
     out = {}
     for mode in ("regions", "tiles"):
-        os.environ.pop("GF_DAF_TILES", None)
-        if mode == "tiles":
-            os.environ["GF_DAF_TILES"] = "1"
+        _lib.set_option("daf.backward_tiles", 1 if mode == "tiles" else 0)
         def run():
             gf, gl, gw = torch.zeros_like(feat), torch.zeros_like(loc), torch.zeros_like(w)
             deformable_aggregation_backward(feat, ss, st, loc, w, go, gf, gl, gw)

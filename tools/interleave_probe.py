@@ -1,5 +1,5 @@
 """Development probe (GPU box): the matrix-core forward and backward with supertiles dealt round-robin to the XCDs (default since
-round 5) against contiguous bands of units (GF_UNITS_BANDS=1), uniform and clustered Gaussian centres -- equal bits?  times?"""
+round 5) against contiguous bands of units (development build, option "dev.units_bands"), uniform and clustered Gaussian centres -- equal bits?  times?"""
 import os
 import sys
 import time
@@ -19,9 +19,7 @@ for config in (sys.argv[1:] or ["nuscenes_gs25600_solid"]):
         t = to_dev(dev, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
         res = {}
         for mode in ("bands", "interleaved"):
-            os.environ.pop("GF_UNITS_BANDS", None)
-            if mode == "bands":
-                os.environ["GF_UNITS_BANDS"] = "1"
+            _lib.set_option("dev.units_bands", 1 if mode == "bands" else 0)   # (development build: GF_LIB=.../libgf_hip_dev.so)
             plan = SplatForwardPlan(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=0)
             out = plan.run().clone()
             torch.cuda.synchronize()
@@ -52,7 +50,7 @@ for config in (sys.argv[1:] or ["nuscenes_gs25600_solid"]):
             torch.cuda.synchronize()
             fb_us = (time.perf_counter() - t0) / 100 * 1e6
             res[mode] = (out, sorted(ts)[2], plan.state_words()[:3], fb_us, [x.clone() for x in grads])
-        os.environ.pop("GF_UNITS_BANDS", None)
+        _lib.set_option("dev.units_bands", 0)
         print(f"{config} clustered={clustered}: bands {res['bands'][1]:.2f} us {res['bands'][2]}, interleaved {res['interleaved'][1]:.2f} us {res['interleaved'][2]}; "
               f"equal bits {bool(torch.equal(res['bands'][0], res['interleaved'][0]))}; forward + backward (module calls) bands {res['bands'][3]:.1f} us, "
               f"interleaved {res['interleaved'][3]:.1f} us; gradients of all but the whole-grid Gaussian equal "

@@ -14,13 +14,12 @@ for config, variant, flags in (("prob_gs6400", _lib.GF_SPLAT_PROB, 0), ("nuscene
         t = to_dev(dev, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
         r = {}
         for mode in ("bands", "interleaved"):
-            os.environ.pop("GF_UNITS_BANDS", None)
-            if mode == "bands": os.environ["GF_UNITS_BANDS"] = "1"
+            _lib.set_option("dev.units_bands", 1 if mode == "bands" else 0)   # (development build: GF_LIB=.../libgf_hip_dev.so)
             plan = SplatForwardPlan(variant, *t, si.H, si.W, si.D, flags=flags)
             out = plan.run().clone(); torch.cuda.synchronize()
             for _ in range(10): plan.run()
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(100): plan.run()
             torch.cuda.synchronize(); r[mode] = (out, (time.perf_counter() - t0) / 100 * 1e6)
-        os.environ.pop("GF_UNITS_BANDS", None)
+        _lib.set_option("dev.units_bands", 0)
         print(f"{config} exact/prob tile kernel clustered={clustered}: bands {r['bands'][1]:.1f} us, interleaved {r['interleaved'][1]:.1f} us, equal bits {bool(torch.equal(r['bands'][0], r['interleaved'][0]))}", flush=True)

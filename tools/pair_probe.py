@@ -21,13 +21,17 @@ small = "--small" in sys.argv
 configs = args or ["nuscenes_gs25600_solid"]
 
 
+_OPTS = {"GF_MFMA_SOLO": "dev.splat_solo", "GF_MFMA_TILE": "splat.mfma_tile_kernel", "GF_MFMA_PAIR": "dev.splat_pair",
+         "GF_SOLO_WAVES": "dev.splat_solo_waves", "GF_FUSED": "dev.splat_fused"}
+
+
 def run(si, flags, env=None, steps=0):
-    for k in ("GF_MFMA_SOLO", "GF_MFMA_TILE", "GF_MFMA_PAIR", "GF_SOLO_WAVES", "GF_FUSED"):
-        os.environ.pop(k, None)
+    for k in _OPTS.values():   # (development build: GF_LIB=.../libgf_hip_dev.so)
+        _lib.set_option(k, 0)
     if env:
         for e in env.split(","):
             k, _, v = e.partition("=")
-            os.environ[k] = v or "1"
+            _lib.set_option(_OPTS[k], int(v or "1"))
     pi, mi, radii, cov6 = prep(si)
     t = to_dev(dev, si.pts, pi, si.means3D, mi, si.opacities, si.semantics, radii, cov6)
     plan = SplatForwardPlan(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=flags)

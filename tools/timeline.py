@@ -1,5 +1,5 @@
 """Debug: per-workgroup timeline of the TILE render kernels (start / list built / consumed / stored).
-python tools/timeline.py [config] [exact]   -- default: the matrix-core tile kernel (forced with GF_MFMA_TILE=1: rows of <= 618
+python tools/timeline.py [config] [exact]   -- default: the matrix-core tile kernel (forced with library option "splat.mfma_tile_kernel": rows of <= 618
 bitmask words otherwise go to the wave-autonomous kernel, whose timeline is tools/timeline_wave.py); "exact": the exact-fp32 tile kernel"""
 import ctypes, sys
 import numpy as np, torch
@@ -11,8 +11,8 @@ _deps = [os.path.join(_b.CSRC, f) for f in _b.SOURCES + _b.HEADERS]
 if not os.path.exists(_tl) or any(os.path.getmtime(d) > os.path.getmtime(_tl) for d in _deps if os.path.exists(d)):
     _b.build(extra_flags=("-DGF_TIMELINE=1",), lib_name="libgf_hip_timeline.so")   # prebuilt in-tree copies travel with gpurun
 os.environ["GF_LIB"] = _tl
-os.environ["GF_MFMA_TILE"] = "1"
 from gaussianformer_amd import _lib
+_lib.set_option("splat.mfma_tile_kernel", 1)
 from gaussianformer_amd.local_aggregate import SplatForwardPlan
 from gaussianformer_amd.synthetic import make_splat_inputs
 import oracle

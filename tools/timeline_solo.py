@@ -1,13 +1,13 @@
 """Debug: per-unit timeline of the solo / fused render kernel (-DGF_TIMELINE=1 build).  python tools/timeline_solo.py [config] [flags]
-flags 1 (GF_PTS_ASSUME_DENSE) = the fused single-launch forward; 0 with GF_MFMA_SOLO=1 = the two-launch solo kernel."""
+flags 1 (GF_PTS_ASSUME_DENSE) = the fused single-launch forward; 0 = option "dev.splat_solo" = the two-launch solo kernel."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 from gaussianformer_amd import build as _b
-_tl = os.path.join(_b.CSRC, "libgf_hip_timeline.so")
+_tl = os.path.join(_b.CSRC, "libgf_hip_timeline_dev.so")
 _deps = [os.path.join(_b.CSRC, f) for f in _b.SOURCES + _b.HEADERS]
 if not os.path.exists(_tl) or any(os.path.getmtime(d) > os.path.getmtime(_tl) for d in _deps if os.path.exists(d)):
-    _b.build(extra_flags=("-DGF_TIMELINE=1",), lib_name="libgf_hip_timeline.so")
+    _b.build(extra_flags=("-DGF_TIMELINE=1", "-DGF_DEV=1"), lib_name="libgf_hip_timeline_dev.so")
 os.environ["GF_LIB"] = _tl
 from gaussianformer_amd import _lib
 from gaussianformer_amd.local_aggregate import SplatForwardPlan
@@ -15,8 +15,7 @@ from gaussianformer_amd.synthetic import make_splat_inputs
 import oracle
 config = sys.argv[1] if len(sys.argv) > 1 else "nuscenes_gs25600_solid"
 flags = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-if not flags:
-    os.environ["GF_MFMA_SOLO"] = "1"
+_lib.set_option("dev.splat_solo" if not flags else "dev.splat_fused", 1)
 dev = torch.device("cuda:0")
 si = make_splat_inputs(config, seed=0)
 pi, mi, radii, cov6 = oracle.prepare_splat_inputs(si.pts, si.means3D, si.scales, si.cov3D, si.pc_min, si.grid_size, si.scale_multiplier)
