@@ -38,6 +38,9 @@ constexpr int kTileX = 8, kTileY = 4;  // a tile (one workgroup) is 8x4 voxel co
 constexpr int kTilesPerSuper = (kSuper / kTileX) * (kSuper / kTileY);
 constexpr int kRecDwords = 32;       // packed per-Gaussian record, 128 B
 constexpr int kWRow = 618;           // bitmask row words (P <= 39 552) the wave-autonomous matrix-core kernels (forward and backward) hold in LDS
+constexpr int kLongWords = 4096;     // ... and the longest rows (P <= 262 144) their long-row instantiations take: the records pass then leaves, per
+                                     // supertile, a SUMMARY of its bitmask row -- one byte per four words, bit k = "word 4 i + k is not zero" -- and
+                                     // a unit fetches the non-zero words only (round 6; splat_fwd.hip, "long rows")
 constexpr int kBwdRowDwords = 32;    // matrix-core backward: one 128-B row of partial gradients per (Gaussian, double brick)
 constexpr int kBwdBigRows = 512;     // ... a Gaussian with more rows than this is summed by whole workgroups (big list)
 constexpr int kBwdBigCap = 1024;     // ... waves of 64 Gaussians the layout words provide for (>= kWRow)
@@ -73,6 +76,9 @@ struct SplatWorkspace {
     float *records;         // [P][32]
     uint2 *boxes;           // [P]  (lo, hi) packed
     unsigned long long *bitmask;  // [nsuper][nrow]: rows of nwords words, padded to an even count (16-byte aligned rows)
+    unsigned char *summary;       // [nsuper][sum_pitch] long rows (kWRow < nrow, nwords <= kLongWords): byte i of a row = which of its words
+                                  // 4 i .. 4 i + 3 are not zero (low four bits); null otherwise
+    int sum_pitch;                // bytes per summary row (a multiple of 16)
     int *voxel2pts;         // [V]   (backward, general pts only)
     uint32_t *vols;         // [P]  backward: box volumes
     uint32_t *bsum;         // [ceil(P/256)] backward: volume sums per 256 Gaussians (sorted order)
@@ -113,6 +119,11 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     ws.records = (float *)(p + off); off += align256((size_t)P * kRecDwords * 4);
     ws.boxes = (uint2 *)(p + off); off += align256((size_t)P * 8);
     ws.bitmask = (unsigned long long *)(p + off); off += align256((size_t)ws.nsuper * ws.nrow * 8);
+    {
+        const bool long_rows = ws.nrow > kWRow && ws.nwords <= kLongWords;
+        ws.sum_pitch = long_rows ? (((ws.nwords + 3) / 4 + 15) & ~15) : 0;
+        ws.summary = long_rows ? (unsigned char *)(p + off) : nullptr; off += align256((size_t)ws.nsuper * ws.sum_pitch);
+    }
     ws.voxel2pts = (int *)(p + off); off += align256((size_t)H * W * D * 4);
     ws.vols = (uint32_t *)(p + off); off += align256((size_t)P * 4);
     ws.bsum = (uint32_t *)(p + off); off += align256((size_t)((P + 255) / 256) * 4);

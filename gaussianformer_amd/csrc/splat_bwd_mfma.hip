@@ -89,6 +89,7 @@ struct BwdMArgs {
     int records_asserted;        // 1: no records pass ran -- stand down unless the workspace still holds the forward's (generation)
     unsigned long long *timeline;  // debug (GF_TIMELINE builds): 8 stamps per unit
     uint32_t *big_table;         // (zero_big_gaussians -> gf_splat_bwd_rows_kernel: see kBwdBigTableAt)
+    uint32_t m_ps, m_nsy;        // ceil(2^32 / units per supertile), ceil(2^32 / nsy): launch constants from the host (as in the forward)
     uint32_t cap;                // rows in `rows`: a row index beyond it is never written (defence in depth: a first row read from a layout
                                  // that was not completed would otherwise be an out-of-bounds store)
 };
@@ -300,8 +301,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     const int per_super = 4 * ((a.D + 7) >> 3);
     const int nunits = a.nsx * a.nsy * per_super;
     const int per_xcd = INTER ? ((a.nsx * a.nsy + 7) >> 3) * per_super : (nunits + 7) >> 3;
-    const uint32_t m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / (unsigned)per_super);
-    const uint32_t m_nsy = (uint32_t)(((1ull << 32) + a.nsy - 1) / (unsigned)a.nsy);
+    const uint32_t m_ps = a.m_ps, m_nsy = a.m_nsy;
     using gptr = const __attribute__((address_space(1))) void *;
     using lptr = __attribute__((address_space(3))) void *;
 
@@ -1282,6 +1282,11 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
     a.gate = gate ? 1 : 0; a.records_asserted = records_asserted;
     a.timeline = g_bwd_timeline;
     a.cap = ws.bwd_cap;
+    {
+        const unsigned per_super = 4u * (unsigned)((D + 7) >> 3);
+        a.m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / per_super);
+        a.m_nsy = (uint32_t)(((1ull << 32) + (unsigned)ws.nsy - 1) / (unsigned)ws.nsy);
+    }
 #if GF_DEV
     if (dev_option(kOptUnitsBands)) hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<false>, dim3(grid), dim3(64), 0, stream, a);   // (comparison: rounds 3, 4)
     else

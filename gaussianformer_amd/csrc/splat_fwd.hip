@@ -43,6 +43,10 @@
 #ifndef GF_PHITAB
 #define GF_PHITAB 1   // wave kernel: the exponent MFMAs' B operands from a compile-time table (kPhiHot) instead of 235 VALU per wave
 #endif
+#ifndef GF_STATIC2
+#define GF_STATIC2 0   // experiment (VERDICT r5 #3b): every wave of the wave kernel takes its SECOND unit statically too (unit local + waves per
+                       // XCD) and only claims from the third on; measured in round 6, see DESIGN.md section 3.2d
+#endif
 #ifndef GF_XP
 #define GF_XP 0   // development: parts of the records pass compiled out (timing experiments only: 1 bitmask stores, 2 record
                   // stores, 4 LDS atomics, 8 verification waves, 16 records waves)
@@ -76,6 +80,8 @@ struct PrepArgs {
     int range_theta_here;    // 1: the records pass checks theta as well as opacity * semantics (no verification waves: GF_PTS_ASSUME_DENSE)
     uint32_t *verdict_words; // null, or the workspace's verdict block [A, B, V0, V1] (kVerdictWords; GF_WORKSPACE_ZEROED callers):
                              // a wave that finds a violation ORs its bits into V[(A + 1) & 1] -- see "one verdict word" below
+    unsigned char *summary;  // null, or [nsuper][sum_pitch] (long rows, WAVES == 4): byte w of row s = which of the four bitmask words this
+    int sum_pitch;           // workgroup w wrote to row s are not zero -- the wave kernel's long-row instantiation fetches only those
     uint32_t *range_flags;   // null, or [nwords + 4]: per wave of 64 Gaussians, bit 2 = a Gaussian's theta may leave the f16
                              // range, bit 3 = |opacity * semantics| may (matrix-core render kernel: both change per frame, so
                              // they are checked in the records pass on EVERY call, GF_PTS_ASSUME_DENSE included)
@@ -577,9 +583,16 @@ __global__ __launch_bounds__(64 * WAVES) void gf_splat_prep_kernel(PrepArgs a)
         wg_sync();
         for (int i = threadIdx.x; i < ns * WAVES; i += 64 * WAVES) {
             const int si = i / WAVES, w = i - si * WAVES;
+            unsigned long long bits = 0ull;
             if ((int)blockIdx.x * WAVES + w < a.nwords && !(GF_XP & 1)) {
-                const unsigned long long bits = s_bits[i];
+                bits = s_bits[i];
                 a.bitmask[(size_t)(s0 + si) * a.nrow + blockIdx.x * WAVES + w] = bits;
+            }
+            if (WAVES == 4 && a.summary) {
+                // long rows: which of this workgroup's four words of row s0 + si are not zero -- one byte per (row, workgroup); four
+                // neighbouring lanes hold the four words (64 WAVES is a multiple of 4, so w == lane & 3)
+                const unsigned long long nzb = __builtin_amdgcn_ballot_w64(bits != 0ull);
+                if (w == 0) a.summary[(size_t)(s0 + si) * a.sum_pitch + blockIdx.x] = (unsigned char)((nzb >> (lane & 60)) & 15ull);
             }
         }
     }
@@ -617,6 +630,11 @@ struct RenderArgs {
     uint32_t *pub_lists, *pub_len;              // ... [nsuper][3][kBwdList] / [nsuper]: the candidate lists, published for the backward
     uint32_t *verdict_words;   // null, or the workspace's verdict block [A, B, V0, V1] (gf_splat_prep_kernel, "one verdict word"): the wave
                                // kernel reads it with ONE load instead of every prep wave's verdict word
+    const unsigned char *summary;   // long rows (gf_splat_render_mfma_wave_kernel<..., LONG = true>): the records pass's row summaries
+    int sum_pitch;
+    uint32_t m_ps, m_nsy;      // wave kernel: ceil(2^32 / units per supertile), ceil(2^32 / nsy) -- launch constants, computed on the host
+                               // (on the device the two 64-bit divisions were 220 scalar instructions at the start of every wave:
+                               // round-6 census, profiles/census_wave_r06.txt)
 };
 
 // Words 3 and 4 of the state block: the workspace's generation (gf_splat_prep_kernel bumped it) and whether the records carry
@@ -1959,14 +1977,34 @@ static_assert(2 * 64 * kC <= 1536 + 3 * kWList, "output staging fits over the sl
 // work between XCDs: 61.1 us per step at gs25600 with sigmoid(N(0,1)) centres; dealt round-robin every XCD sees the same density:
 // 48.1 us.  The locality given up (a Gaussian's record is fetched by as many XCDs as it has neighbouring supertiles) does not
 // show: 43.6 us either way with uniform centres.  Same arithmetic per unit: bit-identical results.
-template <bool LABELS, bool PREP = false, bool INTER = true>
+// LONG (round 6): bitmask rows of kWRow < nrow words, nwords <= kLongWords (39 552 < P <= 262 144: BASELINE config [3], P = 144 000).
+// A row no longer fits the wave's LDS block and four in five of its words are zero, so the unit does not read it: the records pass
+// leaves a SUMMARY of every row (one byte per four words: which of them are not zero; 576 bytes per row at P = 144 000), the unit
+// brings that in (one 16-byte piece per lane, prefetched by the previous unit like the row above), expands it to one bit per word,
+// ranks the non-zero words with one wave scan, and fetches exactly those (~450 of 2 250) from the row by LDS-DMA, already in
+// ascending order -- the dense array the fast path above builds by scanning.  The candidate ids come out of that as before; the
+// list holds kLIds entries (no id copy of the row any more: 896 against 512), so a supertile of the nuScenes shapes (<= 580
+// candidates) is still ONE pass.  A crowded supertile (more non-zero words than the dense array, or more candidates than the list)
+// goes in several passes, each re-ranking from the summary (a pass ends with the pending group flushed -- same groups, same
+// order: bit-identical to the tile kernel, tests/test_splat_mfma_gpu.py).  LDS map of the long-row instantiation:
+//   [    0,  6144)  record slot ... and, while the list is built: non-zero words' low halves [kLDense], high halves, word indices (u16)
+//   [ 6144,  9728)  candidate ids [kLIds]   [ 9728, 13312) packed box lo   [13312, 16896) packed box hi
+//   [15872, 16896)  ... the summary row, prefetched (box hi's tail: read before the boxes are fetched)
+//   [17232, 20480)  hit queue, opacity * semantics: as above
+constexpr int kLDense = 576, kLIds = 896;   // (both multiples of 64: the gathers write whole rounds of 64 entries)
+static_assert(2 * kLDense + kLDense / 2 <= 1536 && 1536 + 3 * kLIds <= 3072 + 2 * kWRow && kLDense % 64 == 0 && kLIds % 64 == 0, "LDS map of the long-row instantiation");
+static_assert(kLongWords <= 64 * 64, "one summary bit per word, 64 per lane");
+template <bool LABELS, bool PREP = false, bool INTER = true, bool LONG = false>
 __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(RenderArgs a)
 {
+    static_assert(!(LONG && PREP), "the matrix-core backward takes rows of <= kWRow words");
     __shared__ __attribute__((aligned(16))) uint32_t s_u[kWLdsDwords];
     float4 *slot = reinterpret_cast<float4 *>(s_u);
-    uint32_t *s_lg = s_u + 1536, *s_blo = s_u + 1536 + kWList, *s_bhi = s_u + 1536 + 2 * kWList;
+    constexpr int kListN = LONG ? kLIds : kWList;   // candidate-list entries
+    uint32_t *s_lg = s_u + 1536, *s_blo = s_u + 1536 + kListN, *s_bhi = s_u + 1536 + 2 * kListN;
     float *stage = reinterpret_cast<float *>(s_u);
     unsigned long long *s_row = reinterpret_cast<unsigned long long *>(s_u + 3072);
+    uint32_t *s_sum = s_u + 3968;   // LONG: the summary row (64 lanes x 16 bytes)
     uint32_t *q_id = s_u + 3072 + 2 * kWRow;
     float *S = reinterpret_cast<float *>(s_u + 3072 + 2 * kWRow + kQCap);
 
@@ -1978,8 +2016,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
 
     // unit index -> (supertile, quarter, z brick) -> supertile row and column: divisions by launch constants, as multiplications
     // by rounded-up reciprocals (exact for the < 2^20 indices of a grid)
-    const uint32_t m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / (unsigned)per_super);
-    const uint32_t m_nsy = (uint32_t)(((1ull << 32) + a.nsy - 1) / (unsigned)a.nsy);
+    const uint32_t m_ps = a.m_ps, m_nsy = a.m_nsy;
     using gptr = const __attribute__((address_space(1))) void *;
     using lptr = __attribute__((address_space(3))) void *;
     int local = (int)(blockIdx.x >> 3);
@@ -1993,10 +2030,14 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             const int s0 = INTER ? 8 * q0 + xcd : q0, r0 = logical - q0 * per_super;
             const int srow0 = a.nsy == 1 ? s0 : (int)__umulhi((uint32_t)s0, m_nsy), scol0 = s0 - srow0 * a.nsy;
             if (srow0 * kSuper + 4 * (r0 & 1) < a.H && scol0 * kSuper + 4 * ((r0 >> 1) & 1) < a.W) {
-                const unsigned long long *bm0 = a.bitmask + (size_t)s0 * a.nrow;
-                for (int i = 0; 128 * i < a.nrow; ++i)
-                    if (128 * i + 2 * lane < a.nrow)
-                        lds_dma16((gptr)(bm0 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
+                if (LONG) {
+                    lds_dma16((gptr)(a.summary + (size_t)s0 * a.sum_pitch + 16 * min(lane, (a.sum_pitch >> 4) - 1)), (lptr)s_sum);
+                } else {
+                    const unsigned long long *bm0 = a.bitmask + (size_t)s0 * a.nrow;
+                    for (int i = 0; 128 * i < a.nrow; ++i)
+                        if (128 * i + 2 * lane < a.nrow)
+                            lds_dma16((gptr)(bm0 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
+                }
                 row_there = true;
             }
         }
@@ -2133,6 +2174,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     // by itself -- so rows that do not fit s_row stay with the tile kernel.)
     const int nchunk = (a.nwords + 63) >> 6;
     int nst_prev = 0;        // ... and this many store instructions were issued after that request
+    bool first_unit = true;
     while (true) {  // units of this wave
         const int logical = INTER ? local : xcd * per_xcd + local;
         const int qs = (int)__umulhi((uint32_t)logical, m_ps);
@@ -2153,10 +2195,15 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             unsigned long long tl[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
 #endif
             // a piece of the bitmask row by LDS-DMA: 128 words per instruction, all of them in flight at once
-            if (!row_there)
-                for (int i = 0; 128 * i < a.nrow; ++i)   // (rows are padded to an even word count)
-                    if (128 * i + 2 * lane < a.nrow)
-                        lds_dma16((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
+            if (!row_there) {
+                if (LONG) {
+                    lds_dma16((gptr)(a.summary + (size_t)s * a.sum_pitch + 16 * min(lane, (a.sum_pitch >> 4) - 1)), (lptr)s_sum);
+                } else {
+                    for (int i = 0; 128 * i < a.nrow; ++i)   // (rows are padded to an even word count)
+                        if (128 * i + 2 * lane < a.nrow)
+                            lds_dma16((gptr)(bm + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
+                }
+            }
             f32x16 acc[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
@@ -2173,12 +2220,14 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             tl[1] = wall_clock64();
 #endif
             int c = 0, sg = 0;
+            int long_lo = 0;       // LONG: rank (among the row's non-zero words) of the first word not yet listed
+            bool long_first = true;  // LONG: the summary in s_sum is the prefetched one
             // ---- fill, fast path (the whole row at once).  Extracting ids bit by bit costs one loop iteration per set bit of the
             // busiest LANE, and with a word per lane a chunk of 64 words has a lane with four or five candidates while most
             // have none (0.6 % of the bits are set): 35 iterations of a dependent 64-bit chain per row, 2.3 us.  So the NONZERO
             // words are first compacted (one scan of per-lane counts, no loop) into a dense array -- it borrows the record slot, idle
             // until the first group -- and the bits are extracted from that: three rounds of two or three iterations.
-            {
+            if (!LONG) {
                 constexpr int kWDense = kWList;
                 uint32_t *s_dw = s_u;                                                               // [kWDense] word index
                 unsigned long long *s_db = reinterpret_cast<unsigned long long *>(s_u + kWDense);  // [kWDense] its bits
@@ -2285,7 +2334,99 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 // earlier lanes first).  A chunk that does not fit any more waits for the next round; one with more candidates
                 // than the whole list holds goes in by eight lane groups of eight words (<= 512 candidates each).
                 bool last = false;
-                while (true) {
+                if (LONG) {
+                    // ---- long rows: summary -> ranks of the non-zero words -> those words, by LDS-DMA, in ascending order -> ids
+                    uint32_t *d_lo = s_u, *d_hi = s_u + kLDense;
+                    unsigned short *d_w = reinterpret_cast<unsigned short *>(s_u + 2 * kLDense);
+                    if (!long_first) {   // (a later pass of a crowded supertile: nothing is in flight here -- the pending group was flushed)
+                        lds_dma16((gptr)(a.summary + (size_t)s * a.sum_pitch + 16 * min(lane, (a.sum_pitch >> 4) - 1)), (lptr)s_sum);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    long_first = false;
+                    const uint4 sv = reinterpret_cast<const uint4 *>(s_sum)[lane];
+                    // sixteen bytes, four bits each -> 64 bits: bit k of lane L = "word 64 L + k of the row is not zero"
+                    auto nib16 = [](uint32_t d) -> uint32_t {
+                        uint32_t x = d & 0x0F0F0F0Fu;
+                        x = (x | (x >> 4)) & 0x00FF00FFu;
+                        return (x | (x >> 8)) & 0x0000FFFFu;
+                    };
+                    unsigned long long sm = (unsigned long long)(nib16(sv.x) | (nib16(sv.y) << 16)) |
+                                            ((unsigned long long)(nib16(sv.z) | (nib16(sv.w) << 16)) << 32);
+                    {   // (the summary's padding bytes and the lanes past the row are not written by anyone)
+                        const int left = a.nwords - 64 * lane;
+                        sm = left >= 64 ? sm : (left > 0 ? sm & bits_below(left) : 0ull);
+                    }
+                    const int cw = __builtin_popcountll(sm);
+                    const int incl_w = wave_inclusive_scan(cw);
+                    const int nd = __builtin_amdgcn_readlane(incl_w, 63);
+                    const int cnt = min(nd - long_lo, kLDense);
+                    {   // word index of every rank in [long_lo, long_lo + cnt): each lane walks its own bits
+                        unsigned long long m = sm;
+                        int t = incl_w - cw - long_lo;
+                        while (m) {
+                            const int b = __builtin_ctzll(m);
+                            m &= m - 1;
+                            if ((unsigned)t < (unsigned)cnt) d_w[t] = (unsigned short)(64 * lane + b);
+                            ++t;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(bm);
+                    for (int k0 = 0; k0 < cnt; k0 += 64) {
+                        const uint32_t w = d_w[min(k0 + lane, cnt - 1)];
+                        lds_dma4((gptr)(bm32 + 2 * w), (lptr)(d_lo + k0));
+                        lds_dma4((gptr)(bm32 + 2 * w + 1), (lptr)(d_hi + k0));
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    int tot = 0, used = 0;
+                    for (int k0 = 0; k0 < cnt; k0 += 64) {
+                        const int j = k0 + lane;
+                        const bool in = j < cnt;
+                        const int jc = min(j, cnt - 1);
+                        unsigned long long bits = (unsigned long long)d_lo[jc] | ((unsigned long long)d_hi[jc] << 32);
+                        bits = in ? bits : 0ull;
+                        const uint32_t id0 = (uint32_t)d_w[jc] * 64u;
+                        const int cb = __builtin_popcountll(bits);
+                        const int incl = wave_inclusive_scan(cb);
+                        const int total = __builtin_amdgcn_readlane(incl, 63);
+                        int pos = -1, adm = 64;
+                        if (tot + total <= kLIds) {
+                            pos = tot + incl - cb;
+                        } else {
+                            // the list is full inside this round: whole groups of eight words (<= 512 ids: the first one always fits an empty list)
+                            adm = 0;
+                            int e_adm = 0;
+                            for (int g8 = 0; g8 < 8; ++g8) {
+                                const int e1 = __builtin_amdgcn_readlane(incl, 8 * g8 + 7);
+                                if (tot + e1 > kLIds) break;
+                                adm = 8 * (g8 + 1);
+                                e_adm = e1;
+                            }
+                            if (lane < adm) pos = tot + incl - cb;
+                            (void)e_adm;
+                        }
+                        if (pos >= 0) {
+                            while (bits) {
+                                const int b = __builtin_ctzll(bits);
+                                bits &= bits - 1;
+                                s_lg[pos++] = id0 + (uint32_t)b;
+                            }
+                        }
+                        if (adm == 64) {
+                            tot += total;
+                            used += min(64, cnt - k0);
+                        } else {
+                            tot += adm ? __builtin_amdgcn_readlane(incl, max(adm - 1, 0)) : 0;
+                            used += min(adm, cnt - k0);
+                            break;
+                        }
+                    }
+                    list_len = tot;
+                    last = long_lo + used >= nd;
+                    long_lo += used;
+                }
+                while (!LONG) {
                     if (c >= nchunk) {
                         last = true;
                         break;
@@ -2369,7 +2510,11 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 if (!tl[3]) tl[3] = wall_clock64();
 #endif
                 // ---- consume: hits of the double brick -> queue -> groups of 32 (one-deep record pipeline, as in the tile kernel)
-                for (int base = 0; base < list_len || (last && base == 0); base += 64) {
+                // (LONG, not the last pass of a crowded supertile: one more, empty batch FLUSHES the pending group -- the next pass builds
+                // its dense array in the record slot, so nothing may be in flight to it; the group is the one that would have been
+                // taken anyway, only its successor is requested later: same groups, same order)
+                const int nbase = list_len + ((LONG && !last) ? 64 : 0);
+                for (int base = 0; base < nbase || (last && base == 0); base += 64) {
                     const int i = base + lane;
                     const int ic = min(i, max(list_len - 1, 0));
                     const uint32_t eg = s_lg[ic];
@@ -2380,6 +2525,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                     if (hit) q_id[(qhead + qlen + (int)mbcnt(todo)) & (kQCap - 1)] = eg;
                     qlen += __builtin_popcountll(todo);
                     const bool final_batch = last && base + 64 >= list_len;
+                    const bool flush = LONG && !last && base >= list_len;
                     while (true) {
                         if (npend == 0) {
                             if (!(qlen >= 32 || (final_batch && qlen > 0))) break;
@@ -2389,7 +2535,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                             request_records_at(qhead, 0, npend);
                         }
                         const int avail = qlen - npend;
-                        if (!(avail >= 32 || final_batch)) break;   // the successor is requested before this group is worked on
+                        if (!(avail >= 32 || final_batch || flush)) break;   // the successor is requested before this group is worked on
                         const int qn = npend;
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pending group's pieces have landed in the slot
 #if GF_TIMELINE
@@ -2402,12 +2548,12 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                         const float4 e0 = slot[192 + lane], e1 = slot[256 + lane], e2 = slot[320 + lane];
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // every lane has its pieces: the slot is free again
                         __builtin_amdgcn_wave_barrier();
-                        const int nnext = min(avail, 32);
+                        const int nnext = (flush && avail < 32) ? 0 : min(avail, 32);   // (a flush forms no partial group)
                         if (nnext > 0) request_records_at(qhead, qn, nnext);
                         // the unit's last group: NOW the next unit is claimed -- as late as its round trip can still hide (under
                         // this group's blocks): a unit claimed early is a unit no idle wave can take at the end of the launch
                         const bool last_group = final_batch && nnext == 0;
-                        if (last_group && lane == 0)
+                        if (last_group && lane == 0 && !(GF_STATIC2 && first_unit))
                             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
                             {
                             const float opa = live ? r0.w : 0.f;
@@ -2516,9 +2662,10 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
             tl[5] = wall_clock64();
 #endif
             // ---- the next unit (claimed during the last group) and its bitmask row: requested now, it travels under the epilogue
-            if (!have_next && lane == 0)   // a unit without a single hit
+            if (!have_next && lane == 0 && !(GF_STATIC2 && first_unit))   // a unit without a single hit
                 asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed)::"memory");
+            if (GF_STATIC2 && first_unit) claimed = (uint32_t)local + (gridDim.x >> 3);
             have_next = true;
             {
                 const int nl = __builtin_amdgcn_readfirstlane((int)claimed), nlog = INTER ? nl : xcd * per_xcd + nl;
@@ -2527,10 +2674,14 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                     const int s2 = INTER ? 8 * q2 + xcd : q2, r2 = nlog - q2 * per_super;
                     const int srow2 = a.nsy == 1 ? s2 : (int)__umulhi((uint32_t)s2, m_nsy), scol2 = s2 - srow2 * a.nsy;
                     if (srow2 * kSuper + 4 * (r2 & 1) < a.H && scol2 * kSuper + 4 * ((r2 >> 1) & 1) < a.W) {
-                        const unsigned long long *bm2 = a.bitmask + (size_t)s2 * a.nrow;
-                        for (int i = 0; 128 * i < a.nrow; ++i)
-                            if (128 * i + 2 * lane < a.nrow)
-                                lds_dma16((gptr)(bm2 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
+                        if (LONG) {
+                            lds_dma16((gptr)(a.summary + (size_t)s2 * a.sum_pitch + 16 * min(lane, (a.sum_pitch >> 4) - 1)), (lptr)s_sum);
+                        } else {
+                            const unsigned long long *bm2 = a.bitmask + (size_t)s2 * a.nrow;
+                            for (int i = 0; 128 * i < a.nrow; ++i)
+                                if (128 * i + 2 * lane < a.nrow)
+                                    lds_dma16((gptr)(bm2 + 128 * i + 2 * lane), (lptr)(s_row + 128 * i));
+                        }
                         next_row = true;
                     }
                 }
@@ -2654,12 +2805,14 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
 #endif
         }
         if (!have_next) {   // a unit outside the grid
-            if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
+            if (lane == 0 && !(GF_STATIC2 && first_unit)) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(ctr), "v"(1u) : "memory");
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed)::"memory");
+            if (GF_STATIC2 && first_unit) claimed = (uint32_t)local + (gridDim.x >> 3);
         }
         local = __builtin_amdgcn_readfirstlane((int)claimed);
         row_there = next_row;
         nst_prev = nst;
+        first_unit = false;
     }
 }
 
@@ -2733,11 +2886,18 @@ static bool mfma_by_wave(int nrow)
 {
     return nrow <= kWRow && option(kOptSplatTileKernel) == 0;
 }
+// ... and its long-row instantiation (round 6) for the rows that do not: kWRow < nrow, nwords <= kLongWords, on a workspace that was
+// handed over zeroed (GF_WORKSPACE_ZEROED: the one-word verdict -- the per-wave verdict words of such a row are more than a render
+// wave can read at its start); anything else stays with the tile kernel
+static bool mfma_by_wave_long(int nrow, int nwords, int flags)
+{
+    return GF_VD1 && nrow > kWRow && nwords <= kLongWords && (flags & GF_WORKSPACE_ZEROED) && option(kOptSplatTileKernel) == 0;
+}
 
 // kind of the forward's matrix-core kernel for a call: 0 tile, 1 wave (round 3); development build only: 2 pair, 3 solo (round 5).
 // The round-5 kernels take plain forwards only (no label epilogue, no backward preparation), rows of <= kPRowMax words, a depth that
 // is a multiple of 4 (16-byte output pieces) and ids that leave room for the box mask beside them.
-static int mfma_kind(int nrow, int D, int P, bool labels, bool prepare_backward)
+static int mfma_kind(int nrow, int D, int P, bool labels, bool prepare_backward, int flags = 0)
 {
 #if GF_DEV
     const bool plain = !labels && !prepare_backward && nrow <= kPRowMax && (D & 3) == 0 && option(kOptSplatTileKernel) == 0;
@@ -2746,7 +2906,7 @@ static int mfma_kind(int nrow, int D, int P, bool labels, bool prepare_backward)
 #else
     (void)D; (void)P; (void)labels; (void)prepare_backward;
 #endif
-    return mfma_by_wave(nrow) ? 1 : 0;
+    return (mfma_by_wave(nrow) || mfma_by_wave_long(nrow, (P + 63) / 64, flags)) ? 1 : 0;
 }
 #if GF_DEV
 static int solo_waves() { return dev_option(kOptSplatSoloWaves) == 3 ? 3 : 2; }
@@ -2762,7 +2922,7 @@ static uint32_t mfma_counter_init(int kind, int nsuper, int nrow, int D)
 #else
     (void)nrow;
 #endif
-    return kind == 1 ? (uint32_t)(mfma_wave_grid(mfma_wave_units(nsuper, D)) / 8) : (uint32_t)(mfma_grid(nsuper * kTilesPerSuper) / 8);
+    return kind == 1 ? (uint32_t)((GF_STATIC2 ? 2 : 1) * (mfma_wave_grid(mfma_wave_units(nsuper, D)) / 8)) : (uint32_t)(mfma_grid(nsuper * kTilesPerSuper) / 8);
 }
 
 static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stream)
@@ -2770,7 +2930,7 @@ static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stre
     hipEvent_t ev0, ev1;
     const bool prof = profile_slot(&ev0, &ev1);
     if (prof) (void)hipEventRecord(ev0, stream);
-    const int kind = mfma_kind(r.nrow, r.D, r.P, r.out_labels != nullptr, r.rows_valid != 0u);
+    const int kind = mfma_kind(r.nrow, r.D, r.P, r.out_labels != nullptr, r.rows_valid != 0u, r.summary ? GF_WORKSPACE_ZEROED : 0);
     const int wave_grid = mfma_wave_grid(mfma_wave_units(nsuper, r.D));
 #if GF_DEV
     if (kind == 3 && solo_waves() == 3)
@@ -2785,7 +2945,11 @@ static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stre
         hipLaunchKernelGGL((gf_splat_render_mfma_kernel<false, false>), dim3(mfma_grid(r.ntiles_total)), dim3(kBlock), 0, stream, r);
     else
 #endif
-    if (kind == 1 && r.out_labels)
+    if (kind == 1 && r.nrow > kWRow && r.out_labels)
+        hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<true, false, true, true>), dim3(wave_grid), dim3(64), 0, stream, r);
+    else if (kind == 1 && r.nrow > kWRow)
+        hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, false, true, true>), dim3(wave_grid), dim3(64), 0, stream, r);
+    else if (kind == 1 && r.out_labels)
         hipLaunchKernelGGL(gf_splat_render_mfma_wave_kernel<true>, dim3(wave_grid), dim3(64), 0, stream, r);
     else if (kind == 1 && r.rows_valid)
         hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, true>), dim3(wave_grid), dim3(64), 0, stream, r);
@@ -2854,6 +3018,7 @@ void launch_prep_for_backward(int radii_per_axis, int P, int N, int H, int W, in
     pa.prescale = 0; pa.exact_det = 0; pa.lattice = 0;
     pa.tile_counters = nullptr; pa.tile_counter_init = 0u;   // (the backward's set-up kernel arms the unit counters)
     pa.range_flags = nullptr; pa.range_theta_here = 0; pa.verdict_words = nullptr;
+    pa.summary = nullptr; pa.sum_pitch = 0;
     pa.unit_totals = ws.bwd_wave_total; pa.unit_local = ws.bwd_row_local; pa.bwd_counters = ws.flags + kBwdCounters;
     pa.bwd_counter_init = (uint32_t)(mfma_wave_grid(mfma_wave_units(ws.nsuper, D)) / 8);
     pa.gen_word = ws.flags + kGenWord; pa.gate_state = state;
@@ -2972,13 +3137,15 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     // 43.8 -> 41.9 us per step at P = 25 601; runs of 32 bytes 42.9, of 64 bytes 44.8 -- the workgroup barriers take over).
     const int env_waves = dev_option(kOptPrepWaves);   // (development build: gf_set_option("dev.prep_waves", 1|2|4|8))
     const bool env_ok = env_waves == 1 || env_waves == 2 || env_waves == 4 || env_waves == 8;
-    const bool staged = P >= 65536 && !env_ok;   // (large P: the records through an LDS image, four waves per workgroup)
-    const int prep_waves = env_ok ? env_waves : P >= 65536 ? 4 : 2;
+    // (long rows, round 6: four waves as well -- the row summaries are one byte per four-wave workgroup)
+    const bool long_rows = ws.summary != nullptr && (flags & GF_WORKSPACE_ZEROED) != 0;
+    const bool staged = (P >= 65536 || long_rows) && !env_ok;   // (large P: the records through an LDS image, four waves per workgroup)
+    const int prep_waves = env_ok ? env_waves : (P >= 65536 || long_rows) ? 4 : 2;
     pa.variant = variant; pa.nprep_blocks = (ws.nwords + prep_waves - 1) / prep_waves; pa.verify = verify ? 1 : 0;
     // matrix-core kernel: the default wherever it applies (include/gf_hip.h, GF_MFMA_SPLAT / GF_EXACT_FP32)
     // (the label epilogue -- argmax mode -- is built into the wave-autonomous kernel only: rows of <= kWRow words)
     const bool mfma_ok = variant == GF_SPLAT_BASE && dense_candidate && P > 0 &&
-                         (!lab.labels || (lab.mode == GF_LABELS_ARGMAX && mfma_by_wave(ws.nrow)));
+                         (!lab.labels || (lab.mode == GF_LABELS_ARGMAX && (mfma_by_wave(ws.nrow) || (mfma_by_wave_long(ws.nrow, ws.nwords, flags) && !env_ok))));
     const bool mfma = mfma_ok && ((flags & GF_MFMA_SPLAT) ||
                                   !(flags & (GF_EXACT_FP32 | GF_FAST_EXP | GF_LIBM_EXP | GF_COMP_EXP)));
     pa.prescale = (!mfma && exp_flavour(variant, flags) == kExpFast) ? 1 : 0;  // the matrix-core kernel scales in fp64 itself
@@ -3000,11 +3167,14 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     pa.range_flags = mfma ? ws.range_flags : nullptr;
     pa.range_theta_here = (mfma && !verify) ? 1 : 0;   // (with the point scans running, their waves take the theta verdict)
     // one verdict word instead of one per prep wave: the wave kernel on a workspace that was handed over zeroed (see gf_splat_prep_kernel)
-    uint32_t *const verdict_words = (GF_VD1 && mfma && (flags & GF_WORKSPACE_ZEROED) &&
-                                     mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr) == 1)
-                                        ? ws.flags + kVerdictWords : nullptr;
+    // (long rows on the wave kernel: with the four-wave records pass that writes the summaries -- not under a development override of it)
+    const int kind_flags = (long_rows && prep_waves == 4) ? GF_WORKSPACE_ZEROED : 0;
+    const int the_kind = mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr, kind_flags);
+    const bool by_wave_long = mfma && the_kind == 1 && ws.nrow > kWRow;
+    uint32_t *const verdict_words = (GF_VD1 && mfma && (flags & GF_WORKSPACE_ZEROED) && the_kind == 1) ? ws.flags + kVerdictWords : nullptr;
     pa.verdict_words = verdict_words;
-    pa.tile_counter_init = !mfma ? 0u : mfma_counter_init(mfma_kind(ws.nrow, D, P, lab.labels != nullptr, pa.unit_totals != nullptr), ws.nsuper, ws.nrow, D);
+    pa.summary = by_wave_long ? ws.summary : nullptr; pa.sum_pitch = ws.sum_pitch;
+    pa.tile_counter_init = !mfma ? 0u : mfma_counter_init(the_kind, ws.nsuper, ws.nrow, D);
 #if GF_DEV
     // The fused single-launch forward (splat_fwd_solo.inc, FusedArgs; development build only): plain base forward on a grid the caller
     // vouches for, a workspace whose flag section was zeroed once, a shape the solo kernel takes, not under stream capture (a replayed
@@ -3054,6 +3224,12 @@ static int splat_forward_impl(const char *fn, int variant, int radii_per_axis, i
     ra.unit_totals = ws.bwd_wave_total; ra.unit_local = ws.bwd_row_local; ra.unit_first = ws.bwd_row_first; ra.unit_cap = ws.bwd_cap;
     ra.pub_lists = ws.bwd_lists; ra.pub_len = ws.bwd_list_len;
     ra.verdict_words = verdict_words;
+    ra.summary = by_wave_long ? ws.summary : nullptr; ra.sum_pitch = ws.sum_pitch;
+    {
+        const unsigned per_super = 4u * (unsigned)((D + 7) >> 3);
+        ra.m_ps = (uint32_t)(((1ull << 32) + per_super - 1) / per_super);
+        ra.m_nsy = (uint32_t)(((1ull << 32) + (unsigned)ws.nsy - 1) / (unsigned)ws.nsy);
+    }
 #if GF_DEV
     if (fused) {
         // (unique per launch; the low 32 bits count from 1 -- the unit counters' tags must grow --, the bits above are a per-process

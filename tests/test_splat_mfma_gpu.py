@@ -68,11 +68,18 @@ def test_mfma_crowded_tile(gpu):
     ("nuscenes_gs144000", dict(P=6000, H=20, W=20, D=16)),            # crowded: lists longer than the wave kernel's, refills
     ("nuscenes_gs25600_solid", dict(P=39000, H=44, W=36, D=24)),     # 610 words (nearly the longest row it takes), three z bricks
     ("nuscenes_gs25600_solid", dict(P=700, H=9, W=7, D=4)),          # one supertile column, one partial brick
+    # round 6, long rows (kWRow < words <= 4096: the wave kernel's long-row instantiation -- summary, ranks, gathered words)
+    ("nuscenes_gs144000", {}),                                        # BASELINE config [3]: 2 250 words, ~450 of them non-zero, one pass
+    ("nuscenes_gs144000", dict(P=50000, H=24, W=24, D=16)),           # crowded: nine supertiles, every word non-zero: several passes
+    ("nuscenes_gs25600_solid", dict(P=45000, H=9, W=7, D=4)),        # every bit set: the list fills inside a round (groups of eight words)
+    ("nuscenes_gs144000", dict(P=40000, H=64, W=40, D=8)),            # just past kWRow (626 words), sparse rows
+    ("nuscenes_gs144000", dict(P=262144, H=48, W=40, D=16)),          # the longest rows it takes (4 096 words)
 ])
 def test_mfma_wave_and_tile_kernels_agree_bit_for_bit(gpu, config, kw):
-    """The two matrix-core kernels -- one wave per double brick (rows of <= 618 words) and one workgroup per tile
-    (the library option "splat.mfma_tile_kernel" forces it) -- take a double brick's hits in the same groups of 32 in ascending index and run the same
-    arithmetic on them: equal bits, whatever path (fast fill, chunked refill) built the lists."""
+    """The two matrix-core kernels -- one wave per double brick (rows of <= 618 words; longer rows, up to 4 096 words, in its
+    long-row instantiation) and one workgroup per tile (the library option "splat.mfma_tile_kernel" forces it) -- take a double
+    brick's hits in the same groups of 32 in ascending index and run the same
+    arithmetic on them: equal bits, whatever path (fast fill, chunked refill, long-row passes) built the lists."""
     from gaussianformer_amd import _lib
     si = make_splat_inputs(config, seed=4, **kw)
     pi, mi, radii, cov6 = prep(si)

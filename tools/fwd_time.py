@@ -22,6 +22,9 @@ def opt(name, default):
         return int(v)
     return default
 reps, steps, flags = opt("--reps", 7), opt("--steps", 200), opt("--flags", 0)
+if "--tile" in args:   # the matrix-core forward on the tile kernel everywhere (library option)
+    args.remove("--tile")
+    _lib.set_option("splat.mfma_tile_kernel", 1)
 dev = torch.device("cuda:0")
 configs = args or ["nuscenes_gs25600_solid", "nuscenes_gs144000"]
 for config in configs:
