@@ -18,6 +18,7 @@ enum Option {
     kOptSplatTileKernel = 0,   // "splat.mfma_tile_kernel": matrix-core forward on the tile kernel where the wave kernel would apply
     kOptDafBackwardTiles,      // "daf.backward_tiles": gf_daf_backward_sorted by pixel tiles (round 1) instead of by image regions
     kOptSubmF32Mfma,           // "subm.f32_mfma": gf_subm_conv_apply on the exact-f32 MFMA kernel instead of the 3 x bf16 split
+    kOptSubmTileGemm,          // "subm.tile_gemm": gf_subm_conv_apply's gather-GEMM with one tile per workgroup also where runs of tiles apply
     kOptProductCount,
     // development build only (GF_DEV)
     kOptSplatPair = kOptProductCount, kOptSplatSolo, kOptSplatSoloWaves, kOptSplatFused, kOptSplatFusedWhy, kOptUnitsBands, kOptPrepWaves,

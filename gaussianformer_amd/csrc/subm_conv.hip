@@ -26,6 +26,7 @@ namespace gf {
 
 constexpr int kPairTile = 128;   // pairs per workgroup tile of the gather-GEMM (32 per wave)
 constexpr int kWgradChunk = 512;  // pairs per workgroup of the weight gradient
+constexpr int kGemmRun = 8;       // consecutive tiles of one offset a workgroup of the run kernel (gf_subm_gemm_bf16_run_kernel) walks
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -42,6 +43,7 @@ struct SubmTables {
     unsigned int *kcursor;  // [K3]
     unsigned char *kmask;   // [K*K][N] bit kz: offset (kxy, kz) of the point has a neighbour cell with points (count pass -> fill pass)
     unsigned int *chunk_start;  // [K3+1] weight-gradient chunks before segment k
+    unsigned int *run_start;    // [K3+1] runs of kGemmRun tiles before segment k (gf_subm_gemm_bf16_run_kernel)
     unsigned long long *total;  // [0] total pairs, [1] non-zero if a cell is too crowded for the 16-bit counts
 };
 
@@ -84,6 +86,7 @@ static SubmTables subm_carve(void *base, int N, long long cells, int K3, size_t 
     t.kcursor = (unsigned int *)(p + off); off += subm_align((size_t)K3 * 4);
     t.kmask = (unsigned char *)(p + off); off += subm_align((size_t)N * 49);  // K <= 7
     t.chunk_start = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
+    t.run_start = (unsigned int *)(p + off); off += subm_align((size_t)(K3 + 1) * 4);
     t.total = (unsigned long long *)(p + off); off += 256;
     *bytes = off;
     return t;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
 {
     // K3 <= 343 entries: one wave, 64 per step, running totals carried in registers
     const int lane = threadIdx.x;
-    unsigned int run = 0, tiles = 0, chunks = 0;
+    unsigned int run = 0, tiles = 0, chunks = 0, runs = 0;
     unsigned long long total64 = 0;
     for (int k0 = 0; k0 < a.K3; k0 += 64) total64 += k0 + lane < a.K3 ? a.t.kcount[k0 + lane] : 0ull;
     for (int d = 32; d >= 1; d >>= 1) total64 += __shfl_xor(total64, d, 64);
@@ -263,21 +266,24 @@ __global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
         const unsigned long long c64 = (k < a.K3 && !over) ? a.t.kcount[k] : 0ull;
         const unsigned int c = (unsigned int)c64;
         const unsigned int tl = (c + kPairTile - 1) / kPairTile, ch = (c + kWgradChunk - 1) / kWgradChunk;
-        unsigned int ic = c, it = tl, ih = ch;
+        const unsigned int rn = (tl + kGemmRun - 1) / kGemmRun;
+        unsigned int ic = c, it = tl, ih = ch, ir = rn;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int uc = __shfl_up(ic, d, 64), ut = __shfl_up(it, d, 64), uh = __shfl_up(ih, d, 64);
-            if (lane >= d) { ic += uc; it += ut; ih += uh; }
+            const unsigned int uc = __shfl_up(ic, d, 64), ut = __shfl_up(it, d, 64), uh = __shfl_up(ih, d, 64), ur = __shfl_up(ir, d, 64);
+            if (lane >= d) { ic += uc; it += ut; ih += uh; ir += ur; }
         }
         if (k < a.K3) {
             a.t.kstart[k] = run + ic - c;
             a.t.tile_start[k] = tiles + it - tl;
             a.t.chunk_start[k] = chunks + ih - ch;
+            a.t.run_start[k] = runs + ir - rn;
             a.t.kcursor[k] = 0;
         }
         run += __shfl(ic, 63, 64);
         tiles += __shfl(it, 63, 64);
         chunks += __shfl(ih, 63, 64);
+        runs += __shfl(ir, 63, 64);
     }
     // pair slots are 32-bit ints: more than 2^31 - 1 pairs is reported like a crowded cell (the prefixes above wrapped)
     if (lane == 0 && total64 >= (1ull << 31)) atomicOr(a.t.total + 1, 2ull);
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(64) void gf_subm_scan_kernel(SubmArgs a)
         a.t.kstart[a.K3] = run;
         a.t.tile_start[a.K3] = tiles;
         a.t.chunk_start[a.K3] = chunks;
+        a.t.run_start[a.K3] = runs;
         a.t.total[0] = total64;
     }
 }
@@ -469,6 +476,118 @@ __global__ __launch_bounds__(256, 3) void gf_subm_gemm_bf16_kernel(SubmArgs a)
 #pragma unroll
             for (int g = 0; g < NG; ++g) a.partial[(size_t)slot * COUT + c_lo + 32 * g + i] = acc[g][r];
         }
+    }
+}
+
+// The same kernel for LONG segments (round 6): a workgroup walks a RUN of kGemmRun consecutive tiles of one offset.
+// Per tile the kernel above pays the whole start-up -- 32 KB of W[k] read, split into three bf16 terms and stored to LDS (a third
+// of its vector-ALU work), a barrier, the gather's two dependent round trips (pair index, then the feature row) -- in front of
+// 1.5 us of MFMAs: at A = 144 000 (5.9 M pairs, 369 tiles per offset) the matrix pipe was busy 29 % of 1.60 ms.  Here the W
+// slice is converted ONCE per run, and the gather is a two-stage pipeline: the pair indices of tile j + 2 and the feature rows of
+// tile j + 1 are requested before tile j's MFMAs.  Same operands, same order of the six terms, same partial rows: bit-identical
+// to the kernel above (tests/test_subm_conv.py).  Two workgroups per CU (two register sets of gathered rows).
+// Measured at A = 144 000 (profiles/subm_run_r06.txt): 1.595 -> 1.493 ms.  With the memory traffic taken out (rows gathered from a
+// handful of addresses: 1.457; no partial stores: 1.297; both: 1.218 ms) the kernel keeps 80 % of its time: it is bound inside the
+// CU -- 96 MFMAs (3 072 matrix cycles) and ~450 vector instructions per wave and tile that two waves per SIMD overlap little -- not
+// by the 3 GB of partial rows.  Built, measured and removed again: the feature rows split into their bf16 terms ONCE per call by a
+// kernel of its own (a row takes part in ~41 pairs) and gathered as three 256-byte pieces -- 1.935 ms: half again as many bytes
+// per gathered row and 244 registers cost more than the ~350 vector instructions per tile saved.
+template <int CIN, int COUT, int SW>
+__global__ __launch_bounds__(256, 2) void gf_subm_gemm_bf16_run_kernel(SubmArgs a)
+{
+    extern __shared__ uint4 s_wb[];  // [3][CIN/16][SW/32][2][32] operands of 16 B
+    constexpr int NC = CIN / 16, NG = SW / 32, NB = CIN / 8, TPB = 256 / SW;
+    static_assert(COUT % SW == 0 && SW % 32 == 0 && CIN % 16 == 0, "unsupported slice");
+    __shared__ unsigned int s_start[kSubmMaxK3 + 1];
+    const unsigned int t = blockIdx.x;
+    const int k = subm_segment_of(a.t.run_start, a.K3, t, s_start);
+    if (t >= s_start[a.K3]) return;  // workgroup-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int c_lo = blockIdx.y * SW;
+    const unsigned int seg_end = a.t.kstart[k + 1];
+    const unsigned int run0 = a.t.kstart[k] + (t - s_start[k]) * (unsigned int)(kGemmRun * kPairTile);   // first slot of the run
+    const int ntiles = (int)min((unsigned int)kGemmRun, (seg_end - run0 + kPairTile - 1) / kPairTile);
+    const unsigned int wslot0 = run0 + wave * 32;   // this wave's first slot in tile 0; tile j: + j kPairTile
+    // pair indices of tiles 0 and 1, feature rows of tile 0: requested before the W slice is converted
+    int row_next = a.pair_in[min(wslot0 + i, seg_end - 1)];                      // (padding lanes repeat the segment's last pair; never stored)
+    int row_next2 = a.pair_in[min(wslot0 + kPairTile + i, seg_end - 1)];
+    constexpr int NA = 2 * NC;   // 16-byte pieces of a gathered row per lane
+    uint4 av[NA];
+    auto gather = [&](uint4 (&dst)[NA], int row) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.feat + (size_t)row * CIN + 8 * h);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { dst[2 * c] = src[4 * c]; dst[2 * c + 1] = src[4 * c + 1]; }
+    };
+    gather(av, row_next);
+    {
+        const float *wsrc = a.weight + (size_t)k * CIN * COUT + c_lo;
+        const int co = tid % SW, g = co >> 5, n = co & 31;
+#pragma unroll
+        for (int blk = tid / SW; blk < NB; blk += TPB) {
+            BF8 w1, w2, w3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split3_bf16(wsrc[(size_t)(8 * blk + j) * COUT + co], w1.e[j], w2.e[j], w3.e[j]);
+            const int idx = (((blk >> 1) * NG + g) * 2 + (blk & 1)) * 32 + n;
+            s_wb[idx] = w1.u;
+            s_wb[NC * NG * 64 + idx] = w2.u;
+            s_wb[2 * NC * NG * 64 + idx] = w3.u;
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < ntiles; ++j) {
+        const unsigned int slot0 = wslot0 + (unsigned int)j * kPairTile;
+        // stage 1: the feature rows of tile j + 1 (its indices arrived during tile j - 1); stage 2: the indices of tile j + 2
+        uint4 an[NA];
+        gather(an, row_next2);
+        const int row_next3 = a.pair_in[min(slot0 + 2 * kPairTile + i, seg_end - 1)];
+        if (slot0 < seg_end) {   // wave-uniform: else this wave's 32 pairs lie past the segment (the last tile of a segment)
+            f32x16 acc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                BF8 a1, a2, a3;
+                const float x[8] = {__uint_as_float(av[2 * c].x), __uint_as_float(av[2 * c].y), __uint_as_float(av[2 * c].z), __uint_as_float(av[2 * c].w),
+                                    __uint_as_float(av[2 * c + 1].x), __uint_as_float(av[2 * c + 1].y), __uint_as_float(av[2 * c + 1].z), __uint_as_float(av[2 * c + 1].w)};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) split3_bf16(x[q], a1.e[q], a2.e[q], a3.e[q]);
+                // (the column groups' chains side by side: a group's six terms keep their order -- small terms first -- but consecutive
+                // MFMAs belong to different accumulators, so none waits for its predecessor's result)
+                BF8 b1[NG], b2[NG], b3[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int idx = ((c * NG + g) * 2 + h) * 32 + i;
+                    b1[g].u = s_wb[idx]; b2[g].u = s_wb[NC * NG * 64 + idx]; b3[g].u = s_wb[2 * NC * NG * 64 + idx];
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.v, b1[g].v, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b3[g].v, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b2[g].v, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b1[g].v, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b2[g].v, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1[g].v, acc[g], 0, 0, 0);
+            }
+            // D layout: column = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h (pair)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned int slot = slot0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (slot < seg_end) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) a.partial[(size_t)slot * COUT + c_lo + 32 * g + i] = acc[g][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NA; ++q) av[q] = an[q];
+        row_next2 = row_next3;
     }
 }
 
@@ -898,9 +1017,19 @@ extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, 
 #undef GF_GEMM
     } else {
         const size_t lds_bf = (size_t)3 * (Cin / 16) * (SW / 32) * 64 * 16;
-#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_bf16_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds_bf, stream, a)
-        GF_SUBM_DISPATCH(GF_GEMM);
+        // long segments (>= 4 runs of kGemmRun tiles per offset on average, by the pair count the caller sized the arrays for): runs of
+        // tiles per workgroup (gf_subm_gemm_bf16_run_kernel); gf_set_option("subm.tile_gemm", 1) keeps one tile per workgroup
+        const bool by_runs = total_pairs / kPairTile >= (long long)K3 * 4 * kGemmRun && option(kOptSubmTileGemm) == 0;
+        if (by_runs) {
+            const dim3 run_grid((unsigned)((total_pairs / kPairTile + K3) / kGemmRun + K3 + 1), Cout / SW);   // x >= the number of runs
+#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_bf16_run_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), run_grid, dim3(256), lds_bf, stream, a)
+            GF_SUBM_DISPATCH(GF_GEMM);
 #undef GF_GEMM
+        } else {
+#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_bf16_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds_bf, stream, a)
+            GF_SUBM_DISPATCH(GF_GEMM);
+#undef GF_GEMM
+        }
     }
     if (Cout == 128) hipLaunchKernelGGL(gf_subm_reduce_kernel<128>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
     else if (Cout == 64) hipLaunchKernelGGL(gf_subm_reduce_kernel<64>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);

@@ -108,12 +108,14 @@ int gf_abi_version(void);
 const char *gf_last_error(void);
 
 /* Library options: process-wide integers set by explicit calls -- the library never reads the environment.  Unknown names
- * return GF_EINVAL.  The product library knows three, all 0 by default, each selecting an alternative kernel kept for comparison
+ * return GF_EINVAL.  The product library knows four, all 0 by default, each selecting an alternative kernel kept for comparison
  * (same results within the documented bounds):
  *   "splat.mfma_tile_kernel"  1: the matrix-core forward runs on the tile kernel (one workgroup per tile) even where the wave
  *                                kernel applies (P <= 39 552); the two are bit-identical
  *   "daf.backward_tiles"      1: gf_daf_backward_sorted accumulates by pixel tiles instead of by image regions
  *   "subm.f32_mfma"           1: gf_subm_conv_apply on the exact-f32 MFMA kernel instead of the 3 x bf16 split
+ *   "subm.tile_gemm"          1: gf_subm_conv_apply's gather-GEMM with one tile of 128 pairs per workgroup also on long segments
+ *                                (>= 32 tiles per offset on average: runs of eight tiles per workgroup otherwise); equal bits
  * A development build (gf_is_development_build() == 1; built by tools/ with -DGF_DEV=1, never shipped as libgf_hip.so) also accepts
  * "dev.*" names for the measured-and-not-kept kernels of earlier rounds. */
 int gf_set_option(const char *name, int value);
@@ -361,7 +363,7 @@ int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const
  * Cin and Cout in {32, 64, 128} (the reference uses 128 -> 128), K odd <= 7.  gf_subm_conv_apply multiplies on the
  * bf16 matrix cores with fp32-EQUIVALENT operands: every fp32 value is split into three bf16 terms and a product is
  * six v_mfma_f32_32x32x16_bf16 partial products accumulated in fp32 (the dropped terms are <= 2^-24 relative each);
- * GF_SUBM_F32_MFMA=1 in the environment selects the f32-MFMA kernel instead (v_mfma_f32_32x32x2_f32: bitwise an fmaf
+ * gf_set_option("subm.f32_mfma", 1) selects the f32-MFMA kernel instead (v_mfma_f32_32x32x2_f32: bitwise an fmaf
  * chain, ~13 % slower).  The weight gradient runs on f32 MFMAs.  Results are deterministic except the weight gradient
  * of segments longer than 512 pairs (float atomics between their chunks).
  */

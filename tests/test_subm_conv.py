@@ -327,6 +327,33 @@ def test_subm_conv_bf16_split_against_f32_mfma(cin, cout):
     assert bool(((split - exact).abs() <= bound).all())
 
 
+@pytest.mark.parametrize("N,shape,cin,cout", [(24000, (40, 40, 16), 128, 128), (9000, (20, 24, 8), 64, 32), (6000, (12, 12, 6), 32, 128)])
+def test_subm_conv_runs_of_tiles_equal_single_tiles(N, shape, cin, cout):
+    """Round 6: on long segments (>= 32 tiles of 128 pairs per offset) the gather-GEMM walks RUNS of eight tiles per workgroup
+    (W slice converted once, two-stage gather pipeline) -- the same operands in the same order as one tile per workgroup
+    (library option "subm.tile_gemm"): equal bits, ragged segment ends and crowded cells included; and both agree with the
+    fp64 definition."""
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.sparse_conv import Rulebook
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    batch, K = 1, 5
+    idx = _points(rng, N, batch, shape)
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(N, cin, generator=g)
+    weight = torch.randn(K ** 3, cin, cout, generator=g) * 0.05
+    rb = Rulebook(idx.to(dev), batch, shape, K)
+    assert rb.total // 128 >= K ** 3 * 32, rb.total                  # the shape does take the run kernel
+    runs = rb.apply(feat.to(dev), weight.to(dev))
+    with _lib.option("subm.tile_gemm", 1):
+        tiles = rb.apply(feat.to(dev), weight.to(dev))
+    assert torch.equal(runs, tiles)
+    if N <= 9000:
+        ref = _dense_reference(feat.double(), idx.long(), weight.double(), batch, shape, K)
+        mag = _dense_reference(feat.double().abs(), idx.long(), weight.double().abs(), batch, shape, K)
+        assert bool(((runs.cpu().double() - ref).abs() <= 2.0 ** -20 * mag + 1e-30).all())
+
+
 def _representative_reference(feat, idx, weight, batch, shape, K):
     """``duplicates="last"`` stated directly (fp64, differentiable): a hash of cell -> the LARGEST point index in it, then
     out[i] = sum_k feat[table[cell(i) + offset_k]] . W[k] -- what spconv's SubMConv3d computes when that duplicate is the
