@@ -685,6 +685,21 @@ def main():
             "roofline": roofline,
         }
         out.update(extras)
+        if use_dist:
+            # the numbers a scaling curve is made of, as flat top-level keys of the line (the nested extras keep the
+            # details): splat kernels alone, the collective's share of a step, and the anchor-sharded END-TO-END frame
+            ko, fs = extras.get("kernel_only"), extras.get("frame_sharded")
+            if isinstance(ko, dict) and "ms_per_step" in ko:
+                out["kernel_only_ms_per_step"] = ko["ms_per_step"]
+                out["collective_ms_per_step"] = max(ms_per_step - ko["ms_per_step"], 0.0)
+                out["kernel_only_value"] = ko["value"]
+            if isinstance(fs, dict):
+                for cfg, key in (("nuscenes_gs25600_solid", "gs25600"), ("nuscenes_gs144000", "gs144000")):
+                    r = fs.get(cfg)
+                    if isinstance(r, dict):
+                        for splat in ("slab", "allreduce"):
+                            if isinstance(r.get(splat), dict):
+                                out[f"frames_per_s_sharded_{key}_{splat}"] = r[splat]["frames_per_s"]
         if single and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(si, pi, mi, radii, cov6)
             try:

@@ -60,6 +60,7 @@ SIGNATURES = {
     "gf_subm_conv_weight_grad": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
     "gf_feature_maps_format": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "gf_head_labels": (_i, [ctypes.c_longlong, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),
+    "gf_daf_fused_forward": (_i, [_i] * 8 + [_vp] * 11),
     "gf_daf_prepare": (_i, [_i] * 6 + [_vp] * 7 + [_vp]),
     "gf_daf_prepare_backward": (_i, [_i] * 6 + [_vp] * 8 + [_vp]),
     "gf_gaussian_prepare": (_i, [_i] * 4 + [_vp, _f, _f, _i, _i] + [_vp] * 8 + [_vp]),

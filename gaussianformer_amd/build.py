@@ -10,7 +10,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libgf_hip.so"
-SOURCES = ["gf_api.hip", "splat_fwd.hip", "splat_bwd.hip", "splat_bwd_mfma.hip", "daf.hip", "gaussian_prepare.hip", "daf_prepare.hip", "head_labels.hip", "feature_format.hip", "subm_conv.hip", "key_points.hip"]
+SOURCES = ["gf_api.hip", "splat_fwd.hip", "splat_bwd.hip", "splat_bwd_mfma.hip", "daf.hip", "gaussian_prepare.hip", "daf_prepare.hip", "daf_fused.hip", "head_labels.hip", "feature_format.hip", "subm_conv.hip", "key_points.hip"]
 HEADERS = ["gf_common.hpp", "splat_fwd_pair.inc", "splat_fwd_solo.inc", os.path.join("..", "..", "include", "gf_hip.h")]
 ARCH = "gfx950"
 # -munsafe-fp-atomics only for the translation units that issue float atomics (hardware fp32 adds without a CAS loop); the

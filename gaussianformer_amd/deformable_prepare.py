@@ -66,3 +66,39 @@ class DeformablePrepareFunction(Function):
 def deformable_prepare(key_points, projection_mat, image_wh, raw_weights, weight_mask=None):
     """Functional form; see :class:`DeformablePrepareFunction`."""
     return DeformablePrepareFunction.apply(key_points, projection_mat, image_wh, raw_weights, weight_mask)
+
+
+def deformable_fused_forward(key_points, projection_mat, image_wh, mc_ms_feat, spatial_shape, scale_start_index,
+                             raw_weights=None, raw_anchor=None, raw_cam=None):
+    """INFERENCE only (no autograd): ``features [bs, A, C]`` of ``DeformableFeatureAggregation.forward`` -- project_points,
+    mask / all_miss / softmax, ``DAF.apply`` and ``features.sum(dim=2)`` (deformable_module.py:174-233,242) -- in ONE launch
+    (``gf_daf_fused_forward``): no ``[A*pts, cams, L, G]`` weights tensor, no ``[A*pts, C]`` sampled features.
+    The attention logits come either as ``raw_weights [bs, A, cams, L, pts, G]`` (the ``weights_fc`` output as the reference
+    reshapes it, :243-253) or -- ``use_camera_embed``, where ``weights_fc`` acts on ``feature + camera_embed`` and is linear
+    (:253-262) -- as its two parts ``raw_anchor [bs, A, L, pts, G]`` and ``raw_cam [bs, cams, L, pts, G]``, added on the fly."""
+    _lib.require_gpu(key_points, projection_mat, image_wh, mc_ms_feat, spatial_shape, scale_start_index, raw_weights, raw_anchor, raw_cam)
+    if any(t is not None and t.requires_grad for t in (key_points, mc_ms_feat, raw_weights, raw_anchor, raw_cam)) and torch.is_grad_enabled():
+        raise RuntimeError("deformable_fused_forward computes no gradients: use deformable_prepare + DeformableAggregationFunction "
+                           "for training, or call it under torch.no_grad()")
+    lib = _lib.load()
+    kp, pm, wh = _c(key_points), _c(projection_mat), _c(image_wh)
+    raw, ra, rc_ = _c(raw_weights), _c(raw_anchor), _c(raw_cam)
+    feat = _c(mc_ms_feat)
+    B, A, pts = kp.shape[:3]
+    cams, num_feat, C = feat.shape[1], feat.shape[2], feat.shape[3]
+    L = spatial_shape.shape[0]
+    if raw is not None:
+        G = raw.shape[5]
+        assert raw.shape == (B, A, cams, L, pts, G) and ra is None and rc_ is None
+    else:
+        G = ra.shape[4]
+        assert ra.shape == (B, A, L, pts, G) and rc_.shape == (B, cams, L, pts, G)
+    assert pm.shape == (B, cams, 4, 4)
+    ss, st = spatial_shape.to(torch.int32).contiguous(), scale_start_index.to(torch.int32).contiguous()
+    out = torch.empty(B, A, C, dtype=f32, device=kp.device)
+    with torch.cuda.device(kp.device):
+        rc = lib.gf_daf_fused_forward(B, A, pts, cams, L, G, C, num_feat, _lib.ptr(kp), _lib.ptr(pm), _lib.ptr(wh), _lib.ptr(raw),
+                                      _lib.ptr(ra), _lib.ptr(rc_), _lib.ptr(feat), _lib.ptr(ss), _lib.ptr(st), _lib.ptr(out),
+                                      _lib.current_stream(kp.device))
+    _lib.check(rc, "gf_daf_fused_forward")
+    return out

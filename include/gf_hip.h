@@ -426,6 +426,25 @@ int gf_splat_forward_labels(int variant, int radii_per_axis, int flags, int P, i
                             void *state, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * (round 6) The deformable aggregation of an INFERENCE frame in one launch: project_points, mask / all_miss / softmax, the
+ * multi-scale bilinear sampling and the sum over the key points (deformable_module.py:174-233,242; ops/src/
+ * deformable_aggregation_cuda.cu:125-187) -- gf_daf_prepare + gf_daf_forward + features.sum(dim=2) without the [A*pts, cams, L, G]
+ * weights tensor and the [A*pts, C] sampled features in between.  No gradients (training keeps the three steps).
+ *   key_points f32 [B,A,pts,3]   projection_mat f32 [B,cams,4,4]   image_wh f32 [B,cams,2] or NULL
+ *   the attention logits, either  raw_weights f32 [B,A,cams,L,pts,G]  (weights_fc output as reshaped at :243-253; the other two NULL)
+ *                        or       raw_anchor f32 [B,A,L,pts,G] + raw_cam f32 [B,cams,L,pts,G]  (use_camera_embed, :253-262: weights_fc
+ *                                 is linear, so its output is the sum of an anchor part and a camera part -- added on the fly here)
+ *   mc_ms_feat / spatial_shape / scale_start_index / num_feat as gf_daf_forward
+ *   out f32 [B,A,C]
+ * G a power of two, pts * cams <= 256, L * G <= 64, C a multiple of 8 G with C / 8 dividing 64.  Equal to the three-step path up to
+ * the order of the sums (~1e-6 of a row's magnitude).
+ */
+int gf_daf_fused_forward(int B, int A, int pts, int cams, int L, int G, int C, int num_feat, const float *key_points,
+                         const float *projection_mat, const float *image_wh, const float *raw_weights, const float *raw_anchor,
+                         const float *raw_cam, const float *mc_ms_feat, const int *spatial_shape, const int *scale_start_index,
+                         float *out, void *stream);
+
+/*
  * Fused caller-side preparation of the deformable aggregation.
  * Replaces, in DeformableFeatureAggregation.forward (model/encoder/gaussian_encoder/deformable_module.py):
  *   project_points :268-285 (4x4 projection, depth clamp 1e-5, image_wh normalisation, visibility mask),

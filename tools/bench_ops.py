@@ -122,8 +122,11 @@ for A in (25600, 144000):
     flops = 2.0 * rb.total * 128 * 128
     report("subm_conv rulebook (count + host read + fill)", f"A={A}", sec, 16 * A + 8 * rb.total, {"pairs": rb.total})
     sec = timed(lambda: rb.apply(feat_sc, w_sc), iters=10)
-    report("subm_conv apply 5^3 128->128 (gather-GEMM + reduce)", f"A={A}", sec, 4 * (2 * rb.total * 128 + 125 * 128 * 128 + 2 * A * 128),
-           {"pairs": rb.total, "TFLOPs": flops / sec / 1e12})
+    # (the COMPULSORY bytes -- features in, rows out, weights, pair indices --, not the partial rows the formulation
+    # writes and re-reads for itself; the op is compute-bound: its bound is the bf16 matrix rate, six MFMA products per fp32 product)
+    report("subm_conv apply 5^3 128->128 (gather-GEMM + reduce)", f"A={A}", sec, 4 * (125 * 128 * 128 + 2 * A * 128) + 4 * rb.total,
+           {"pairs": rb.total, "TFLOPs_fp32_equivalent": flops / sec / 1e12, "frac_of_dense_bf16_peak_2500TFs_at_six_products": 6 * flops / sec / 2.5e15,
+            "self_inflicted_partial_row_MB": 2 * 4 * rb.total * 128 / 1e6})
     go_sc = torch.randn(A, 128, device=dev)
     sec = timed(lambda: rb.weight_grad(feat_sc, go_sc), iters=10)
     report("subm_conv weight gradient", f"A={A}", sec, 4 * (2 * rb.total * 128 + 125 * 128 * 128), {"pairs": rb.total, "TFLOPs": flops / sec / 1e12})
@@ -149,6 +152,44 @@ def projected_inputs(pts):
     vis = float(((loc2 > 0) & (loc2 < 1)).all(-1).float().sum(-1).mean())
     return loc2.contiguous(), w2.contiguous(), vis
 
+
+def fused_case(A):
+    """Round 6: one encoder block's deformable aggregation for INFERENCE -- gf_daf_fused_forward (one launch, the logits in their
+    anchor and camera parts) against what it replaces: the broadcast add of the two parts, gf_daf_prepare, gf_daf_forward and the
+    sum over the key points (deformable_module.py:174-233,242)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_frame
+    from gaussianformer_amd.deformable_prepare import deformable_fused_forward, deformable_prepare
+    g = torch.Generator(device="cpu").manual_seed(1)
+    lo = torch.tensor(bench_frame.PC_RANGE[:3]); hi = torch.tensor(bench_frame.PC_RANGE[3:])
+    centre = lo + (hi - lo) * torch.rand(1, A, 3, generator=g)
+    offs = torch.tensor(bench_frame.FIX_SCALE + [[0.3, 0.3, 0.0], [-0.3, 0.3, 0.0]]) * 0.35
+    kp = (centre[:, :, None] + offs[None, None]).to(dev)
+    pm, wh = bench_frame.cameras(dev)
+    ra = torch.randn(1, A, 4, 9, 4, generator=g).to(dev)
+    rc = torch.randn(1, 6, 4, 9, 4, generator=g).to(dev)
+    d = make_daf_inputs(num_pts=9, seed=0)
+    feat, ss, st = (torch.from_numpy(d[k]).to(dev) for k in ("mc_ms_feat", "spatial_shape", "scale_start_index"))
+
+    def three():
+        raw = (ra[:, :, None] + rc[:, None]).reshape(1, A, 6, 4, 9, 4)
+        loc, w = deformable_prepare(kp, pm, wh, raw)
+        return deformable_aggregation_forward(feat, ss, st, loc, w).reshape(1, A, 9, 128).sum(dim=2)
+    with torch.no_grad():
+        want = three()
+        got = deformable_fused_forward(kp, pm, wh, feat, ss, st, raw_anchor=ra, raw_cam=rc)
+        err = float(((got - want).abs() / want.abs().amax(dim=-1, keepdim=True).clamp(min=1e-3)).max())
+        # compulsory bytes of the block: key points, the two logit parts, the rows of the pyramid it touches (at most all of it), one output row
+        nbytes = 4 * (kp.numel() + ra.numel() + rc.numel() + feat.numel() + A * 128)
+        sec = timed(lambda: deformable_fused_forward(kp, pm, wh, feat, ss, st, raw_anchor=ra, raw_cam=rc))
+        report("daf_fused_forward (projection + softmax + sampling + key-point sum, one launch)", f"A={A}", sec, nbytes,
+               {"anchors": A, "max_row_scaled_diff_vs_three_steps": err})
+        sec = timed(three)
+        report("... the same block in three steps (logit add, gf_daf_prepare, gf_daf_forward, torch sum)", f"A={A}", sec, nbytes, {"anchors": A})
+
+
+for A_ in (25600, 144000):
+    fused_case(A_)
 
 for pts, name in DAF_CASES:
     d = make_daf_inputs(num_pts=pts, seed=0)
