@@ -357,7 +357,9 @@ def main():
                 return None
             plan = SplatForwardPlan(wl.variant, *wl.tensors, si.H, si.W, si.D, flags=_lib.GF_PTS_AUTO | _lib.GF_EXACT_FP32)
             ref_out = wl.plan.run(wl.stream).clone()
+            torch.cuda.synchronize()   # (wl.stream is a raw handle: nothing orders torch's ops behind the launches on it but this)
             got = plan.run(wl.stream)
+            torch.cuda.synchronize()
             err = float(((got - ref_out).abs() / got.abs().clamp(min=1.0)).max())
             err_abs = float((got - ref_out).abs().max())
             for _ in range(max(2, args.warmup // 2)):
@@ -425,7 +427,10 @@ def main():
             # NEVER the headline: `value` above re-verifies the grid in every step.
             plan = SplatForwardPlan(wl.variant, *wl.tensors, si.H, si.W, si.D, flags=_lib.GF_PTS_ASSUME_DENSE)
             ref_out = wl.plan.run(wl.stream).clone()
-            same = bool(torch.equal(plan.run(wl.stream), ref_out))
+            torch.cuda.synchronize()
+            got_v = plan.run(wl.stream)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(got_v, ref_out))
             for _ in range(max(2, args.warmup // 2)):
                 plan.run(wl.stream)
             torch.cuda.synchronize()
