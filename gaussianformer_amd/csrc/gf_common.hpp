@@ -44,9 +44,11 @@ constexpr int kLongWords = 4096;     // ... and the longest rows (P <= 262 144) 
                                      // a unit fetches the non-zero words only (round 6; splat_fwd.hip, "long rows")
 constexpr int kBwdRowDwords = 32;    // matrix-core backward: one 128-B row of partial gradients per (Gaussian, double brick)
 constexpr int kBwdBigRows = 512;     // ... a Gaussian with more rows than this is summed by whole workgroups (big list)
-constexpr int kBwdBigCap = 1024;     // ... waves of 64 Gaussians the layout words provide for (>= kWRow)
+constexpr int kBwdBigCap = 4608;     // ... layout words: one per wave of 64 Gaussians (<= kLongWords), then the table of big Gaussians (splat_bwd_mfma.hip)
 constexpr int kBwdCounters = 5632;   // flag-section index of the matrix-core backward's per-XCD unit counters ([+ 64 x]; the forward's: 4608)
 constexpr int kBwdList = 256;       // candidate-list entries of the matrix-core backward (and of a list the forward publishes for it)
+constexpr int kBwdPubLong = 896;    // ... entries of a list the forward's long-row instantiation publishes (its whole one-pass list; the backward
+                                    // takes it in pieces of kBwdList)
 constexpr int kListsBad = 8101;      // flag-section word: a supertile's list did not fit kBwdList (the backward then scans the bitmask rows itself)
 constexpr int kFusedCounters = 6144; // flag-section index of the fused forward's per-XCD counter blocks ([+ 128 x] dwords = 64 64-bit words each)
 constexpr int kFusedRowMax = 1024;   // bitmask row words up to which a workspace carries the fused forward's per-XCD copies
@@ -92,7 +94,8 @@ struct SplatWorkspace {
     uint32_t *bwd_wave_total;  // [kBwdBigCap] matrix-core backward: rows needed by each wave of 64 Gaussians (bit 31: one needs > kBwdBigRows)
     uint32_t *bwd_row_local;   // [P] ... a Gaussian's offset among its wave's rows (records pass)
     uint32_t *bwd_row_first;   // [P] ... its first row in bwd_rows (0xFFFFFFFF: no room) = prefix of the totals + offset
-    uint32_t *bwd_lists;       // [nsuper][3][kBwdList] ... every supertile's candidate list (ids, packed box lo, packed box hi), published by the forward
+    uint32_t *bwd_lists;       // [nsuper][3][bwd_pub] ... every supertile's candidate list (ids, packed box lo, packed box hi), published by the forward
+    int bwd_pub;               // ... entries per piece: kBwdList, or kBwdPubLong for long rows
     uint32_t *bwd_list_len;    // [nsuper] ... its length
     float *bwd_rows;        // [bwd_cap][32] matrix-core backward: partial gradients per (Gaussian, double brick)
     uint32_t bwd_cap;       // rows available (0: the shape does not take the matrix-core backward)
@@ -139,13 +142,15 @@ inline SplatWorkspace carve_workspace(void *base, int P, int N, int H, int W, in
     // ~13.5), what does not fit is accumulated with atomics instead
     {
         const long long nunits = (long long)ws.nsuper * 4 * ((D + 7) / 8);
-        const long long cap = ws.nrow <= kWRow ? 16ll * P + 2 * nunits + 1024 : 0;
+        // (long rows, round 6: P > 39 552 means smaller Gaussians -- 6 rows each at nuscenes_gs144000 --, ten are provided for)
+        const long long cap = ws.nrow <= kWRow ? 16ll * P + 2 * nunits + 1024 : ws.nwords <= kLongWords ? 10ll * P + 2 * nunits + 1024 : 0;
         ws.bwd_cap = (uint32_t)(cap < (1ll << 31) ? cap : (1ll << 31) - 1);
     }
     ws.bwd_wave_total = (uint32_t *)(p + off); off += align256((size_t)kBwdBigCap * 4);
     ws.bwd_row_local = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? P : 0) * 4);
     ws.bwd_row_first = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? P : 0) * 4);
-    ws.bwd_lists = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? ws.nsuper : 0) * 3 * kBwdList * 4);
+    ws.bwd_pub = ws.nrow <= kWRow ? kBwdList : kBwdPubLong;
+    ws.bwd_lists = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? ws.nsuper : 0) * 3 * ws.bwd_pub * 4);
     ws.bwd_list_len = (uint32_t *)(p + off); off += align256((size_t)(ws.bwd_cap ? ws.nsuper : 0) * 4);
     ws.bwd_rows = (float *)(p + off); off += align256((size_t)ws.bwd_cap * kBwdRowDwords * 4);
     {

@@ -65,8 +65,8 @@ union H8 {
 // The Gaussians with more than kBwdBigRows rows (normally one: the whole-grid "empty" Gaussian), as a table the gradient kernel's
 // zeroing wave leaves for the row-sum kernel: [0] = count (0xFFFFFFFF: more than kBwdBigTable, the row-sum kernel finds them itself),
 // then (Gaussian, first row, rows) triples in ascending Gaussian order.  It lives in the unused tail of the layout words
-// (bwd_wave_total holds kBwdBigCap = 1024 words, the matrix-core backward takes P <= 64 kWRow: 618 of them).
-constexpr int kBwdBigTableAt = 640, kBwdBigTable = (kBwdBigCap - kBwdBigTableAt - 1) / 3;
+// (bwd_wave_total holds kBwdBigCap words; the matrix-core backward takes P <= 64 kLongWords: at most 4 096 of them are layout words).
+constexpr int kBwdBigTableAt = kLongWords, kBwdBigTable = (kBwdBigCap - kBwdBigTableAt - 1) / 3;
 static_assert(kBwdBigTableAt >= kWRow && kBwdBigTable >= 64, "the table sits past the layout words in use");
 
 struct BwdMArgs {
@@ -221,14 +221,16 @@ __device__ __forceinline__ void zero_big_gaussians(const BwdMArgs &a, int lane)
     const int nw = (a.P + 63) >> 6;
     constexpr int kPer = (kWRow + 63) / 64;
     static_assert(kPer == 10, "operand list below");
+    int nbig = 0;   // entries of the table so far (wave-uniform)
+    // (ten layout words per lane and batch -- one batch covers the short rows' 618 waves of Gaussians, long rows take up to seven)
+    for (int kb = 0; 64 * kb < nw; kb += kPer) {
     uint32_t fl[kPer];   // (all loads first, clamped: as `in range ? load : 0` each is a branch with its own round trip)
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) fl[k] = a.wave_total[min(64 * k + lane, nw - 1)];
+    for (int k = 0; k < kPer; ++k) fl[k] = a.wave_total[min(64 * (kb + k) + lane, nw - 1)];
     asm volatile("" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]), "+v"(fl[4]), "+v"(fl[5]), "+v"(fl[6]), "+v"(fl[7]), "+v"(fl[8]), "+v"(fl[9]));
-    int nbig = 0;   // entries of the table so far (wave-uniform)
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const int w0 = 64 * k;
+        const int w0 = 64 * (kb + k);
         const bool f = w0 + lane < nw && (fl[k] >> 31) != 0u;
         unsigned long long m = __builtin_amdgcn_ballot_w64(f);
         while (m) {
@@ -267,11 +269,19 @@ __device__ __forceinline__ void zero_big_gaussians(const BwdMArgs &a, int lane)
             nbig += __builtin_popcountll(bm);
         }
     }
+    }
     if (lane == 0) a.big_table[0] = nbig <= kBwdBigTable ? (uint32_t)nbig : 0xFFFFFFFFu;
 }
 
 // ---------------------------------------------------------------------------------------
-template <bool INTER>   // supertiles dealt to the XCDs round-robin (default) or in contiguous bands: see gf_splat_render_mfma_wave_kernel
+// LONG (round 6): bitmask rows of more than kWRow words (39 552 < P <= 262 144).  A unit never brings such a row into LDS: it takes the
+// list the forward's long-row instantiation published for its supertile (up to kBwdPubLong entries, consumed in pieces of kMList: the
+// next piece is fetched when the list has been filtered -- the record slot is not involved, so nothing is flushed); a supertile
+// whose list was not published (crowded: more than one pass in the forward -- its length word says 0xFFFFFFFF), or a workspace that
+// no longer holds the forward's lists, falls back to the chunked fill below, which reads the row's words from global memory (correct
+// for any row length; ~1 us per 64 words).  Same groups in the same order as the short-row instantiation would form: the arithmetic
+// per (Gaussian, double brick) does not depend on how the list was delivered.
+template <bool INTER, bool LONG = false>   // INTER: supertiles dealt to the XCDs round-robin (default) or in contiguous bands: see gf_splat_render_mfma_wave_kernel
 __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_u[kMLdsDwords];
@@ -348,16 +358,17 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
     // The forward published every supertile's candidate list (GF_PREPARE_BACKWARD) and the workspace still holds it: the unit
     // takes the list -- ids and packed boxes, 3 KB in three requests -- instead of the bitmask row, and skips the row scan and
     // the box round trip (1.7 + ~1 us of a unit's 21.6).
-    const bool use_lists = a.lists && still_there && lbad == 0u;
+    const bool use_lists = a.lists && still_there && (LONG || lbad == 0u);   // (LONG: per supertile, by its length word)
     auto request_unit = [&](int s_, int Xw_, int Y0_, int Zw_) {
         int wl = lane;
         asm volatile("" : "+v"(wl));
         if (use_lists) {
-            const uint32_t *src = a.lists + (size_t)s_ * (3 * kMList) + 4 * wl;
+            const int pstride = LONG ? kBwdPubLong : kMList;   // (compile-time: the short-row instantiation keeps its code)
+            const uint32_t *src = a.lists + (size_t)s_ * (3 * pstride) + 4 * wl;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                __builtin_amdgcn_global_load_lds((gptr)(src + kMList * k), (lptr)(s_lg + kMList * k), 16, 0, 0);
-        } else {
+                __builtin_amdgcn_global_load_lds((gptr)(src + pstride * k), (lptr)(s_lg + kMList * k), 16, 0, 0);
+        } else if (!LONG) {
             request_row(a.bitmask + (size_t)s_ * a.nrow, wl);
         }
         const int per_col = dl_by16 ? 36 : 144, step_off = dl_by16 ? 28 : 64, step_col = dl_by16 ? 1 : 0, fl = dl_by16 ? 4 : 1;
@@ -408,11 +419,14 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
             // ---- candidate list: the forward's, as it landed -- or from the row: the forward's fast path (nonzero words compacted,
             // bits extracted side by side)
             bool have_boxes = false;
-            if (use_lists) {
+            const bool pub_unit = LONG ? (use_lists && published_len != 0xFFFFFFFFu) : use_lists;   // this unit's list came from the forward
+            int pub_done = 0;          // LONG: entries of the published list taken so far
+            bool pub_fetch = false;    // LONG: the next piece has to be fetched (the first one came with the unit's requests)
+            if (pub_unit) {
                 list_len = min((int)published_len, kMList);
                 c = nchunk;
                 have_boxes = true;
-            } else {
+            } else if (!LONG) {
                 constexpr int kWDense = kMList;
                 uint32_t *s_dw = s_u;
                 unsigned long long *s_db = reinterpret_cast<unsigned long long *>(s_u + kWDense);
@@ -644,7 +658,24 @@ __global__ __launch_bounds__(64, 2) void gf_splat_bwd_mfma_kernel(BwdMArgs a)
 #endif
             while (true) {  // fill the list (chunked path only), consume it, until the row is exhausted
                 bool last = false;
-                while (true) {
+                if (LONG && pub_unit) {
+                    if (pub_fetch) {   // the next piece of the published list: ids, box lo, box hi, 256 entries each
+                        int wl = lane;
+                        asm volatile("" : "+v"(wl));
+                        const int e0 = min(pub_done + 4 * wl, kBwdPubLong - 4);   // (a lane past the list's end reads its last entries again: unused)
+                        const uint32_t *src = a.lists + (size_t)s * (3 * kBwdPubLong) + e0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            __builtin_amdgcn_global_load_lds((gptr)(src + kBwdPubLong * k), (lptr)(s_lg + kMList * k), 16, 0, 0);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        list_len = min((int)published_len - pub_done, kMList);
+                        have_boxes = true;
+                    }
+                    pub_done += list_len;
+                    last = pub_done >= (int)published_len;
+                    pub_fetch = true;
+                }
+                while (!(LONG && pub_unit)) {
                     if (c >= nchunk) {
                         last = true;
                         break;
@@ -1125,7 +1156,7 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
     if (bad) return;
     // ---- big Gaussians: 64-row work items, dealt to the workgroups of this range in the same order everywhere.
     __shared__ __attribute__((aligned(16))) float s_part[32][32];
-    __shared__ int s_wave[kBwdBigCap], s_cnt[64];
+    __shared__ int s_wave[kLongWords], s_cnt[64];   // (one flag per wave of 64 Gaussians)
     __shared__ uint32_t s_first[64];
     __shared__ int s_nwave;
     __shared__ uint32_t s_tab[3 * 64];
@@ -1178,22 +1209,22 @@ __global__ __launch_bounds__(256) void gf_splat_bwd_rows_kernel(BwdRowsArgs a)
     // (more big Gaussians than the table holds: every workgroup walks the flagged waves and their Gaussians itself)
     const int nw = (a.P + 63) >> 6;
     {   // (one round trip for all the layout words, then wave 0 compacts the flagged ones in order)
-        uint32_t wt[kBwdBigCap / 256];
+        uint32_t wt[kLongWords / 256];
 #pragma unroll
-        for (int k = 0; k < kBwdBigCap / 256; ++k) wt[k] = a.wave_total[min(tid + 256 * k, nw - 1)];
+        for (int k = 0; k < kLongWords / 256; ++k) wt[k] = a.wave_total[min(tid + 256 * k, nw - 1)];
 #pragma unroll
-        for (int k = 0; k < kBwdBigCap / 256; ++k) s_wave[tid + 256 * k] = (int)(wt[k] >> 31);
+        for (int k = 0; k < kLongWords / 256; ++k) s_wave[tid + 256 * k] = (int)(wt[k] >> 31);
     }
     __syncthreads();
     if (tid < 64) {
         int n = 0;
-        bool fs[kBwdBigCap / 64];
+        bool fs[kLongWords / 64];
 #pragma unroll
-        for (int k = 0; k < kBwdBigCap / 64; ++k) fs[k] = 64 * k + tid < nw && s_wave[64 * k + tid] != 0;
+        for (int k = 0; k < kLongWords / 64; ++k) fs[k] = 64 * k + tid < nw && s_wave[64 * k + tid] != 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();   // (the list below overwrites the flags, front to back, never ahead of what was read)
 #pragma unroll
-        for (int k = 0; k < kBwdBigCap / 64; ++k) {
+        for (int k = 0; k < kLongWords / 64; ++k) {
             const int w0 = 64 * k;
             const bool f = fs[k];
             const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
@@ -1291,7 +1322,8 @@ void launch_splat_backward_mfma(int radii_per_axis, int P, int N, int H, int W, 
     if (dev_option(kOptUnitsBands)) hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<false>, dim3(grid), dim3(64), 0, stream, a);   // (comparison: rounds 3, 4)
     else
 #endif
-    hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
+    if (ws.nrow > kWRow) hipLaunchKernelGGL((gf_splat_bwd_mfma_kernel<true, true>), dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(gf_splat_bwd_mfma_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
     BwdRowsArgs r{ws.records, ws.bwd_rows, means_grad, opa_grad, sem_grad, cov_grad, ws.bwd_wave_total, ws.bwd_row_first, gen_word,
                   ws.bwd_wave_total + kBwdBigTableAt, ws.flags + kBwdCounters, state, (uint32_t)(grid / 8), P, gate, (P + 31) / 32, records_asserted};
     hipLaunchKernelGGL(gf_splat_bwd_rows_kernel, dim3(r.ngauss_blocks + (dev_option(kOptBwdNoBig) ? 0 : 256)), dim3(256), 0, stream, r);

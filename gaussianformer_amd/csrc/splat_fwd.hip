@@ -643,7 +643,8 @@ struct RenderArgs {
 __device__ __forceinline__ void stamp_state(const RenderArgs &a, uint32_t rows_ready = 0u)
 {
     a.state[3] = a.verify_flags[kGenWord - 64];   // (verify_flags = flags + 64)
-    a.state[4] = rows_ready;   // bit 0: every Gaussian's first row is in the workspace and the rows fit the buffer
+    a.state[4] = rows_ready;   // bit 0: every Gaussian's first row is in the workspace and the rows fit the buffer; bit 1: the layout was
+                               // taken and the rows do NOT fit (a caller does better with the Gaussian-major backward then)
 }
 
 // The matrix-core backward's row layout, finished inside the forward: the records pass left the rows each wave of 64 Gaussians
@@ -689,6 +690,56 @@ __device__ __forceinline__ bool finish_row_layout(const RenderArgs &a, uint32_t 
     for (int j = 0; j < kPer; ++j) {
         const int w = (int)blockIdx.x + kRowLayoutBlocks * j, g = 64 * w + lane;
         if (w < nw && g < a.P) a.unit_first[g] = fits ? s_base[w] + loc[j] : 0xFFFFFFFFu;
+    }
+    return fits;
+}
+
+// The same for long rows (kWRow < nwords <= kLongWords waves of Gaussians; round 6): `per` = ceil(nwords / 64) layout words per lane,
+// in batches of twelve loads (as a plain loop every load was a round trip of its own); the prefix of every wave goes to LDS --
+// up to 16 KB: the long-row kernel's whole block is idle at this point --, then workgroup b writes the first rows of the waves
+// b, b + kRowLayoutBlocks, ... (36 of them at P = 144 000).
+__device__ __forceinline__ bool finish_row_layout_long(const RenderArgs &a, uint32_t *s_base, int lane)
+{
+    const int nw = a.nwords;
+    const int per = (nw + 63) >> 6;
+    constexpr int kBatch = 12;
+    uint32_t mine = 0u;
+    for (int k0 = 0; k0 < per; k0 += kBatch) {
+        uint32_t t[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) t[k] = a.unit_totals[min(per * lane + k0 + k, nw - 1)];
+        asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]));
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const int w = per * lane + k0 + k;
+            const uint32_t v = (k0 + k < per && w < nw) ? (t[k] & 0x7FFFFFFFu) : 0u;
+            if (k0 + k < per && w < nw) s_base[w] = mine;   // (the lane's own running sum: the lane's base is added below)
+            mine += v;
+        }
+    }
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)mine);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t base = incl - mine;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < per; ++k) {
+        const int w = per * lane + k;
+        if (w < nw) s_base[w] += base;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool fits = total <= a.unit_cap;
+    const int nj = (nw - (int)blockIdx.x + kRowLayoutBlocks - 1) / kRowLayoutBlocks;   // waves of Gaussians this workgroup writes
+    for (int j0 = 0; j0 < nj; j0 += kBatch) {
+        uint32_t loc[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) loc[j] = a.unit_local[min(64 * ((int)blockIdx.x + kRowLayoutBlocks * (j0 + j)) + lane, a.P - 1)];
+        asm volatile("" : "+v"(loc[0]), "+v"(loc[1]), "+v"(loc[2]), "+v"(loc[3]), "+v"(loc[4]), "+v"(loc[5]), "+v"(loc[6]), "+v"(loc[7]), "+v"(loc[8]), "+v"(loc[9]), "+v"(loc[10]), "+v"(loc[11]));
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int w = (int)blockIdx.x + kRowLayoutBlocks * (j0 + j), g = 64 * w + lane;
+            if (j0 + j < nj && w < nw && g < a.P) a.unit_first[g] = fits ? s_base[w] + loc[j] : 0xFFFFFFFFu;
+        }
     }
     return fits;
 }
@@ -1992,12 +2043,11 @@ static_assert(2 * 64 * kC <= 1536 + 3 * kWList, "output staging fits over the sl
 //   [15872, 16896)  ... the summary row, prefetched (box hi's tail: read before the boxes are fetched)
 //   [17232, 20480)  hit queue, opacity * semantics: as above
 constexpr int kLDense = 576, kLIds = 896;   // (both multiples of 64: the gathers write whole rounds of 64 entries)
-static_assert(2 * kLDense + kLDense / 2 <= 1536 && 1536 + 3 * kLIds <= 3072 + 2 * kWRow && kLDense % 64 == 0 && kLIds % 64 == 0, "LDS map of the long-row instantiation");
+static_assert(2 * kLDense + kLDense / 2 <= 1536 && 1536 + 3 * kLIds <= 3072 + 2 * kWRow && kLDense % 64 == 0 && kLIds % 64 == 0 && kLIds == kBwdPubLong, "LDS map of the long-row instantiation");
 static_assert(kLongWords <= 64 * 64, "one summary bit per word, 64 per lane");
 template <bool LABELS, bool PREP = false, bool INTER = true, bool LONG = false>
 __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(RenderArgs a)
 {
-    static_assert(!(LONG && PREP), "the matrix-core backward takes rows of <= kWRow words");
     __shared__ __attribute__((aligned(16))) uint32_t s_u[kWLdsDwords];
     float4 *slot = reinterpret_cast<float4 *>(s_u);
     constexpr int kListN = LONG ? kLIds : kWList;   // candidate-list entries
@@ -2104,7 +2154,7 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0x), "+v"(q0y), "+v"(q0z), "+v"(q1x), "+v"(q1y), "+v"(q1z)::"memory");   // (landed with the verdict words)
     uint32_t rows_ready = 0u;
     if (PREP && blockIdx.x < (unsigned)kRowLayoutBlocks && a.rows_valid && !verdict)   // (slot area of the LDS block: idle until the first list is built)
-        rows_ready = finish_row_layout(a, s_u, lane) ? 1u : 0u;
+        rows_ready = (LONG ? finish_row_layout_long(a, s_u, lane) : finish_row_layout(a, s_u, lane)) ? 1u : 2u;
     if (blockIdx.x == 0 && lane == 0 && a.state) {
         a.state[0] = (verdict & 1) ? 1u : 0u;
         a.state[1] = verdict ? GF_PATH_ARBITRARY : GF_PATH_MATRIX_CORE_WAVE;
@@ -2496,14 +2546,16 @@ __global__ __launch_bounds__(64, 2) void gf_splat_render_mfma_wave_kernel(Render
                 // or is longer than the backward's list area, raises a flag instead and the backward scans the rows itself.
                 if (PREP && a.rows_valid && r == 0 && !published) {
                     published = true;
-                    if (last && list_len <= kBwdList) {
-                        uint32_t *dst = a.pub_lists + (size_t)s * (3 * kBwdList);
+                    constexpr int kPub = LONG ? kBwdPubLong : kBwdList;   // (long rows: the whole one-pass list; the backward takes it in pieces)
+                    if (last && list_len <= kPub) {
+                        uint32_t *dst = a.pub_lists + (size_t)s * (3 * kPub);
                         for (int i = lane; i < list_len; i += 64) {
-                            dst[i] = s_lg[i]; dst[kBwdList + i] = s_blo[i]; dst[2 * kBwdList + i] = s_bhi[i];
+                            dst[i] = s_lg[i]; dst[kPub + i] = s_blo[i]; dst[2 * kPub + i] = s_bhi[i];
                         }
                         if (lane == 0) a.pub_len[s] = (uint32_t)list_len;
                     } else if (lane == 0) {
-                        atomicOr(const_cast<uint32_t *>(a.verify_flags) + (kListsBad - 64), 1u);
+                        if (LONG) a.pub_len[s] = 0xFFFFFFFFu;   // (this supertile only: its units of the backward read the row themselves)
+                        else atomicOr(const_cast<uint32_t *>(a.verify_flags) + (kListsBad - 64), 1u);
                     }
                 }
 #if GF_TIMELINE
@@ -2947,6 +2999,8 @@ static void launch_render_mfma(const RenderArgs &r, int nsuper, hipStream_t stre
 #endif
     if (kind == 1 && r.nrow > kWRow && r.out_labels)
         hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<true, false, true, true>), dim3(wave_grid), dim3(64), 0, stream, r);
+    else if (kind == 1 && r.nrow > kWRow && r.rows_valid)
+        hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, true, true, true>), dim3(wave_grid), dim3(64), 0, stream, r);
     else if (kind == 1 && r.nrow > kWRow)
         hipLaunchKernelGGL((gf_splat_render_mfma_wave_kernel<false, false, true, true>), dim3(wave_grid), dim3(64), 0, stream, r);
     else if (kind == 1 && r.out_labels)

@@ -382,7 +382,9 @@ class _LocalAggregate(torch.autograd.Function):
         elif ctx.state_event is not None and ctx.state_event.query():
             words = ctx.state_host.tolist()
             on_matrix_cores = words[0] == 0 and words[1] in _lib.GF_PATHS_MATRIX_CORE
-            bflags = _lib.GF_MFMA_SPLAT if on_matrix_cores else _lib.GF_EXACT_FP32
+            # (word 4, bit 1: the forward took the matrix-core backward's row layout and the rows do not fit its buffer -- many
+            # large Gaussians; what does not fit would be added with atomics, tens of times slower than the Gaussian-major kernels)
+            bflags = _lib.GF_MFMA_SPLAT if on_matrix_cores and not (words[4] & 2) else _lib.GF_EXACT_FP32
             # the forward's records pass laid out the backward's rows as well (word 4); if nobody has been handed this stream's
             # workspace since, the backward does not repeat that pass
             if on_matrix_cores and (words[4] & 1) and ctx.ws_stamp == _Workspace.stamp(out_grad.device):

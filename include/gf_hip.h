@@ -87,7 +87,10 @@ extern "C" {
  * forward at P = 25 601 -- so that gf_splat_backward starts with its gradient kernel, whose units read those lists instead of
  * scanning bitmask rows: no records pass, no set-up launch (GF_RECORDS_VALID), 25 us less.  Without it the forward does none of this and
  * the backward prepares everything itself.  Word 4 of the state block, bit 0: the layout is there and every row fits the
- * buffer.  Ignored where the matrix-core backward does not apply. */
+ * buffer; bit 1: the layout was taken and the rows do NOT fit (many large Gaussians: the matrix-core backward would add what does
+ * not fit with atomics -- correct, but the Gaussian-major backward, GF_EXACT_FP32, is the faster one then; the Python module
+ * follows this bit).  Rows of more than 618 words (39 552 < P <= 262 144, round 6) publish a supertile's whole one-pass list (up to
+ * 896 entries).  Ignored where the matrix-core backward does not apply. */
 #define GF_PREPARE_BACKWARD 1024
 /* The caller promises that the workspace's first 32 KB (its flag section) were zero when the workspace was first handed to the
  * library (e.g. allocated with hipMemset / torch.zeros) and have since only been written by the library.  The matrix-core forward

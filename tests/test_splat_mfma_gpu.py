@@ -524,6 +524,44 @@ def test_backward_when_a_supertile_has_more_candidates_than_a_published_list_hol
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config, kw", [
+    ("nuscenes_gs144000", dict(P=50000, H=24, W=24, D=16)),           # crowded supertiles: several passes in the forward, nothing published
+    ("nuscenes_gs144000", dict(P=40000, H=64, W=40, D=8)),            # 626 words: just past the short rows; lists published, in pieces
+    ("nuscenes_gs144000", dict(P=60000, H=96, W=88, D=16)),           # lists of one to four pieces
+    ("nuscenes_gs25600_solid", dict(P=45000, H=72, W=64, D=16)),      # large Gaussians: the rows do not fit the buffer (state word 4, bit 1)
+    ("nuscenes_gs25600_solid", dict(P=45000, H=16, W=16, D=8)),       # a grid of few workgroups: nothing prepared, the backward lays out itself
+])
+def test_backward_on_long_rows(gpu, config, kw):
+    """Round 6: the matrix-core backward on bitmask rows of more than 618 words (39 552 < P <= 262 144, BASELINE config [3]).  The
+    forward's long-row instantiation publishes every supertile's whole one-pass list (up to 896 entries), the backward's units take
+    it in pieces of 256; a supertile that went in several passes publishes nothing and its units read the row's words from memory.
+    Row by row within 1e-3 of the exact Gaussian-major kernels (whose gradients are the reference's, test_ref_parity); the same
+    bits with and without the forward's preparation."""
+    from gaussianformer_amd import _lib
+    from util import assert_grad_rows_close, whole_grid_rows
+    si = make_splat_inputs(config, seed=3, **kw)
+    pi, mi, radii, cov6 = prep(si)
+    g = np.random.default_rng(1).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
+    whole = whole_grid_rows(mi, radii, si.H, si.W, si.D)
+    _, t, state0, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6)
+    plain = _bwd(gpu, si, t, state0, g)                                  # the backward lays its rows out itself, scans the rows
+    exact = _bwd(gpu, si, t, state0, g, flags=_lib.GF_EXACT_FP32)
+    _, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_PREPARE_BACKWARD)
+    words = state.view(torch.int32)[:5].tolist()
+    assert words[0] == 0 and words[1] == _lib.GF_PATH_MATRIX_CORE_WAVE, words
+    prepared = bool(words[4] & 1)
+    assert prepared == (config == "nuscenes_gs144000"), words
+    # "the rows do not fit": the module takes the Gaussian-major backward then
+    assert bool(words[4] & 2) == (not prepared and si.H > 16), words
+    got = _bwd(gpu, si, t, state, g, flags=(_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if prepared else 0)
+    for a, b, c, name in zip(got, plain, exact, ("means", "opacity", "semantics", "cov")):
+        if prepared:   # (rows that do not fit are added with atomics, in no fixed order)
+            assert np.array_equal(a, b), name
+        assert_grad_rows_close(a, c.reshape(a.shape), whole, what=name)
+        assert_grad_rows_close(b, c.reshape(b.shape), whole, what=name + " (unprepared)")
+
+
+@pytest.mark.gpu
 def test_module_training_steps_with_two_aggregators_sharing_the_stream(gpu):
     """A few "training steps" through the autograd module, with a second aggregator call of another shape between a forward and its
     backward (it is handed the same workspace): the module's bookkeeping (workspace stamps, state words on the host) must pass
