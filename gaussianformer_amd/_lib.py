@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GF_LIB selects a development variant built by build.build(lib_name=...) (tools/ only)
 LIB_PATH = os.environ.get("GF_LIB") or os.path.join(_HERE, "csrc", "libgf_hip.so")
 
-GF_ABI_VERSION = 3
+GF_ABI_VERSION = 4
 GF_SPLAT_BASE, GF_SPLAT_PROB = 0, 1
 GF_NUM_CHANNELS = 18
 GF_LABELS_ARGMAX, GF_LABELS_PROB_THRESHOLD, GF_LABELS_PROB_GEOSEM = 0, 1, 2
@@ -57,6 +57,8 @@ SIGNATURES = {
     "gf_subm_rulebook_fill_range": (_i, [_i] * 8 + [_vp] * 4 + [_vp]),
     "gf_subm_rulebook_build_range": (_i, [_i] * 8 + [_vp, _vp, _sz, _vp, _vp, ctypes.c_longlong, _vp]),
     "gf_subm_conv_apply": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
+    "gf_subm_apply_scratch_bytes": (_sz, [_i, _i]),
+    "gf_subm_conv_apply_scratch": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp, _sz, _vp]),
     "gf_subm_conv_weight_grad": (_i, [_i] * 8 + [ctypes.c_longlong] + [_vp] * 6 + [_vp]),
     "gf_feature_maps_format": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "gf_head_labels": (_i, [ctypes.c_longlong, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),

@@ -79,7 +79,7 @@ namespace gf {
 static std::atomic<int> g_options[kOptCount];
 int option(int which) { return which >= 0 && which < kOptCount ? g_options[which].load(std::memory_order_relaxed) : 0; }
 static const struct { const char *name; int which; } kOptionNames[] = {
-    {"splat.mfma_tile_kernel", kOptSplatTileKernel}, {"daf.backward_tiles", kOptDafBackwardTiles}, {"subm.f32_mfma", kOptSubmF32Mfma}, {"subm.tile_gemm", kOptSubmTileGemm},
+    {"splat.mfma_tile_kernel", kOptSplatTileKernel}, {"daf.backward_tiles", kOptDafBackwardTiles}, {"subm.f32_mfma", kOptSubmF32Mfma}, {"subm.tile_gemm", kOptSubmTileGemm}, {"subm.bf16x3", kOptSubmBf16x3},
 #if GF_DEV
     {"dev.splat_pair", kOptSplatPair}, {"dev.splat_solo", kOptSplatSolo}, {"dev.splat_solo_waves", kOptSplatSoloWaves},
     {"dev.splat_fused", kOptSplatFused}, {"dev.splat_fused_why", kOptSplatFusedWhy}, {"dev.units_bands", kOptUnitsBands},

@@ -19,6 +19,7 @@ enum Option {
     kOptDafBackwardTiles,      // "daf.backward_tiles": gf_daf_backward_sorted by pixel tiles (round 1) instead of by image regions
     kOptSubmF32Mfma,           // "subm.f32_mfma": gf_subm_conv_apply on the exact-f32 MFMA kernel instead of the 3 x bf16 split
     kOptSubmTileGemm,          // "subm.tile_gemm": gf_subm_conv_apply's gather-GEMM with one tile per workgroup also where runs of tiles apply
+    kOptSubmBf16x3,            // "subm.bf16x3": gf_subm_conv_apply_scratch on the three-term bf16 split (six products) instead of two f16 terms (three)
     kOptProductCount,
     // development build only (GF_DEV)
     kOptSplatPair = kOptProductCount, kOptSplatSolo, kOptSplatSoloWaves, kOptSplatFused, kOptSplatFusedWhy, kOptUnitsBands, kOptPrepWaves,

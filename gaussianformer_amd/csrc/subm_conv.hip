@@ -591,6 +591,235 @@ __global__ __launch_bounds__(256, 2) void gf_subm_gemm_bf16_run_kernel(SubmArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Round 6, second half: fp32-equivalent operands as TWO f16 terms (hi + lo, 11 + 11 significant bits) and THREE products per
+// fp32 product (lo hi + hi lo + hi hi; the dropped lo lo is <= 2^-22 |ab|) instead of three bf16 terms and six products: the
+// gather-GEMM above is bound by its six MFMAs per product (0.83 of 1.49 ms at 144 000 anchors, §3.7), and the matrix cores run
+// f16 at the bf16 rate.  What f16 lacks is range, so both operands are scaled by powers of two -- exactly, and undone exactly:
+//   * a feature row is multiplied by 2^e with its largest |x| brought to [2^14, 2^15): the hi term has 11 significant bits, the
+//     lo term = x 2^e - hi another 11 unless it falls below f16's smallest normal (elements 2^17 times smaller than the row's
+//     largest; the absolute error of such an element is <= 2^-25 where the row's largest is 2^14, i.e. 2^-39 of it).  Scaling a
+//     ROW of the A operand is scaling the row of the product: a partial row is the accumulator times 2^-(e_row + e_col);
+//   * a column of the W slice likewise (one exponent per output channel and offset).
+// The rows are split ONCE per call by gf_subm_split_rows_kernel (a row takes part in ~41 pairs) into scratch the caller
+// provides -- [hi CIN x f16][lo CIN x f16] per row, the same 4 CIN bytes the fp32 row has, and the row's exponent -- so the
+// gather brings MFMA operands (16 bytes = 8 channels of one term) and the GEMM's vector work per tile is the epilogue.  With
+// bf16 this was built and lost (three terms = half again as many gathered bytes); two f16 terms are the fp32 row's bytes.
+// Error of a product ~ 2^-21 relative (measured against the fp64 definition in tests/test_subm_conv.py, same 3e-5 bound).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+union HF8 {
+    f16x8 v;
+    _Float16 e[8];
+    uint4 u;
+};
+
+// exponent e with |x| 2^e in [2^14, 2^15) (x a finite non-zero normal; zero, denormals, inf and NaN get the nearest end of the range)
+__device__ __forceinline__ int subm_scale_exp(float amax)
+{
+    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    const int E = eb == 0 ? -126 : eb == 255 ? 127 : eb - 127;
+    return 14 - E;
+}
+__device__ __forceinline__ void split2_f16(float x, int e, _Float16 &hi, _Float16 &lo)
+{
+    const float xs = ldexpf(x, e);
+    hi = (_Float16)xs;
+    lo = (_Float16)(xs - (float)hi);
+}
+
+// rows16: [N][2][CIN/8] 16-byte pieces (hi terms, then lo terms); row_exp: [N].  CIN / 8 threads per row.
+template <int CIN>
+__global__ __launch_bounds__(256) void gf_subm_split_rows_kernel(const float *feat, int N, uint4 *rows16, int *row_exp)
+{
+    constexpr int TPR = CIN / 8;   // threads per row: 4, 8 or 16
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int row = tid / TPR, q = tid % TPR;
+    const int rc = min(row, N - 1);
+    const float4 *src = reinterpret_cast<const float4 *>(feat + (size_t)rc * CIN + 8 * q);
+    const float4 v0 = src[0], v1 = src[1];
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[j]));   // (fmaxf drops a NaN: a NaN element still reaches the operands as a NaN)
+#pragma unroll
+    for (int d = 1; d < TPR; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+    const int e = subm_scale_exp(m);
+    HF8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split2_f16(x[j], e, hi.e[j], lo.e[j]);
+    if (row < N) {
+        rows16[(size_t)row * (2 * TPR) + q] = hi.u;
+        rows16[(size_t)row * (2 * TPR) + TPR + q] = lo.u;
+        if (q == 0) row_exp[row] = e;
+    }
+}
+
+struct SubmSplit {
+    const uint4 *rows16;   // gf_subm_split_rows_kernel's output
+    const int *row_exp;
+};
+
+// W slice -> LDS as two f16 terms in B-operand order ([term][chunk][32-column group][K half][column] x 8 f16), one exponent per
+// column of the slice (s_ecol).  A thread converts 8 consecutive input channels of one output column at a time; the TPB threads
+// of a column agree on its largest |w| through s_cmax.
+template <int CIN, int COUT, int SW>
+__device__ __forceinline__ void subm_stage_w_f16(const float *wsrc, uint4 *s_wb, float *s_cmax, int *s_ecol)
+{
+    constexpr int NC = CIN / 16, NG = SW / 32, NB = CIN / 8, TPB = 256 / SW, PER = (NB + TPB - 1) / TPB;
+    const int tid = threadIdx.x, co = tid % SW, g = co >> 5, n = co & 31, b0 = tid / SW;
+    float w[PER][8];
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int blk = min(b0 + TPB * u, NB - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            w[u][j] = wsrc[(size_t)(8 * blk + j) * COUT + co];
+            m = fmaxf(m, fabsf(w[u][j]));
+        }
+    }
+    s_cmax[b0 * SW + co] = m;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < TPB; ++u) m = fmaxf(m, s_cmax[u * SW + co]);
+    const int e = subm_scale_exp(m);
+    if (b0 == 0) s_ecol[co] = e;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int blk = b0 + TPB * u;
+        if (blk < NB) {
+            HF8 w1, w2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split2_f16(w[u][j], e, w1.e[j], w2.e[j]);
+            const int idx = (((blk >> 1) * NG + g) * 2 + (blk & 1)) * 32 + n;
+            s_wb[idx] = w1.u;
+            s_wb[NC * NG * 64 + idx] = w2.u;
+        }
+    }
+    __syncthreads();
+}
+
+// one tile's MFMAs and partial rows: av = [chunk][hi, lo] operands of this lane's pair, er = its row exponent
+template <int CIN, int COUT, int SW>
+__device__ __forceinline__ void subm_tile_f16(const SubmArgs &a, const uint4 (&av)[CIN / 8], int er, const uint4 *s_wb, const int *s_ecol,
+                                              unsigned int slot0, unsigned int seg_end, int c_lo, int i, int h)
+{
+    constexpr int NC = CIN / 16, NG = SW / 32;
+    f32x16 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        HF8 ah, al, bh[NG], bl[NG];
+        ah.u = av[2 * c]; al.u = av[2 * c + 1];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int idx = ((c * NG + g) * 2 + h) * 32 + i;
+            bh[g].u = s_wb[idx]; bl[g].u = s_wb[NC * NG * 64 + idx];
+        }
+        // (small terms first; the column groups' chains side by side, as in the bf16 kernels)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh[g].v, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl[g].v, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh[g].v, acc[g], 0, 0, 0);
+    }
+    int ec[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) ec[g] = s_ecol[32 * g + i];
+    // D layout: column = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h (pair); the row's exponent sits in lane `row`
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int e_row = __shfl(er, rho);
+        const unsigned int slot = slot0 + rho;
+        if (slot < seg_end) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) a.partial[(size_t)slot * COUT + c_lo + 32 * g + i] = ldexpf(acc[g][r], -(e_row + ec[g]));
+        }
+    }
+}
+
+template <int CIN, int COUT, int SW, int MINB = 3>
+__global__ __launch_bounds__(256, MINB) void gf_subm_gemm_f16_kernel(SubmArgs a, SubmSplit sp)
+{
+    extern __shared__ uint4 s_wb[];  // [2][CIN/16][SW/32][2][32] operands of 16 B
+    constexpr int NC = CIN / 16;
+    static_assert(COUT % SW == 0 && SW % 32 == 0 && CIN % 16 == 0, "unsupported slice");
+    __shared__ unsigned int s_start[kSubmMaxK3 + 1];
+    __shared__ float s_cmax[256];
+    __shared__ int s_ecol[SW];
+    const unsigned int t = blockIdx.x;
+    const int k = subm_segment_of(a.t.tile_start, a.K3, t, s_start);
+    if (t >= s_start[a.K3]) return;  // workgroup-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int c_lo = blockIdx.y * SW;
+    const unsigned int slot0 = a.t.kstart[k] + (t - s_start[k]) * kPairTile + wave * 32;
+    const unsigned int seg_end = a.t.kstart[k + 1];
+    const int row = a.pair_in[min(slot0 + i, seg_end - 1)];  // padding lanes repeat the segment's last pair; never stored
+    const uint4 *src = sp.rows16 + (size_t)row * (CIN / 4);
+    uint4 av[2 * NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { av[2 * c] = src[2 * c + h]; av[2 * c + 1] = src[CIN / 8 + 2 * c + h]; }
+    const int er = sp.row_exp[row];
+    subm_stage_w_f16<CIN, COUT, SW>(a.weight + (size_t)k * CIN * COUT + c_lo, s_wb, s_cmax, s_ecol);
+    if (slot0 >= seg_end) return;  // wave-uniform: this wave's 32 pairs lie past the segment
+    subm_tile_f16<CIN, COUT, SW>(a, av, er, s_wb, s_ecol, slot0, seg_end, c_lo, i, h);
+}
+
+// ... and in runs of kGemmRun tiles on long segments (gf_subm_gemm_bf16_run_kernel's pipeline: indices two tiles ahead, rows one)
+template <int CIN, int COUT, int SW>
+__global__ __launch_bounds__(256, 2) void gf_subm_gemm_f16_run_kernel(SubmArgs a, SubmSplit sp)
+{
+    extern __shared__ uint4 s_wb[];
+    constexpr int NC = CIN / 16, NA = 2 * NC;
+    static_assert(COUT % SW == 0 && SW % 32 == 0 && CIN % 16 == 0, "unsupported slice");
+    __shared__ unsigned int s_start[kSubmMaxK3 + 1];
+    __shared__ float s_cmax[256];
+    __shared__ int s_ecol[SW];
+    const unsigned int t = blockIdx.x;
+    const int k = subm_segment_of(a.t.run_start, a.K3, t, s_start);
+    if (t >= s_start[a.K3]) return;  // workgroup-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int c_lo = blockIdx.y * SW;
+    const unsigned int seg_end = a.t.kstart[k + 1];
+    const unsigned int run0 = a.t.kstart[k] + (t - s_start[k]) * (unsigned int)(kGemmRun * kPairTile);   // first slot of the run
+    const int ntiles = (int)min((unsigned int)kGemmRun, (seg_end - run0 + kPairTile - 1) / kPairTile);
+    const unsigned int wslot0 = run0 + wave * 32;   // this wave's first slot in tile 0; tile j: + j kPairTile
+    int row_next = a.pair_in[min(wslot0 + i, seg_end - 1)];                      // (padding lanes repeat the segment's last pair; never stored)
+    int row_next2 = a.pair_in[min(wslot0 + kPairTile + i, seg_end - 1)];
+    uint4 av[NA];
+    auto gather = [&](uint4 (&dst)[NA], int &e, int row) {
+        const uint4 *src = sp.rows16 + (size_t)row * (CIN / 4);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { dst[2 * c] = src[2 * c + h]; dst[2 * c + 1] = src[CIN / 8 + 2 * c + h]; }
+        e = sp.row_exp[row];
+    };
+    int er;
+    gather(av, er, row_next);
+    subm_stage_w_f16<CIN, COUT, SW>(a.weight + (size_t)k * CIN * COUT + c_lo, s_wb, s_cmax, s_ecol);
+    for (int j = 0; j < ntiles; ++j) {
+        const unsigned int slot0 = wslot0 + (unsigned int)j * kPairTile;
+        // (built and measured, round 6: ONE register set of rows at three or four workgroups per CU instead of this pipeline -- 1.52 and
+        // 1.64 against 1.52 ms: more waves do not hide what is a request rate, not a latency)
+        uint4 an[NA];
+        int en;
+        gather(an, en, row_next2);
+        const int row_next3 = a.pair_in[min(slot0 + 2 * kPairTile + i, seg_end - 1)];
+        if (slot0 < seg_end)   // wave-uniform: else this wave's 32 pairs lie past the segment (the last tile of a segment)
+            subm_tile_f16<CIN, COUT, SW>(a, av, er, s_wb, s_ecol, slot0, seg_end, c_lo, i, h);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) av[q] = an[q];
+        er = en;
+        row_next2 = row_next3;
+    }
+}
+
 // out[i] = sum over k ascending of the partial rows of (i, k): COUT/4 lanes per point
 template <int COUT>
 __global__ __launch_bounds__(256) void gf_subm_reduce_kernel(SubmArgs a)
@@ -991,9 +1220,14 @@ extern "C" int gf_subm_rulebook_build_range(int N, int batch, int X, int Y, int 
         else CALL(32, 32);                                            \
     } while (0)
 
-extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
-                                  const float *features, const float *weight, const void *tables, const int *pair_in,
-                                  float *partial, float *out, void *stream_)
+extern "C" size_t gf_subm_apply_scratch_bytes(int N, int Cin)
+{
+    return N > 0 && Cin > 0 ? gf::subm_align((size_t)N * Cin * 4) + gf::subm_align((size_t)N * 4) : 0;
+}
+
+static int subm_conv_apply_impl(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
+                                const float *features, const float *weight, const void *tables, const int *pair_in,
+                                float *partial, float *out, void *scratch, size_t scratch_bytes, void *stream_)
 {
     using namespace gf;
     hipStream_t stream = (hipStream_t)stream_;
@@ -1011,17 +1245,46 @@ extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, 
     const dim3 gemm_grid((unsigned)(total_pairs / kPairTile + K3), Cout / SW);  // x >= the number of tiles, whatever the split over the segments
     const int rows = 256 / (Cout / 4);
     const bool exact_f32 = option(kOptSubmF32Mfma) != 0;  // gf_set_option("subm.f32_mfma", 1): the exact-f32 MFMA kernel
+    // long segments (>= 4 runs of kGemmRun tiles per offset on average, by the pair count the caller sized the arrays for): runs of
+    // tiles per workgroup; gf_set_option("subm.tile_gemm", 1) keeps one tile per workgroup
+    const bool by_runs = total_pairs / kPairTile >= (long long)K3 * 4 * kGemmRun && option(kOptSubmTileGemm) == 0;
+    const dim3 run_grid((unsigned)((total_pairs / kPairTile + K3) / kGemmRun + K3 + 1), Cout / SW);   // x >= the number of runs
     if (exact_f32) {
 #define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds, stream, a)
         GF_SUBM_DISPATCH(GF_GEMM);
 #undef GF_GEMM
+    } else if (scratch && option(kOptSubmBf16x3) == 0) {
+        // two f16 terms, three products (round 6): rows split once into the caller's scratch, then the gather-GEMM on them
+        GF_CHECK_ARG(scratch_bytes >= gf_subm_apply_scratch_bytes(N, Cin) && ((uintptr_t)scratch & 15) == 0, "scratch too small or not 16-byte aligned");
+        SubmSplit sp;
+        uint4 *rows16 = (uint4 *)scratch;
+        int *row_exp = (int *)((char *)scratch + subm_align((size_t)N * Cin * 4));
+        sp.rows16 = rows16; sp.row_exp = row_exp;
+        const unsigned sblocks = (unsigned)(((long long)N * (Cin / 8) + 255) / 256);
+        if (Cin == 128) hipLaunchKernelGGL(gf_subm_split_rows_kernel<128>, dim3(sblocks), dim3(256), 0, stream, features, N, rows16, row_exp);
+        else if (Cin == 64) hipLaunchKernelGGL(gf_subm_split_rows_kernel<64>, dim3(sblocks), dim3(256), 0, stream, features, N, rows16, row_exp);
+        else hipLaunchKernelGGL(gf_subm_split_rows_kernel<32>, dim3(sblocks), dim3(256), 0, stream, features, N, rows16, row_exp);
+        const size_t lds_h = (size_t)2 * (Cin / 16) * (SW / 32) * 64 * 16;
+        // 128 -> 128 (the encoder's layers): ONE workgroup takes all 128 output channels of its pairs -- a row is gathered once instead
+        // of once per 64-channel slice (the gather, not the matrix pipe, is what the f16 kernels wait for: 1.52 -> 1.15 ms at 144 000
+        // anchors); the same MFMA chains per output element, so the same bits as the 64-channel slices
+        if (Cin == 128 && Cout == 128 && by_runs) {
+            hipLaunchKernelGGL((gf_subm_gemm_f16_run_kernel<128, 128, 128>), dim3(run_grid.x, 1), dim3(256), 2 * lds_h, stream, a, sp);
+        } else if (Cin == 128 && Cout == 128) {
+            hipLaunchKernelGGL((gf_subm_gemm_f16_kernel<128, 128, 128, 2>), dim3(gemm_grid.x, 1), dim3(256), 2 * lds_h, stream, a, sp);
+        } else
+        if (by_runs) {
+#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_f16_run_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), run_grid, dim3(256), lds_h, stream, a, sp)
+            GF_SUBM_DISPATCH(GF_GEMM);
+#undef GF_GEMM
+        } else {
+#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_f16_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds_h, stream, a, sp)
+            GF_SUBM_DISPATCH(GF_GEMM);
+#undef GF_GEMM
+        }
     } else {
         const size_t lds_bf = (size_t)3 * (Cin / 16) * (SW / 32) * 64 * 16;
-        // long segments (>= 4 runs of kGemmRun tiles per offset on average, by the pair count the caller sized the arrays for): runs of
-        // tiles per workgroup (gf_subm_gemm_bf16_run_kernel); gf_set_option("subm.tile_gemm", 1) keeps one tile per workgroup
-        const bool by_runs = total_pairs / kPairTile >= (long long)K3 * 4 * kGemmRun && option(kOptSubmTileGemm) == 0;
         if (by_runs) {
-            const dim3 run_grid((unsigned)((total_pairs / kPairTile + K3) / kGemmRun + K3 + 1), Cout / SW);   // x >= the number of runs
 #define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_bf16_run_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), run_grid, dim3(256), lds_bf, stream, a)
             GF_SUBM_DISPATCH(GF_GEMM);
 #undef GF_GEMM
@@ -1036,6 +1299,24 @@ extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, 
     else hipLaunchKernelGGL(gf_subm_reduce_kernel<32>, dim3((N + rows - 1) / rows), dim3(256), 0, stream, a);
     GF_CHECK_LAUNCH();
     return GF_OK;
+}
+
+extern "C" int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
+                                  const float *features, const float *weight, const void *tables, const int *pair_in,
+                                  float *partial, float *out, void *stream_)
+{
+    return subm_conv_apply_impl(N, batch, X, Y, Z, K, Cin, Cout, total_pairs, features, weight, tables, pair_in, partial, out, nullptr, 0, stream_);
+}
+
+extern "C" int gf_subm_conv_apply_scratch(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
+                                          const float *features, const float *weight, const void *tables, const int *pair_in,
+                                          float *partial, float *out, void *scratch, size_t scratch_bytes, void *stream_)
+{
+    if (N > 0 && !scratch) {
+        gf::set_error("%s: null scratch (gf_subm_apply_scratch_bytes)", __func__);
+        return GF_EINVAL;
+    }
+    return subm_conv_apply_impl(N, batch, X, Y, Z, K, Cin, Cout, total_pairs, features, weight, tables, pair_in, partial, out, scratch, scratch_bytes, stream_);
 }
 
 extern "C" int gf_subm_conv_weight_grad(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout,

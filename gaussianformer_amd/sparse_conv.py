@@ -130,10 +130,14 @@ class Rulebook:
         dev = features.device
         out = torch.empty(self.N, cout, dtype=f32, device=dev)
         partial = torch.empty(max(self.total, 1), cout, dtype=f32, device=dev)
+        # (the rows as two f16 terms under a power-of-two scale per row, split once per call: gf_subm_conv_apply_scratch)
+        nscratch = int(lib.gf_subm_apply_scratch_bytes(self.N, cin))
+        scratch = torch.empty(max(nscratch, 16), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.gf_subm_conv_apply(*self.dims, cin, cout, self.total, _lib.ptr(features), _lib.ptr(weight), _lib.ptr(self.tables),
-                                        _lib.ptr(self.pair_in), _lib.ptr(partial), _lib.ptr(out), _lib.current_stream(dev))
-        _lib.check(rc, "gf_subm_conv_apply")
+            rc = lib.gf_subm_conv_apply_scratch(*self.dims, cin, cout, self.total, _lib.ptr(features), _lib.ptr(weight), _lib.ptr(self.tables),
+                                                _lib.ptr(self.pair_in), _lib.ptr(partial), _lib.ptr(out), _lib.ptr(scratch), nscratch,
+                                                _lib.current_stream(dev))
+        _lib.check(rc, "gf_subm_conv_apply_scratch")
         return out
 
     def weight_grad(self, features, grad_out):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 3   /* 3 (round 6): gf_set_option / gf_get_option / gf_is_development_build, gf_daf_fused_forward; GF_WORKSPACE_ZEROED = one verdict word; workspace without the fused forward's per-XCD copies */
+#define GF_ABI_VERSION 4   /* 4 (round 6, later): gf_subm_conv_apply_scratch / gf_subm_apply_scratch_bytes, option "subm.bf16x3", state word 4 bit 1, long rows in the matrix-core backward; 3 (round 6): gf_set_option / gf_get_option / gf_is_development_build, gf_daf_fused_forward; GF_WORKSPACE_ZEROED = one verdict word; workspace without the fused forward's per-XCD copies */
 
 /* error codes */
 #define GF_OK 0
@@ -118,6 +118,7 @@ const char *gf_last_error(void);
  *   "daf.backward_tiles"      1: gf_daf_backward_sorted accumulates by pixel tiles instead of by image regions
  *   "subm.f32_mfma"           1: gf_subm_conv_apply on the exact-f32 MFMA kernel instead of the 3 x bf16 split
  *   "subm.tile_gemm"          1: gf_subm_conv_apply's gather-GEMM with one tile of 128 pairs per workgroup also on long segments
+ *   "subm.bf16x3"             1: gf_subm_conv_apply_scratch on the three-term bf16 split (six products) instead of two f16 terms (three)
  *                                (>= 32 tiles per offset on average: runs of eight tiles per workgroup otherwise); equal bits
  * A development build (gf_is_development_build() == 1; built by tools/ with -DGF_DEV=1, never shipped as libgf_hip.so) also accepts
  * "dev.*" names for the measured-and-not-kept kernels of earlier rounds. */
@@ -369,6 +370,13 @@ int gf_feature_maps_format(int planes, int C, int L, const int *hw, float *const
  * gf_set_option("subm.f32_mfma", 1) selects the f32-MFMA kernel instead (v_mfma_f32_32x32x2_f32: bitwise an fmaf
  * chain, ~13 % slower).  The weight gradient runs on f32 MFMAs.  Results are deterministic except the weight gradient
  * of segments longer than 512 pairs (float atomics between their chunks).
+ * gf_subm_conv_apply_scratch (round 6) is the same operator with `scratch` of gf_subm_apply_scratch_bytes(N, Cin) bytes (device,
+ * 16-byte aligned, contents irrelevant before and after the call): the feature rows are split once per call into TWO f16 terms
+ * under an exact power-of-two scale per row (the weight slices likewise, per output column) and a product is THREE
+ * v_mfma_f32_32x32x16_f16 partial products (dropped term <= 2^-22 relative) -- half the matrix-core work of the bf16 form,
+ * ~2^-21 per product instead of 2^-24 (both far inside 3e-5 of the fp64 definition, tests/test_subm_conv.py).  The Python
+ * module calls this one; gf_set_option("subm.bf16x3", 1) makes it take the three-term bf16 kernels (= gf_subm_conv_apply),
+ * "subm.f32_mfma" the exact-f32 MFMA kernel.
  */
 /* (round 5) The block's own preamble -- voxel indices (batch, x, y, z) of the anchor centres, spconv3d_module.py:56-66 -- in one
  * launch instead of a dozen elementwise ops; the same fp32 operations in the same order, each rounded on its own.  `anchor` is
@@ -398,6 +406,10 @@ int gf_subm_rulebook_build_range(int N, int batch, int X, int Y, int Z, int K, i
 int gf_subm_conv_apply(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
                        const float *features, const float *weight, const void *tables, const int *pair_in,
                        float *partial, float *out, void *stream);
+size_t gf_subm_apply_scratch_bytes(int N, int Cin);
+int gf_subm_conv_apply_scratch(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
+                               const float *features, const float *weight, const void *tables, const int *pair_in,
+                               float *partial, float *out, void *scratch, size_t scratch_bytes, void *stream);
 int gf_subm_conv_weight_grad(int N, int batch, int X, int Y, int Z, int K, int Cin, int Cout, long long total_pairs,
                              const float *features, const float *grad_out, const void *tables, const int *pair_in,
                              const int *pair_out, float *grad_weight, void *stream);

@@ -317,14 +317,50 @@ def test_subm_conv_bf16_split_against_f32_mfma(cin, cout):
     mag = _dense_reference(feat.double().abs(), idx.long(), weight.double().abs(), batch, shape, K)
     rb = Rulebook(idx.to(dev), batch, shape, K)
     from gaussianformer_amd import _lib
-    split = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()
+    split = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()     # round 6: two f16 terms under row / column scales, three products
+    with _lib.option("subm.bf16x3", 1):
+        split3 = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()   # three bf16 terms, six products (rounds 2 - 5)
     with _lib.option("subm.f32_mfma", 1):
         exact = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()
-    assert not torch.equal(split, exact)                          # two different kernels did run
-    bound = 2.0 ** -20 * mag + 1e-30        # 16 units of fp32 roundoff of sum |a||b| (a plain bf16 product: 2^-8)
+    assert not torch.equal(split, exact) and not torch.equal(split3, exact) and not torch.equal(split, split3)   # three different kernels did run
+    bound = 2.0 ** -20 * mag + 1e-30        # 16 units of fp32 roundoff of sum |a||b| (a plain bf16 product: 2^-8, a plain f16 one: 2^-11)
     assert bool(((exact - ref).abs() <= bound).all())
+    assert bool(((split3 - ref).abs() <= bound).all())
     assert bool(((split - ref).abs() <= bound).all())
     assert bool(((split - exact).abs() <= bound).all())
+    print("max error in units of 2^-24 sum|a||b|: f16 x 2", float(((split - ref).abs() / (2.0 ** -24 * mag + 1e-300)).max()),
+          "bf16 x 3", float(((split3 - ref).abs() / (2.0 ** -24 * mag + 1e-300)).max()),
+          "f32 mfma", float(((exact - ref).abs() / (2.0 ** -24 * mag + 1e-300)).max()))
+
+
+def test_subm_conv_f16_split_rows_of_extreme_magnitude():
+    """The two-term f16 split scales every feature row and every weight column by an exact power of two: rows of magnitude 1e-30
+    and 1e+30 next to ordinary ones, an all-zero row, a zero weight column and denormal weights give what the f32-MFMA kernel
+    gives, to the same bound."""
+    from gaussianformer_amd import _lib
+    from gaussianformer_amd.sparse_conv import Rulebook
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4)
+    N, batch, shape, K, cin, cout = 900, 1, (10, 9, 6), 3, 64, 64
+    idx = _points(rng, N, batch, shape)
+    g = torch.Generator().manual_seed(10)
+    feat = torch.randn(N, cin, generator=g)
+    feat[::7] *= 1e-30
+    feat[3::7] *= 1e+15
+    feat[5] = 0.0
+    weight = torch.randn(K ** 3, cin, cout, generator=g) * 0.05
+    weight[:, :, 3] = 0.0
+    weight[:, :, 4] *= 1e-36          # denormal-range weights
+    weight[:, :, 5] *= 1e+12
+    ref = _dense_reference(feat.double(), idx.long(), weight.double(), batch, shape, K)
+    mag = _dense_reference(feat.double().abs(), idx.long(), weight.double().abs(), batch, shape, K)
+    rb = Rulebook(idx.to(dev), batch, shape, K)
+    split = rb.apply(feat.to(dev), weight.to(dev)).cpu().double()
+    assert bool(torch.isfinite(split).all())
+    # (column 4: products of 1e-36 weights underflow fp32 in every kernel; judged against fp32's smallest normal)
+    bound = 2.0 ** -20 * mag + 2.0 ** -120
+    assert bool(((split - ref).abs() <= bound).all()), float(((split - ref).abs() / bound).max())
+    assert bool((split[:, 3] == 0).all())
 
 
 @pytest.mark.parametrize("N,shape,cin,cout", [(24000, (40, 40, 16), 128, 128), (9000, (20, 24, 8), 64, 32), (6000, (12, 12, 6), 32, 128)])
@@ -348,6 +384,11 @@ def test_subm_conv_runs_of_tiles_equal_single_tiles(N, shape, cin, cout):
     with _lib.option("subm.tile_gemm", 1):
         tiles = rb.apply(feat.to(dev), weight.to(dev))
     assert torch.equal(runs, tiles)
+    with _lib.option("subm.bf16x3", 1):                              # (the three-term bf16 kernels: the same two organisations)
+        runs3 = rb.apply(feat.to(dev), weight.to(dev))
+        with _lib.option("subm.tile_gemm", 1):
+            tiles3 = rb.apply(feat.to(dev), weight.to(dev))
+    assert torch.equal(runs3, tiles3) and not torch.equal(runs3, runs)
     if N <= 9000:
         ref = _dense_reference(feat.double(), idx.long(), weight.double(), batch, shape, K)
         mag = _dense_reference(feat.double().abs(), idx.long(), weight.double().abs(), batch, shape, K)
