@@ -419,6 +419,33 @@ def main():
                      "algorithmic_bytes": ab, "op_achieved": ab / dt / 1e9, "op_frac": ab / dt / 1e9 / HBM_PEAK_GBS}}
             if note3:
                 r["roofline"]["traffic_note"] = note3
+            # ... and its backward (round 6: the matrix-core backward takes rows of up to 4 096 words), as the autograd module
+            # calls the pair, with the Gaussian-major exact kernels beside it
+            try:
+                from gaussianformer_amd.local_aggregate import splat_backward, splat_forward
+                t3, s3 = w3.tensors, w3.si
+                lg3, _, _, _, st3 = splat_forward(w3.variant, *t3, s3.H, s3.W, s3.D, flags=_lib.GF_PREPARE_BACKWARD)
+                torch.cuda.synchronize()
+                words = st3.view(torch.int32)[:5].tolist()
+                fast = words[0] == 0 and words[1] in _lib.GF_PATHS_MATRIX_CORE and (words[4] & 1)
+                g3 = torch.randn(lg3.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+                tb = {}
+                for name, fl in (("matrix_core", (_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if fast else 0), ("exact_fp32", _lib.GF_EXACT_FP32)):
+                    fn = lambda: splat_backward(w3.variant, *t3, s3.H, s3.W, s3.D, g3, state=st3, flags=fl)
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize()
+                    t9 = time.perf_counter()
+                    for _ in range(steps):
+                        fn()
+                    torch.cuda.synchronize()
+                    tb[name] = (time.perf_counter() - t9) / steps
+                by3 = 128 * w3.P_total + 24 * w3.N + 72 * w3.N + 112 * w3.P_total
+                r["backward"] = {"us_per_call": tb["matrix_core"] * 1e6, "exact_fp32_us_per_call": tb["exact_fp32"] * 1e6,
+                                 "algorithmic_bytes": by3, "frac_of_8TBs": by3 / tb["matrix_core"] / 8e12,
+                                 "forward_prepared_rows": bool(fast), "state_words": words}
+            except Exception as e:  # noqa: BLE001  (an extra must not take the line down)
+                r["backward"] = {"error": repr(e)}
             return r
 
         def verified_once():

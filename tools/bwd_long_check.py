@@ -23,6 +23,14 @@ for cfg, kw in cases:
     fast = words[0] == 0 and words[1] in _lib.GF_PATHS_MATRIX_CORE and (words[4] & 1)
     mc = splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=(_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if fast else 0)
     mc = [x.clone() for x in mc]
+    def timed(fn, n=20):
+        for _ in range(3): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
+    # (timed BEFORE the exact pipeline runs: that one uses the workspace, after which a backward that vouches for the forward's records
+    # -- GF_RECORDS_VALID -- stands down and returns NaN)
+    t_mc = timed(lambda: splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=(_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if fast else 0))
     ex = splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=_lib.GF_EXACT_FP32)
     torch.cuda.synchronize()
     whole = whole_grid_rows(mi, radii, si.H, si.W, si.D)
@@ -30,15 +38,9 @@ for cfg, kw in cases:
     for name, a, b in zip(("means", "opacity", "semantics", "cov"), mc, ex):
         e = grad_row_errors(a.cpu().numpy(), b.cpu().numpy(), whole)
         errs[name] = (round(e["ordinary"], 7), round(e.get("whole_grid", 0.0) or 0.0, 7))
-    def timed(fn, n=20):
-        for _ in range(3): fn()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(n): fn()
-        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
     def fb():
         lg, _, _, _, st = splat_forward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, flags=_lib.GF_PREPARE_BACKWARD)
         return splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=st, flags=(_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if fast else 0)
-    t_mc = timed(lambda: splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=(_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if fast else 0))
     t_ex = timed(lambda: splat_backward(_lib.GF_SPLAT_BASE, *t, si.H, si.W, si.D, g, state=state, flags=_lib.GF_EXACT_FP32))
     t_fb = timed(fb)
     print(cfg, kw, "state", words, "fast", bool(fast), "row errors (ordinary, whole-grid) vs exact:", errs,
