@@ -156,7 +156,7 @@ def main():
     import oracle  # checker side only: host pre-processing restatement + cpu_baseline legs
     from gaussianformer_amd import _lib
     from gaussianformer_amd.local_aggregate import SplatForwardPlan
-    from gaussianformer_amd.sharded import shard_bounds, sharded_splat_forward
+    from gaussianformer_amd.sharded import EXCHANGES, shard_bounds, sharded_splat_forward, sum_across_ranks
     from gaussianformer_amd.synthetic import make_splat_inputs
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,6 +208,7 @@ def main():
 
     class Workload:
         """One frame's Gaussian set (seed 0, identical on every rank), this rank's contiguous shard bound to a plan."""
+        exchange = "all_reduce"   # how the partial grids are summed at N > 1 (sharded.sum_across_ranks); chosen in the warm-up below
 
         def __init__(self, config):
             self.config = config
@@ -247,9 +248,11 @@ def main():
                 return self.plan.run(self.stream)
             if shared_gpu:
                 logits = self.plan.run(self.stream)
-                all_reduce(logits)
+                h = logits.cpu()
+                sum_across_ranks(h, None, Workload.exchange)
+                logits.copy_(h)
                 return logits
-            return sharded_splat_forward(self.local, None, *self.full)
+            return sharded_splat_forward(self.local, None, *self.full, exchange=Workload.exchange)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -272,6 +275,20 @@ def main():
     for _ in range(SETTLE_STEPS + args.warmup):
         wl.step()
     torch.cuda.synchronize()
+
+    # ---- N > 1, still untimed: which exchange sums the partial grids fastest on THIS node (one RCCL all-reduce; chunks sent
+    # straight to their owners over all xGMI links at once, summed there, all-gathered; RCCL's reduce-scatter + all-gather --
+    # sharded.sum_across_ranks).  Ten steps each, max over ranks (so every rank sees the same numbers and takes the same one).
+    exchange_tune = None
+    if use_dist and world > 1:
+        exchange_tune = {}
+        for how in EXCHANGES:
+            Workload.exchange = how
+            exchange_tune[how] = timed(wl.step, 10, 3) / 10 * 1e3
+        Workload.exchange = min(exchange_tune, key=exchange_tune.get)
+        for _ in range(args.warmup):
+            wl.step()
+        torch.cuda.synchronize()
 
     # ---- headline: exactly K steps, nothing else on the stream (no event records: a hipEvent pair costs ~3 us of
     # stream time, which at --steps 20 used to bracket every timed launch)
@@ -712,11 +729,14 @@ def main():
                                    f"grid (N={N} voxel-centre points), bs=1",
                        "P_total": P, "P_per_gpu": P_launch, "N": N, "pts_layout": "auto-detected dense grid",
                        "parallelism": "single GPU" if not use_dist else
-                                      f"the frame's Gaussians in {world} contiguous shards + one all-reduce of the logits "
-                                      f"({'gloo via host copies, shared GPU (test mode)' if shared_gpu else 'RCCL'})"},
+                                      f"the frame's Gaussians in {world} contiguous shards + the sum of the partial logits "
+                                      f"({Workload.exchange}; {'gloo via host copies, shared GPU (test mode)' if shared_gpu else 'RCCL'})"},
             "roofline": roofline,
         }
         out.update(extras)
+        if exchange_tune:
+            out["exchange"] = Workload.exchange
+            out["exchange_autotune_ms_per_step"] = exchange_tune   # ten untimed steps each in the warm-up, max over ranks
         if use_dist:
             # the numbers a scaling curve is made of, as flat top-level keys of the line (the nested extras keep the
             # details): splat kernels alone, the collective's share of a step, and the anchor-sharded END-TO-END frame

@@ -24,10 +24,59 @@ def shard_bounds(P, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def sharded_splat_forward(local_splat, pts, means3D, opacities, semantics, scales, cov3D, group=None):
+EXCHANGES = ("all_reduce", "direct", "reduce_scatter")
+
+
+def sum_across_ranks(t, group=None, how="all_reduce"):
+    """Sum of every rank's ``t`` (contiguous, same shape everywhere), left in ``t`` on every rank.  Three ways to move the
+    46 MB of partial logits:
+
+    ``"all_reduce"``      one RCCL all-reduce (what north_star names; RCCL picks the algorithm -- a ring over the node's
+                          xGMI links is bound by ONE link, 7/4 of the tensor through it);
+    ``"direct"``          the exchange the fully connected xGMI topology suggests: the tensor in ``world``
+                          chunks, chunk j of every rank sent straight to rank j (``all_to_all_single``: ``world - 1``
+                          point-to-point transfers per rank, one per link, all links busy at once), summed there in rank
+                          order by one kernel, and the reduced chunks all-gathered the same way -- 2/world of the tensor per
+                          link instead of a ring's 2 (world - 1)/world through every link in turn; every chunk is reduced by
+                          exactly one rank in a fixed order, so all ranks hold the same bits;
+    ``"reduce_scatter"``  RCCL's own reduce-scatter + all-gather.
+
+    Which one wins is a property of the node and the RCCL build: ``bench.py --gpus N`` times all three in its warm-up and
+    reports the choice.  Sizes that ``world`` does not divide are padded for the chunked forms."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return t
+    if how == "all_reduce":
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+    if how not in EXCHANGES:
+        raise ValueError(f"exchange {how!r}: one of {EXCHANGES}")
+    flat = t.view(-1)
+    n = flat.numel()
+    chunk = (n + world - 1) // world
+    if chunk * world != n:
+        padded = flat.new_zeros(chunk * world)
+        padded[:n] = flat
+    else:
+        padded = flat
+    mine = flat.new_empty(chunk)
+    if how == "direct":
+        recv = flat.new_empty(world * chunk)
+        dist.all_to_all_single(recv, padded, group=group)       # recv[r] = rank r's partial of MY chunk
+        torch.sum(recv.view(world, chunk), dim=0, out=mine)
+    else:
+        dist.reduce_scatter_tensor(mine, padded, op=dist.ReduceOp.SUM, group=group)
+    out = padded if padded is not flat else flat.new_empty(world * chunk)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    flat.copy_(out[:n])
+    return t
+
+
+def sharded_splat_forward(local_splat, pts, means3D, opacities, semantics, scales, cov3D, group=None, exchange="all_reduce"):
     """``local_splat(pts, means3D, opacities, semantics, scales, cov3D) -> logits [N,18]`` is
     the single-GPU op (``local_aggregate.LocalAggregator``); Gaussian arguments carry the
-    leading batch dim of 1 like the reference's.  Returns the full logits on every rank."""
+    leading batch dim of 1 like the reference's.  Returns the full logits on every rank; ``exchange``: how the partial
+    grids are summed (``sum_across_ranks``)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     P = means3D.shape[1]
@@ -35,8 +84,7 @@ def sharded_splat_forward(local_splat, pts, means3D, opacities, semantics, scale
     logits = local_splat(pts, means3D[:, lo:hi], opacities[:, lo:hi], semantics[:, lo:hi], scales[:, lo:hi],
                          cov3D[:, lo:hi])
     if world > 1:
-        logits = logits.contiguous()
-        dist.all_reduce(logits, op=dist.ReduceOp.SUM, group=group)
+        logits = sum_across_ranks(logits.contiguous(), group, exchange)
     return logits
 
 

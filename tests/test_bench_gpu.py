@@ -45,6 +45,8 @@ def test_bench_single_gpu_line(gpu):
     bw = b["splat_backward"]
     assert "error" not in bw and bw["finite"] is True and bw["forward_prepared_rows"] is True
     assert 0 < bw["us_per_call"] < bw["exact_fp32_us_per_call"] * 1.2
+    b3 = g3["backward"]   # round 6: config [3]'s backward on the matrix cores (long rows)
+    assert "error" not in b3 and b3["forward_prepared_rows"] is True and 0 < b3["us_per_call"] < b3["exact_fp32_us_per_call"]
 
 
 def test_bench_two_rank_strong_scaling_path(gpu):
@@ -58,6 +60,9 @@ def test_bench_two_rank_strong_scaling_path(gpu):
     assert b["config"]["P_total"] == 25601 and b["config"]["P_per_gpu"] == 12801      # shard_bounds(25601, 0, 2)
     assert b["check_max_scaled_err_vs_single_device"] <= 1e-4
     assert b["kernel_only"]["ms_per_step"] <= b["ms_per_step"]
+    # round 6: the exchange of the partial grids is chosen in the warm-up among the three of sharded.sum_across_ranks
+    assert b["exchange"] in ("all_reduce", "direct", "reduce_scatter") and set(b["exchange_autotune_ms_per_step"]) == {"all_reduce", "direct", "reduce_scatter"}
+    assert b["exchange"] in b["config"]["parallelism"]
     # round 6: the scaling curve's numbers as flat keys of the line
     assert b["kernel_only_ms_per_step"] == b["kernel_only"]["ms_per_step"] and b["collective_ms_per_step"] >= 0
     for key in ("gs25600", "gs144000"):

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from gaussianformer_amd.sharded import (shard_bounds, sharded_splat_forward, sharded_splat_forward_prob, slab_bounds,
+from gaussianformer_amd.sharded import (EXCHANGES, shard_bounds, sharded_splat_forward, sum_across_ranks, sharded_splat_forward_prob, slab_bounds,
                                         slab_splat_forward, slab_splat_labels)
 from gaussianformer_amd.synthetic import make_splat_inputs
 
@@ -72,6 +72,59 @@ def test_two_rank_sharded_forward_matches_single_rank():
     single = _local_splat_factory(si)(*args).numpy()
     assert np.array_equal(results[0], results[1])          # every rank holds the full grid
     assert np.abs(results[0] - single).max() <= 1e-5 * max(1.0, np.abs(single).max())
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for n in (18 * 96, 1001):                              # a size the world divides, and one it does not (padded chunks)
+        g = torch.Generator().manual_seed(100 + rank)
+        mine = torch.randn(n, generator=g) * (10.0 ** (rank - 1))
+        for how in EXCHANGES:
+            t = mine.clone().view(-1, 1) if n == 1001 else mine.clone().view(96, 18)
+            out = sum_across_ranks(t, None, how)
+            assert out is t                                 # in place, like all_reduce
+            res[(n, how)] = t.reshape(-1).numpy().copy()
+    si, args = _inputs()
+    res["splat"] = sharded_splat_forward(_local_splat_factory(si), *args, exchange="direct").numpy()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchanges_agree(world):
+    """The three ways to sum the partial grids (one all-reduce; chunks sent straight to their owner, summed there in rank order,
+    all-gathered; RCCL's reduce-scatter + all-gather): the same sum on every rank -- bit-identical across ranks for each way
+    (every element is reduced in one place), equal to the fp64 sum to fp32 rounding, and for two ranks (a + b is commutative)
+    bit-identical to each other."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for n in (18 * 96, 1001):
+        exact = sum((torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) * (10.0 ** (r - 1))).double() for r in range(world)).numpy()
+        for how in EXCHANGES:
+            for r in range(1, world):
+                assert np.array_equal(results[0][(n, how)], results[r][(n, how)]), (n, how, r)
+            assert np.abs(results[0][(n, how)] - exact).max() <= 4e-7 * np.abs(exact).max(), (n, how)
+        if world == 2:
+            assert np.array_equal(results[0][(n, "direct")], results[0][(n, "all_reduce")])
+            assert np.array_equal(results[0][(n, "reduce_scatter")], results[0][(n, "all_reduce")])
+    si, args = _inputs()
+    single = _local_splat_factory(si)(*args).numpy()
+    assert np.abs(results[0]["splat"] - single).max() <= 1e-5 * max(1.0, np.abs(single).max())
+    assert all(np.array_equal(results[0]["splat"], results[r]["splat"]) for r in range(1, world))
 
 
 # ---- prob variant: numerator / probability / density add up, 1 - bin multiplies, normalisation afterwards
