@@ -24,3 +24,9 @@ timeout 300 python tools/bench_step.py > $OUT/bench_step_$R.json 2> gpurun_out/b
 timeout 300 python bench.py --config nuscenes_gs144000 --no-cpu-baseline --no-extras > $OUT/bench_gs144000_$R.json 2> gpurun_out/bench_gs144000.err; head -c 400 $OUT/bench_gs144000_$R.json
 # the development build's kernels stay honest (pair / solo / fused against the oracle)
 if [ -f gaussianformer_amd/csrc/libgf_hip_dev.so ]; then GF_LIB=$PWD/gaussianformer_amd/csrc/libgf_hip_dev.so timeout 600 python tools/dev_kernels_check.py 2>&1 | grep -v amdgpu.ids | tail -6 > $OUT/dev_kernels_$R.txt; cat $OUT/dev_kernels_$R.txt; fi
+# round 6, second half: the matrix-core backward on long rows (pair timings + kernel trace), the long-row sweep, the sparse convolution's
+# three gather-GEMM arithmetics side by side
+(timeout 200 python tools/prof_fb.py nuscenes_gs144000; timeout 200 python tools/prof_fb.py nuscenes_gs25600_solid; timeout 300 python tools/bwd_long_check.py) 2>&1 | grep -v amdgpu.ids > $OUT/bwd_long_rows_$R.txt; cut -c1-250 $OUT/bwd_long_rows_$R.txt
+rm -rf gpurun_out/kt_fb; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_fb -- python tools/prof_fb.py nuscenes_gs144000 30 > gpurun_out/kt_fb.log 2>&1; cp $(find gpurun_out/kt_fb -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_fwd_bwd_gs144000_$R.csv; head -5 $OUT/kernel_stats_fwd_bwd_gs144000_$R.csv | cut -c1-140
+timeout 600 python tools/long_rows_sweep.py 16 2>&1 | grep -v amdgpu.ids > $OUT/long_rows_sweep_$R.txt; tail -1 $OUT/long_rows_sweep_$R.txt
+timeout 300 python tools/subm_f16_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/subm_f16_probe_$R.txt; cat $OUT/subm_f16_probe_$R.txt
