@@ -61,6 +61,8 @@ struct SubmArgs {
     int N, batch, X, Y, Z, K, K3, Cin, Cout;
     long long cells;
     long long pair_capacity;  // > 0: the pair arrays hold this many entries; a larger rulebook raises total[1] bit 2 and stays empty
+    int gate;                 // f16 gather-GEMM kernels: 0 = run; 1 = run only if the DEVICE's pair count says "long segments", 2 = only if it
+                              // says "short" (a rulebook sized by a capacity: the host knows an upper bound of the pair count, not the count)
     int out_lo, out_hi;       // output points [out_lo, out_hi): only they get pairs; EVERY point is a neighbour (anchor-sharded frame: a rank
                               // computes its own anchors' rows from the all-gathered set, spconv3d_module.py:10-83 run 1/world times)
 };
@@ -743,9 +745,19 @@ __device__ __forceinline__ void subm_tile_f16(const SubmArgs &a, const uint4 (&a
     }
 }
 
+// "long segments" = at least 4 runs of kGemmRun tiles per offset on average -- by the rulebook's own pair count
+__device__ __forceinline__ bool subm_gate_passes(const SubmArgs &a)
+{
+    if (a.gate == 0) return true;
+    const unsigned long long real = a.t.total[0];
+    const bool long_segments = real / kPairTile >= (unsigned long long)a.K3 * 4 * kGemmRun;
+    return long_segments == (a.gate == 1);
+}
+
 template <int CIN, int COUT, int SW, int MINB = 3>
 __global__ __launch_bounds__(256, MINB) void gf_subm_gemm_f16_kernel(SubmArgs a, SubmSplit sp)
 {
+    if (!subm_gate_passes(a)) return;   // workgroup-uniform
     extern __shared__ uint4 s_wb[];  // [2][CIN/16][SW/32][2][32] operands of 16 B
     constexpr int NC = CIN / 16;
     static_assert(COUT % SW == 0 && SW % 32 == 0 && CIN % 16 == 0, "unsupported slice");
@@ -775,6 +787,7 @@ __global__ __launch_bounds__(256, MINB) void gf_subm_gemm_f16_kernel(SubmArgs a,
 template <int CIN, int COUT, int SW>
 __global__ __launch_bounds__(256, 2) void gf_subm_gemm_f16_run_kernel(SubmArgs a, SubmSplit sp)
 {
+    if (!subm_gate_passes(a)) return;   // workgroup-uniform
     extern __shared__ uint4 s_wb[];
     constexpr int NC = CIN / 16, NA = 2 * NC;
     static_assert(COUT % SW == 0 && SW % 32 == 0 && CIN % 16 == 0, "unsupported slice");
@@ -1268,17 +1281,27 @@ static int subm_conv_apply_impl(int N, int batch, int X, int Y, int Z, int K, in
         // 128 -> 128 (the encoder's layers): ONE workgroup takes all 128 output channels of its pairs -- a row is gathered once instead
         // of once per 64-channel slice (the gather, not the matrix pipe, is what the f16 kernels wait for: 1.52 -> 1.15 ms at 144 000
         // anchors); the same MFMA chains per output element, so the same bits as the 64-channel slices
-        if (Cin == 128 && Cout == 128 && by_runs) {
-            hipLaunchKernelGGL((gf_subm_gemm_f16_run_kernel<128, 128, 128>), dim3(run_grid.x, 1), dim3(256), 2 * lds_h, stream, a, sp);
-        } else if (Cin == 128 && Cout == 128) {
-            hipLaunchKernelGGL((gf_subm_gemm_f16_kernel<128, 128, 128, 2>), dim3(gemm_grid.x, 1), dim3(256), 2 * lds_h, stream, a, sp);
-        } else
-        if (by_runs) {
-#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_f16_run_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), run_grid, dim3(256), lds_h, stream, a, sp)
-            GF_SUBM_DISPATCH(GF_GEMM);
-#undef GF_GEMM
+        // `total_pairs` is an UPPER bound of the pair count when the rulebook was sized by a capacity (pairs_per_point = 64 where the
+        // encoder's 25 600 anchors have 8): deciding by it sent such a call to the run kernel with a fifth of the workgroups the chip
+        // has CUs (74 against 54 us).  So when the bound says "long segments" BOTH organisations are launched and the rulebook's own
+        // count, on the device, lets exactly one of them run (the other's workgroups leave after one load; the tile grid of that
+        // launch is capped at the most tiles a "short" rulebook can have).  A bound that says "short" needs no second launch.
+        SubmArgs a_run = a, a_tile = a;
+        a_run.gate = 1;
+        a_tile.gate = by_runs ? 2 : 0;
+        const bool force_tile = option(kOptSubmTileGemm) != 0;
+        const unsigned tile_blocks = by_runs && !force_tile ? (unsigned)min((long long)gemm_grid.x, (long long)K3 * 4 * kGemmRun + K3) : gemm_grid.x;
+        if (force_tile) a_tile.gate = 0;
+        if (Cin == 128 && Cout == 128) {
+            if (by_runs) hipLaunchKernelGGL((gf_subm_gemm_f16_run_kernel<128, 128, 128>), dim3(run_grid.x, 1), dim3(256), 2 * lds_h, stream, a_run, sp);
+            hipLaunchKernelGGL((gf_subm_gemm_f16_kernel<128, 128, 128, 2>), dim3(tile_blocks, 1), dim3(256), 2 * lds_h, stream, a_tile, sp);
         } else {
-#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_f16_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), gemm_grid, dim3(256), lds_h, stream, a, sp)
+            if (by_runs) {
+#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_f16_run_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), run_grid, dim3(256), lds_h, stream, a_run, sp)
+                GF_SUBM_DISPATCH(GF_GEMM);
+#undef GF_GEMM
+            }
+#define GF_GEMM(CI, CO) hipLaunchKernelGGL((gf_subm_gemm_f16_kernel<CI, CO, (CO >= 64 ? 64 : 32)>), dim3(tile_blocks, gemm_grid.y), dim3(256), lds_h, stream, a_tile, sp)
             GF_SUBM_DISPATCH(GF_GEMM);
 #undef GF_GEMM
         }

@@ -298,6 +298,30 @@ def test_subm_conv_without_host_read():
         tight(x, anchor)
 
 
+@pytest.mark.parametrize("N,cin,cout", [(9000, 128, 128), (9000, 64, 32), (24000, 128, 128), (24000, 32, 64)])
+def test_subm_conv_capacity_rulebook_takes_the_organisation_its_pair_count_asks_for(N, cin, cout):
+    """A rulebook sized by a capacity hands the library an upper bound of its pair count.  Where the bound says "long segments" the
+    gather-GEMM is launched in both organisations (runs of eight tiles; one tile per workgroup) and the rulebook's own count, read
+    on the device, lets exactly one of them write: the same bits as with the exact rulebook -- 9 000 points: bound long, count
+    short; 24 000 points: both long."""
+    from gaussianformer_amd.sparse_conv import Rulebook
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(13)
+    batch, shape, K = 1, (40, 40, 16), 5
+    idx = _points(rng, N, batch, shape).to(dev)
+    g = torch.Generator().manual_seed(6)
+    feat = torch.randn(N, cin, generator=g).to(dev)
+    weight = (torch.randn(K ** 3, cin, cout, generator=g) * 0.05).to(dev)
+    exact = Rulebook(idx, batch, shape, K)
+    roomy = Rulebook(idx, batch, shape, K, pair_capacity=128 * N)
+    long_bound, long_count = (128 * N) // 128 >= K ** 3 * 32, exact.total // 128 >= K ** 3 * 32
+    assert long_bound and long_count == (N == 24000), (exact.total, N)
+    a, b = exact.apply(feat, weight), roomy.apply(feat, weight)
+    assert roomy.check() == exact.total
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    assert float(a.abs().max()) > 0
+
+
 @pytest.mark.parametrize("cin,cout", [(128, 128), (32, 64)])
 def test_subm_conv_bf16_split_against_f32_mfma(cin, cout):
     """The default gather-GEMM (fp32 operands split into three bf16 terms, six bf16 MFMAs per product) against the
