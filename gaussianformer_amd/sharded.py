@@ -66,9 +66,10 @@ def sum_across_ranks(t, group=None, how="all_reduce"):
         torch.sum(recv.view(world, chunk), dim=0, out=mine)
     else:
         dist.reduce_scatter_tensor(mine, padded, op=dist.ReduceOp.SUM, group=group)
-    out = padded if padded is not flat else flat.new_empty(world * chunk)
-    dist.all_gather_into_tensor(out, mine, group=group)
-    flat.copy_(out[:n])
+    # (the partial grid has been sent / reduced: the gathered sum lands where it was -- no second buffer, no copy, when world divides n)
+    dist.all_gather_into_tensor(padded, mine, group=group)
+    if padded is not flat:
+        flat.copy_(padded[:n])
     return t
 
 
