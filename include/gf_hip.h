@@ -177,7 +177,8 @@ int gf_splat_forward(int variant, int radii_per_axis, int flags, int P, int N, i
  *
  * Two implementations.  (1) The Gaussian-major exact-fp32 kernels (every variant, arbitrary points; gradients ~1e-6 of the
  * tensor's maximum from the reference's own kernels).  (2) For the base variant after a forward that one of the matrix-core
- * kernels rendered (word 1 of `state`) and bitmask rows of <= 618 words (P <= 39 552): the voxel-major matrix-core backward --
+ * kernels rendered (word 1 of `state`) and bitmask rows of <= 4 096 words (P <= 262 144; rows of more than 618 words, P > 39 552,
+ * since round 6: they take the forward's published lists in pieces): the voxel-major matrix-core backward --
  * every double brick loads its gradient rows once, the sums over voxels are contractions on the MFMAs (split-f16 operands,
  * fp32 accumulate), per-(Gaussian, brick) partial rows are added up in a fixed order
  * (~1e-5 from the reference; tolerance 1e-3).  Which one applies is device-side knowledge, so by default BOTH pipelines are
@@ -188,7 +189,10 @@ int gf_splat_forward(int variant, int radii_per_axis, int flags, int P, int N, i
  *   GF_RECORDS_VALID  (2) without its records pass and set-up launch: see the flag (pairs with GF_PREPARE_BACKWARD in the forward).
  *   GF_PTS_ASSUME_DENSE / GF_PTS_GENERAL as in the forward (they select (1)'s body; (2) takes its verdict from `state`).
  * State block after a forward: word 0 = pts is not the dense grid, 1 = GF_PATH_*, 2 = verdict bits, 3 = the workspace's
- * generation at that forward, 4 bit 0 = the matrix-core backward's rows are laid out in the workspace and all fit.
+ * generation at that forward, 4 bit 0 = the matrix-core backward's rows are laid out in the workspace and all fit, bit 1 = they
+ * were laid out and do NOT fit.
+ * Limit: P <= 262 144 Gaussians per call (the block prefix of (1) lives in LDS); more is refused with GF_EINVAL -- shard the set
+ * (gradients are per Gaussian: a backward per shard with the same out_grad gives the same rows).  The forward has no such limit.
  */
 int gf_splat_backward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
                       int W, int D, const float *pts, const int *points_int,

@@ -562,6 +562,38 @@ def test_backward_on_long_rows(gpu, config, kw):
 
 
 @pytest.mark.gpu
+def test_forward_and_backward_past_the_longest_rows(gpu):
+    """P > 262 144 (rows of more than 4 096 words): the tile kernel renders (matrix cores), nothing is prepared for a backward; the
+    backward's documented limit is 262 144 Gaussians per call -- more is refused loudly, and a backward per shard of the set gives
+    the rows (gradients are per Gaussian)."""
+    from gaussianformer_amd import _lib
+    si = make_splat_inputs("nuscenes_gs144000", seed=5, P=270000, H=48, W=40, D=8)
+    pi, mi, radii, cov6 = prep(si)
+    g = np.random.default_rng(2).standard_normal((si.pts.shape[0], 18)).astype(np.float32)
+    exact_out, t, state_e, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_EXACT_FP32)
+    out, t, state, _ = hip_splat_forward(gpu, si, pi, mi, radii, cov6, flags=_lib.GF_PREPARE_BACKWARD)
+    words = state.view(torch.int32)[:5].tolist()
+    assert words[0] == 0 and words[1] == _lib.GF_PATH_MATRIX_CORE and (words[4] & 3) == 0, words
+    assert np.abs(out["logits"] - exact_out["logits"]).max() <= 1e-4
+    with pytest.raises(RuntimeError, match="too many Gaussians"):
+        _bwd(gpu, si, t, state, g)
+    # two shards of 135 000: the matrix-core backward (long rows) of each against the exact one
+    import copy
+    for lo, hi in ((0, 135000), (135000, 270000)):
+        sh = copy.copy(si)
+        sh.means3D, sh.opacities, sh.semantics, sh.scales, sh.cov3D = (a[lo:hi] for a in (si.means3D, si.opacities, si.semantics, si.scales, si.cov3D))
+        spi, smi, sradii, scov6 = pi, mi[lo:hi], radii[lo:hi], cov6[lo:hi]
+        _, ts, sts, _ = hip_splat_forward(gpu, sh, spi, smi, sradii, scov6, flags=_lib.GF_PREPARE_BACKWARD)
+        ws = sts.view(torch.int32)[:5].tolist()
+        assert ws[1] == _lib.GF_PATH_MATRIX_CORE_WAVE, ws
+        got = _bwd(gpu, sh, ts, sts, g, flags=(_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if ws[4] & 1 else 0)
+        ex = _bwd(gpu, sh, ts, sts, g, flags=_lib.GF_EXACT_FP32)
+        from util import assert_grad_rows_close
+        for a, b, name in zip(got, ex, ("means", "opacity", "semantics", "cov")):
+            assert_grad_rows_close(a, b.reshape(a.shape), None, what=name)
+
+
+@pytest.mark.gpu
 def test_module_training_steps_with_two_aggregators_sharing_the_stream(gpu):
     """A few "training steps" through the autograd module, with a second aggregator call of another shape between a forward and its
     backward (it is handed the same workspace): the module's bookkeeping (workspace stamps, state words on the host) must pass
