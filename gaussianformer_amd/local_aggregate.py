@@ -278,6 +278,9 @@ class SplatForwardPipeline:
         return logits, self.events[i]
 
 
+BACKWARD_MAX_GAUSSIANS = 262144   # gf_splat_backward's limit per call (include/gf_hip.h)
+
+
 def splat_backward(variant, pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D,
                    H, W, D, logits_grad, fwd_outputs=None, bin_logits_grad=None, density_grad=None,
                    state=None, flags=_lib.GF_PTS_AUTO):
@@ -287,6 +290,18 @@ def splat_backward(variant, pts, points_int, means3D, means3D_int, opacities, se
     Returns ``(means3D_grad, opacity_grad, semantics_grad, cov3D_grad)``."""
     lib = _lib.load()
     _lib.require_gpu(pts, points_int, means3D, means3D_int, opacities, semantics, radii, cov3D, logits_grad)
+    if means3D.shape[0] > BACKWARD_MAX_GAUSSIANS:
+        # gf_splat_backward takes 262 144 Gaussians per call (include/gf_hip.h); the reference has no such limit, and gradients are
+        # per Gaussian: a call per shard with the same out_grad (and the forward's per-point outputs) gives the same rows.  A shard
+        # does not have the forward's records: the Gaussian-major pipeline, whatever the flags asked for.
+        sflags = (flags & (_lib.GF_PTS_ASSUME_DENSE | _lib.GF_PTS_GENERAL)) | _lib.GF_EXACT_FP32
+        parts = []
+        for lo in range(0, means3D.shape[0], BACKWARD_MAX_GAUSSIANS):
+            sl = slice(lo, lo + BACKWARD_MAX_GAUSSIANS)
+            parts.append(splat_backward(variant, pts, points_int, means3D[sl], means3D_int[sl], opacities[sl], semantics[sl],
+                                        radii[sl], cov3D[sl], H, W, D, logits_grad, fwd_outputs=fwd_outputs,
+                                        bin_logits_grad=bin_logits_grad, density_grad=density_grad, state=state, flags=sflags))
+        return tuple(torch.cat(col, dim=0) for col in zip(*parts))
     dev = pts.device
     f32, i32 = torch.float32, torch.int32
     # the same coercions as the forward (the reference calls .contiguous().data<float>() on every backward

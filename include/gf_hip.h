@@ -192,7 +192,8 @@ int gf_splat_forward(int variant, int radii_per_axis, int flags, int P, int N, i
  * generation at that forward, 4 bit 0 = the matrix-core backward's rows are laid out in the workspace and all fit, bit 1 = they
  * were laid out and do NOT fit.
  * Limit: P <= 262 144 Gaussians per call (the block prefix of (1) lives in LDS); more is refused with GF_EINVAL -- shard the set
- * (gradients are per Gaussian: a backward per shard with the same out_grad gives the same rows).  The forward has no such limit.
+ * (gradients are per Gaussian: a backward per shard with the same out_grad gives the same rows; the Python op does so by itself).
+ * The forward has no such limit.
  */
 int gf_splat_backward(int variant, int radii_per_axis, int flags, int P, int N, int C, int H,
                       int W, int D, const float *pts, const int *points_int,

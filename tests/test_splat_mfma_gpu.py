@@ -575,8 +575,9 @@ def test_forward_and_backward_past_the_longest_rows(gpu):
     words = state.view(torch.int32)[:5].tolist()
     assert words[0] == 0 and words[1] == _lib.GF_PATH_MATRIX_CORE and (words[4] & 3) == 0, words
     assert np.abs(out["logits"] - exact_out["logits"]).max() <= 1e-4
-    with pytest.raises(RuntimeError, match="too many Gaussians"):
-        _bwd(gpu, si, t, state, g)
+    whole = _bwd(gpu, si, t, state, g)          # the Python op shards the set for the C entry point (262 144 per call)
+    from gaussianformer_amd.local_aggregate import BACKWARD_MAX_GAUSSIANS
+    assert BACKWARD_MAX_GAUSSIANS < 270000 and all(np.isfinite(a).all() and a.shape[0] == 270000 for a in whole)
     # two shards of 135 000: the matrix-core backward (long rows) of each against the exact one
     import copy
     for lo, hi in ((0, 135000), (135000, 270000)):
@@ -589,8 +590,11 @@ def test_forward_and_backward_past_the_longest_rows(gpu):
         got = _bwd(gpu, sh, ts, sts, g, flags=(_lib.GF_MFMA_SPLAT | _lib.GF_RECORDS_VALID) if ws[4] & 1 else 0)
         ex = _bwd(gpu, sh, ts, sts, g, flags=_lib.GF_EXACT_FP32)
         from util import assert_grad_rows_close
-        for a, b, name in zip(got, ex, ("means", "opacity", "semantics", "cov")):
+        for a, b, w, name in zip(got, ex, whole, ("means", "opacity", "semantics", "cov")):
             assert_grad_rows_close(a, b.reshape(a.shape), None, what=name)
+            # the sharded op's rows are these rows (the exact kernels cut the concatenated boxes into wave ranges by the shard's total:
+            # a box split elsewhere rounds elsewhere, so to rounding, not bit for bit)
+            assert_grad_rows_close(w[lo:hi].reshape(a.shape), b.reshape(a.shape), None, what=name + " (sharded op)", rtol=2e-5)
 
 
 @pytest.mark.gpu
