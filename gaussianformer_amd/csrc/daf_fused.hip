@@ -22,6 +22,20 @@
 // points are not summed last): equal to ~1e-6 of the row's magnitude, tests/test_daf_fused.py holds them to 1e-5.
 #include "gf_common.hpp"
 
+#ifndef GF_FU_UNROLL
+#define GF_FU_UNROLL 1   // levels of a visible pair whose row pieces are in flight together (measured, round 6: 2 -> 126 registers, four waves
+                         // per SIMD, 147 us at 25 600 anchors; 1 with the allocation held to six waves -> 78 registers, 130 us; 4 -> 217 us)
+#endif
+#ifndef GF_FU_MINB
+#define GF_FU_MINB 6     // workgroups (of four waves) per CU the register allocation aims for (7: eight spilled registers, 139 us; 8: 167 us)
+#endif
+#ifndef GF_FU_CPL
+#define GF_FU_CPL 8      // channels per lane
+#endif
+#ifndef GF_FU_SPLIT
+#define GF_FU_SPLIT 0   // experiment: a lane owns channels [4 cv, 4 cv + 4) and [C/2 + 4 cv, + 4) instead of eight consecutive ones
+#endif
+
 namespace gf {
 
 constexpr int kFuMaxPairs = 256;   // pts * cams per anchor (as gf_daf_prepare)
@@ -45,7 +59,7 @@ __device__ __forceinline__ float fu_exp(float x) { return __builtin_amdgcn_exp2f
 
 // one workgroup = 4 waves = 4 consecutive anchors
 template <int CPL>   // channels per lane (8: C = 128 in sixteen lanes)
-__global__ __launch_bounds__(256) void gf_daf_fused_kernel(DafFusedArgs a)
+__global__ __launch_bounds__(256, GF_FU_MINB) void gf_daf_fused_kernel(DafFusedArgs a)
 {
     extern __shared__ float s_dyn[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -75,8 +89,15 @@ __global__ __launch_bounds__(256) void gf_daf_fused_kernel(DafFusedArgs a)
     if (anchor >= nanchor) return;
     const int CV = a.C / CPL;              // lanes per row
     const int sg = lane / CV, cv = lane - sg * CV, nsg = 64 / CV;
+#if GF_FU_SPLIT
+    // (a tap's row as two load instructions of sixteen CONSECUTIVE 16-byte pieces each, instead of two instructions that each touch
+    // every second piece of all four 128-byte lines)
+    const int c0 = cv * 4, c1 = a.C / 2 + cv * 4;
+    const int grp = c0 / (a.C / a.G), grp1 = c1 / (a.C / a.G);
+#else
     const int c0 = cv * CPL;
     const int grp = c0 / (a.C / a.G);
+#endif
     // ---- 1. projection (project_points, deformable_module.py:268-285) and the list of visible pairs
     if (!a.raw)
         for (int i = lane; i < LPG; i += 64) s_anc[i] = a.raw_anchor[anchor * LPG + i];
@@ -139,12 +160,15 @@ __global__ __launch_bounds__(256) void gf_daf_fused_kernel(DafFusedArgs a)
         // (lane % G == g holds group g's maximum and sum; a sampling lane needs those of ITS channel group: lane grp < G has them)
         const float inv_mine = s > 0.f ? 1.f / s : 0.f;
         const float inv = __shfl(inv_mine, grp, 64), mg = __shfl(m, grp, 64);
+#if GF_FU_SPLIT
+        const float inv1 = __shfl(inv_mine, grp1, 64), mg1 = __shfl(m, grp1, 64);
+#endif
         // ---- 3. sampling: lane group sg takes the visible pairs sg, sg + nsg, ...
         for (int v = sg; v < nvis; v += nsg) {
             const int pc = s_list[v], cam = pc & 255;
             const float2 uv = s_uv[(pc >> 8) * a.cams + cam];
             const float *fcam = a.feat + ((size_t)b * a.cams + cam) * a.num_feat * a.C + c0;
-#pragma unroll 2
+#pragma unroll GF_FU_UNROLL
             for (int l = 0; l < a.L; ++l) {
                 const int h = a.spatial_shape[2 * l], w = a.spatial_shape[2 * l + 1];
                 const float h_im = uv.y * h - 0.5f, w_im = uv.x * w - 0.5f;   // deformable_aggregation_cuda.cu:174-175
@@ -159,16 +183,24 @@ __global__ __launch_bounds__(256) void gf_daf_fused_kernel(DafFusedArgs a)
                 float v1[CPL], v2[CPL], v3[CPL], v4[CPL];
 #pragma unroll
                 for (int j = 0; j < CPL; j += 4) {
-                    *reinterpret_cast<float4 *>(v1 + j) = *reinterpret_cast<const float4 *>(base + (size_t)(hc0 * w + wc0) * a.C + j);
-                    *reinterpret_cast<float4 *>(v2 + j) = *reinterpret_cast<const float4 *>(base + (size_t)(hc0 * w + wc1) * a.C + j);
-                    *reinterpret_cast<float4 *>(v3 + j) = *reinterpret_cast<const float4 *>(base + (size_t)(hc1 * w + wc0) * a.C + j);
-                    *reinterpret_cast<float4 *>(v4 + j) = *reinterpret_cast<const float4 *>(base + (size_t)(hc1 * w + wc1) * a.C + j);
+                    const int jo = GF_FU_SPLIT ? (j ? a.C / 2 : 0) : j;   // (split: the second piece lies C/2 channels further)
+                    *reinterpret_cast<float4 *>(v1 + j) = *reinterpret_cast<const float4 *>(base + (size_t)(hc0 * w + wc0) * a.C + jo);
+                    *reinterpret_cast<float4 *>(v2 + j) = *reinterpret_cast<const float4 *>(base + (size_t)(hc0 * w + wc1) * a.C + jo);
+                    *reinterpret_cast<float4 *>(v3 + j) = *reinterpret_cast<const float4 *>(base + (size_t)(hc1 * w + wc0) * a.C + jo);
+                    *reinterpret_cast<float4 *>(v4 + j) = *reinterpret_cast<const float4 *>(base + (size_t)(hc1 * w + wc1) * a.C + jo);
                 }
                 const float wt = fu_exp(logit_at(pc, l, grp) - mg) * inv;
+#if GF_FU_SPLIT
+                const float wt1 = fu_exp(logit_at(pc, l, grp1) - mg1) * inv1;
+#endif
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
                     const float x1 = ok1 ? v1[j] : 0.f, x2 = ok2 ? v2[j] : 0.f, x3 = ok3 ? v3[j] : 0.f, x4 = ok4 ? v4[j] : 0.f;
+#if GF_FU_SPLIT
+                    acc[j] += (w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4) * (j < 4 ? wt : wt1);
+#else
                     acc[j] += (w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4) * wt;
+#endif
                 }
             }
         }
@@ -180,7 +212,8 @@ __global__ __launch_bounds__(256) void gf_daf_fused_kernel(DafFusedArgs a)
     if (sg == 0) {
         float *o = a.out + anchor * a.C + c0;
 #pragma unroll
-        for (int j = 0; j < CPL; j += 4) *reinterpret_cast<float4 *>(o + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+        for (int j = 0; j < CPL; j += 4)
+            *reinterpret_cast<float4 *>(o + (GF_FU_SPLIT ? (j ? a.C / 2 : 0) : j)) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
     }
 }
 
@@ -213,8 +246,8 @@ extern "C" int gf_daf_fused_forward(int B, int A, int pts, int cams, int L, int 
     GF_CHECK_ARG(lds <= 160 * 1024, "shape needs more LDS than a CU has");
     const long long nanchor = (long long)B * A;
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gf_daf_fused_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gf_daf_fused_kernel<8>, dim3((unsigned)((nanchor + 3) / 4)), dim3(256), lds, stream, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gf_daf_fused_kernel<GF_FU_CPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gf_daf_fused_kernel<GF_FU_CPL>, dim3((unsigned)((nanchor + 3) / 4)), dim3(256), lds, stream, a);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }
