@@ -1,14 +1,17 @@
-"""Microbenchmark (GPU box): does a buffer that was just written come back from the Infinity Cache?  Write (copy_ from a small
-source is avoided: fill_) then read (sum) buffers of growing size, back to back.  python tools/microbench/mall_probe.py"""
-import torch, time
+"""Microbenchmark (GPU box): does a buffer that is rewritten in place come back from the Infinity Cache (256 MB)?  x.mul_(c) -- one read and
+one write of every byte -- repeated on buffers of growing size; bytes moved per second by the events around 20 repeats.
+python tools/microbench/mall_probe.py"""
+import torch
 dev = torch.device("cuda:0")
-for mb in (16, 32, 64, 128, 192, 256, 512, 1024, 3072):
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for mb in (16, 32, 64, 96, 128, 192, 256, 384, 512, 1024, 3072):
     n = mb * 1024 * 1024 // 4
-    x = torch.empty(n, device=dev)
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    tw, tr = [], []
-    for it in range(6):
-        e[0].record(); x.fill_(float(it)); e[1].record(); s = x.sum(); e[2].record(); torch.cuda.synchronize()
-        if it >= 2: tw.append(e[0].elapsed_time(e[1])); tr.append(e[1].elapsed_time(e[2]))
-    w, r = min(tw), min(tr)
-    print(f"{mb:5d} MB: write {w*1e3:8.1f} us = {mb/1024/w*1e3/1.024:6.2f} TB/s; read-after-write {r*1e3:8.1f} us = {mb/1024/r*1e3/1.024:6.2f} TB/s", flush=True)
+    x = torch.ones(n, device=dev)
+    for _ in range(3): x.mul_(1.0001)
+    torch.cuda.synchronize()
+    reps = 20
+    e0.record()
+    for _ in range(reps): x.mul_(1.0001)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"{mb:5d} MB in place: {ms * 1e3:8.1f} us per pass = {2 * mb / 1024 / 1.024 / ms:6.2f} TB/s (read + write)", flush=True)
