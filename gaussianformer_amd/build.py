@@ -44,7 +44,11 @@ def build(force=False, verbose=False, extra_flags=(), lib_name=None):
     out_lib = lib_path() if lib_name is None else os.path.join(CSRC, lib_name)
     tag = "" if lib_name is None else "." + os.path.splitext(lib_name)[0]
     objs = []
-    common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+    # -Os, not -O3 (round 6, measured: tools/gpu/os_compare.sh): the persistent splat kernels are instruction streams, and -O3's
+    # unrolling and peeling make them 6 % longer (the wave kernel: 17 048 -> 15 984 bytes) for nothing -- forward 41.0 -> 40.0 us per
+    # step, 83.9 -> 81.2 us at P = 144 000, matrix-core backward 75.2 -> 73.7 us; the gather-bound kernels (deformable aggregation,
+    # sparse convolution) are indifferent; same bits everywhere
+    common = [_hipcc(), f"--offload-arch={ARCH}", "-Os", "-std=c++17", "-fPIC",
               "-Wall", "-Wno-unused-function", "-Wno-inline-asm", *extra_flags]
     procs = []
     for src in SOURCES:

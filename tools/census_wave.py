@@ -46,7 +46,7 @@ phases = [
 ]
 with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
     json.dump(phases, f)
-print("# tools/census_wave.py -- static instruction counts of gf_splat_render_mfma_wave_kernel<false,false,true> (gfx950, -O3) per source")
+print("# tools/census_wave.py -- static instruction counts of gf_splat_render_mfma_wave_kernel<false,false,true> (gfx950, -Os: the product build since the second half of round 6; -O3 before: profiles/census_wave_O3_r06.txt) per source")
 print("# phase, weighted by trips per unit at nuscenes_gs25600_solid.  Cycle weights: VALU 4, transcendental 16 (quarter rate), fp64 8")
 print("# (upper bound: v_fma_f64 issues at full rate on this part).  PMC of the same kernel (profiles/pmc_wave_vs_solo_r05.txt): 8.39 M VALU")
 print("# wave-instructions per launch = 1 680 per unit; SALU 3.86 M = 772 per unit.")

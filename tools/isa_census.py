@@ -1,5 +1,5 @@
 """Static census of a kernel's ISA by source line: compile splat_fwd.hip (or another source) for gfx950 with line tables
-(-gline-tables-only keeps -O3 code generation) and count, per source line of the .hip file, the VALU / transcendental / fp64 /
+(-gline-tables-only keeps the product build's -Os code generation) and count, per source line of the .hip file, the VALU / transcendental / fp64 /
 MFMA / SALU / LDS / vector-memory instructions the kernel's code holds for it.  Lines are then grouped into the PHASES given on the
 command line (name=first-last, in source lines) and weighted by trip counts (name*count) to give instructions per unit of work.
 
@@ -47,7 +47,7 @@ def classify(op):
 
 def assemble(src, extra):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm", "-gline-tables-only",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-Wno-inline-asm", "-gline-tables-only",
            "--cuda-device-only", "-S", src, "-o", out] + extra
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return out

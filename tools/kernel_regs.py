@@ -16,7 +16,7 @@ if "--" in args:
 src = args[0] if args else os.path.join(ROOT, "gaussianformer_amd", "csrc", "splat_fwd.hip")
 sub = args[1] if len(args) > 1 else ""
 out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm", "--cuda-device-only", "-S", src, "-o", out] + extra,
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-Wno-inline-asm", "--cuda-device-only", "-S", src, "-o", out] + extra,
                check=True, stderr=subprocess.DEVNULL)
 t = open(out).read()
 os.unlink(out)

@@ -4,7 +4,7 @@
 set -e
 name=$1; shift
 C=gaussianformer_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm "$@" -c $C/splat_fwd.hip -o $C/splat_fwd.$name.o
+hipcc --offload-arch=gfx950 -Os -std=c++17 -fPIC -Wno-inline-asm "$@" -c $C/splat_fwd.hip -o $C/splat_fwd.$name.o
 objs=""
 for f in gf_api splat_bwd splat_bwd_mfma daf daf_fused gaussian_prepare daf_prepare head_labels feature_format subm_conv key_points; do objs="$objs $C/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libgf_hip_$name.so $C/splat_fwd.$name.o $objs
