@@ -102,7 +102,7 @@ extern "C" {
 /* values of word 1 of the state block after gf_splat_forward: which body rendered the call */
 #define GF_PATH_EXACT_TILE 0     /* exact-fp32 tile kernel (dense grid) */
 #define GF_PATH_MATRIX_CORE 1    /* split-f16 MFMA kernel (dense exact lattice), one workgroup per tile: P > 262 144, or P > 39 552 on a workspace without GF_WORKSPACE_ZEROED */
-#define GF_PATH_MATRIX_CORE_WAVE 3 /* the same arithmetic (equal bits), one wave per double brick: P <= 39 552 */
+#define GF_PATH_MATRIX_CORE_WAVE 3 /* the same arithmetic (equal bits), one wave per double brick: P <= 39 552, and (long-row instantiation, GF_WORKSPACE_ZEROED) P <= 262 144 */
 #define GF_PATH_MATRIX_CORE_PAIR 4 /* development build only (gf_is_development_build): round 5's two-waves-per-double-brick kernel -- measured, NOT the default, not in the product library */
 #define GF_PATH_MATRIX_CORE_SOLO 5 /* development build only: round 5's single-wave kernel with the opacity in the exponent -- measured, NOT the default, not in the product library */
 #define GF_PATH_ARBITRARY 2      /* arbitrary-points body (pts not the dense grid, or a failed lattice / range verdict) */
